@@ -1,0 +1,156 @@
+/*
+ * sparkmi.h -- C ABI of libsparkmi.so: the MI355X (gfx950) Spark-TTS inference hot path.
+ *
+ * The reference (arghyasur1991/Spark-TTS) is pure Python and has no FFI of its own; its seams
+ * for this path are Python call sites.  Each entry point below names the reference call it
+ * stands behind, so a maintainer can bind it (ctypes stub in INTEGRATION.md):
+ *
+ *   smi_llm_*   <- AutoModelForCausalLM.generate(...)            cli/SparkTTS.py:197-204
+ *                  (Qwen2 forward: transformers modeling_qwen2.py, pinned 4.46.2 at requirements.txt:12)
+ *   smi_voc_*   <- BiCodec.detokenize(semantic, global)          sparktts/models/bicodec.py:171-189
+ *                  via BiCodecTokenizer.detokenize               sparktts/models/audio_tokenizer.py:132-146
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch types.  Every function returns an int:
+ *     0 = SMI_OK, negative = SMI_E*.  smi_last_error() returns a thread-local message.
+ *   - "dev" pointers are device (HBM) addresses on the current HIP device, "host" pointers are
+ *     ordinary host memory.  `stream` is a hipStream_t passed as void* (0 = default stream).
+ *   - The caller owns the weight arenas (they must outlive the handle).  The library owns the
+ *     handle, its KV cache and scratch (allocated at create, freed at destroy).
+ *   - A handle is bound to the device current at create and may be used by one host thread at
+ *     a time.  All launches go to the caller's stream; nothing synchronises unless stated.
+ *   - There is no CPU fallback anywhere behind this ABI.
+ */
+#ifndef SPARKMI_H
+#define SPARKMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMI_OK 0
+#define SMI_EINVAL (-1)   /* bad argument / shape outside the kernel contract */
+#define SMI_EHIP (-2)     /* a HIP runtime call failed (message has hipGetErrorString) */
+#define SMI_ENOMEM (-3)   /* device allocation failed */
+#define SMI_ESTATE (-4)   /* call sequence violated (e.g. decode before prefill) */
+
+#define SMI_ABI_VERSION 1
+#define SMI_MAX_ROWS 32   /* rows (= concurrent sequences, or prompt tokens per prefill chunk) per step */
+
+int smi_version(void);
+const char* smi_last_error(void);
+/* Fills name[0..n) with the device's gcnArchName; fails unless it is a gfx950 part. */
+int smi_device_check(char* name, int n);
+
+/* ------------------------------------------------------------------------------------------
+ * LLM: Qwen2 decoder-only LM, greedy generation with a KV cache.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct smi_llm smi_llm;
+
+typedef struct smi_llm_cfg {
+  int32_t vocab_size;        /* config.json: vocab_size */
+  int32_t hidden_size;       /* multiple of 32 */
+  int32_t num_layers;
+  int32_t num_heads;         /* query heads */
+  int32_t num_kv_heads;
+  int32_t head_dim;          /* must be 64 */
+  int32_t intermediate_size; /* multiple of 32 */
+  int32_t max_slots;         /* concurrent sequences, 1..SMI_MAX_ROWS */
+  int32_t max_positions;     /* tokens (prompt + generated) per sequence */
+  int32_t kv_dtype;          /* 0 = bf16 KV cache, 1 = f32 KV cache */
+  int32_t use_graph;         /* 1 = replay the decode step as a hipGraph */
+  float rms_eps;
+} smi_llm_cfg;
+
+/* Arena sections.  The arena is one device buffer the caller fills (see sparkmi/arena.py):
+ *   matrices: bf16, rows grouped into 16-row x 32-col tiles stored [n_tile][k_tile][k8:4][n:16][8]
+ *             (one tile = 1 KiB = exactly one wave64 x 16-byte load = one MFMA 16x16x32 A operand);
+ *   QKV rows: q heads, then k heads, then v heads; inside each q/k head the 64 rows are ordered
+ *             (0,32,1,33,...) so a RoPE pair sits in adjacent rows; QKV bias in the same order;
+ *   GATE_UP rows: gate and up interleaved (g0,u0,g1,u1,...);
+ *   LM_HEAD: vocab padded up to a multiple of 16 rows with zeros (also the embedding table);
+ *   norms/bias: f32;  ROPE: float2 (cos,sin) [max_positions][head_dim/2].                      */
+enum smi_llm_section {
+  SMI_LLM_LN1 = 0, SMI_LLM_WQKV, SMI_LLM_BQKV, SMI_LLM_WO, SMI_LLM_LN2, SMI_LLM_WGU, SMI_LLM_WD, /* per layer */
+  SMI_LLM_FINAL_NORM, SMI_LLM_LM_HEAD, SMI_LLM_ROPE,                                            /* layer = 0 */
+  SMI_LLM_NUM_SECTIONS
+};
+/* Total arena size in bytes for this config (0 on invalid config). */
+size_t smi_llm_arena_bytes(const smi_llm_cfg* cfg);
+/* Byte offset and byte size of one section; returns SMI_EINVAL for a bad section/layer. */
+int smi_llm_arena_section(const smi_llm_cfg* cfg, int section, int layer, size_t* offset, size_t* bytes);
+
+int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_bytes, smi_llm** out);
+int smi_llm_destroy(smi_llm* h);
+
+/* Start B sequences (slots 0..B-1): run the prompts through the model (KV cache filled) and emit
+ * each sequence's first new token (generate()'s prefill forward + argmax).
+ *   ids_host:  [B][P_max] int64 prompt ids, right-padded;  lens_host: [B] prompt lengths (>= 1).
+ *   eos_id:    a sequence stops counting tokens after emitting it; pass -1 to never stop.       */
+int smi_llm_prefill(smi_llm* h, const int64_t* ids_host, const int32_t* lens_host, int B, int P_max,
+                    int64_t eos_id, void* stream);
+/* Run n_steps more greedy decode steps for all B sequences (finished ones keep stepping; their
+ * tokens are not counted).  Asynchronous. */
+int smi_llm_decode(smi_llm* h, int n_steps, void* stream);
+/* Synchronises the stream; *all_done = 1 when every sequence has emitted eos. */
+int smi_llm_all_done(smi_llm* h, int* all_done, void* stream);
+/* Synchronises; copies the generated ids: out_host [B][cap] int64 (row b holds lens_host[b] ids,
+ * the eos included when one was emitted). */
+int smi_llm_get_tokens(smi_llm* h, int64_t* out_host, int32_t* lens_host, int cap, void* stream);
+/* Test/teacher-forcing entry: feeds ids_host[0..S) at positions 0..S-1 of slot 0 (cache reset) and
+ * writes every position's logits to logits_dev [S][vocab_size] f32. */
+int smi_llm_forward_logits(smi_llm* h, const int64_t* ids_host, int S, float* logits_dev, void* stream);
+/* Steps generated so far per sequence (including the prefill token), and the KV bytes per token. */
+int smi_llm_steps(smi_llm* h);
+/* Per-kernel timing probe used by bench.py: launches ONLY the named decode-step kernel of `layer`
+ * `iters` times on `stream` (inputs are whatever the scratch holds), bracketed by HIP events, and
+ * returns the average milliseconds per launch.  kernel: 0 qkv, 1 attn, 2 o_proj, 3 gate_up,
+ * 4 down, 5 lm_head, 6 finalize, 7 = the whole decode step (graph or eager as configured). */
+int smi_llm_time_kernel(smi_llm* h, int kernel, int layer, int iters, float* ms_avg, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Vocoder: BiCodec.detokenize (codebook lookup, d-vector, ConvNeXt prenet, WaveGenerator).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct smi_voc smi_voc;
+
+typedef struct smi_voc_cfg {
+  int32_t vq_input_dim, codebook_size, codebook_dim;
+  int32_t spk_out_dim, spk_latent_dim, spk_token_num, fsq_dims; /* fsq_dims = len(fsq_levels) */
+  int32_t fsq_levels[8];
+  int32_t pre_input_channels, pre_dim, pre_inter, pre_layers, pre_out_channels, pre_cond_dim;
+  int32_t pre_num_down;      /* len(sample_ratios); every ratio must be 1 */
+  int32_t pre_tanh_final;
+  int32_t dec_in, dec_channels, dec_nblocks;
+  int32_t dec_rates[8], dec_ksizes[8];
+  int32_t max_batch;         /* utterances per forward */
+  int32_t max_frames;        /* semantic frames per utterance */
+} smi_voc_cfg;
+
+/* The vocoder arena is a flat f32 buffer of tensors in the order smi_voc_arena_entry enumerates
+ * (name = the reference state_dict key after remove_weight_norm, or a derived packed tensor). */
+int smi_voc_arena_count(const smi_voc_cfg* cfg);
+int smi_voc_arena_entry(const smi_voc_cfg* cfg, int index, char* name, int name_cap,
+                        size_t* offset, size_t* bytes, int32_t* packing);
+size_t smi_voc_arena_bytes(const smi_voc_cfg* cfg);
+
+int smi_voc_create(const smi_voc_cfg* cfg, const void* arena_dev, size_t arena_bytes, smi_voc** out);
+int smi_voc_destroy(smi_voc* h);
+/* sem_dev [B][T_max] int64 semantic ids (row b valid for lens_host[b] frames), glob_dev [B][Ntok]
+ * int32 global ids, wav_dev [B][hop*T_max] f32 (samples beyond hop*lens[b] are zeroed).
+ * Each row's result equals an un-padded B=1 run of that row. */
+int smi_voc_forward(smi_voc* h, const int64_t* sem_dev, const int32_t* lens_host, const int32_t* glob_dev,
+                    int B, int T_max, float* wav_dev, void* stream);
+/* Test entry: copies an internal activation (after `stage`) of the last forward to out_dev. */
+int smi_voc_debug_stage(smi_voc* h, int stage, float* out_dev, size_t max_floats, size_t* n_floats, void* stream);
+/* Per-kernel timing probe (see smi_llm_time_kernel): stage index into the launch list of the last
+ * forward; returns avg ms and the kernel's FLOPs per launch. */
+int smi_voc_num_launches(smi_voc* h);
+int smi_voc_time_launch(smi_voc* h, int index, int iters, float* ms_avg, double* flops, char* name, int name_cap, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARKMI_H */
