@@ -1,0 +1,967 @@
+// smi_llm.hip -- Qwen2 speech-token generator for gfx950 (MI355X).
+//
+// Stands behind AutoModelForCausalLM.generate(..., do_sample=False) as called at
+// cli/SparkTTS.py:197-204 of the reference; the arithmetic restated is transformers'
+// modeling_qwen2.py (RMSNorm :247-252, attention :150-235, RoPE :91-135, MLP :46-48).
+//
+// One "step" pushes M <= 32 rows through the model.  A row is (sequence slot, position, token):
+// in decode the rows are the B live sequences, in prefill they are 32 prompt tokens.  Every row is
+// independent in every kernel, so a batched step is bit-identical to B single-sequence steps.
+//
+// Kernels per layer (HBM-bound weight streaming; weights read exactly once per step):
+//   k_gemm<QKV>   RMSNorm prologue -> [q|k|v] projection -> +bias -> RoPE -> q buffer / KV-cache append
+//   k_attn        GQA attention over the cached keys (online softmax, wave64 shuffles + LDS combine)
+//   k_gemm<RESID> o_proj, residual add in the epilogue
+//   k_gemm<SWIGLU> RMSNorm prologue -> [gate|up] (row-interleaved) -> silu(g)*u
+//   k_gemm<RESID> down_proj, residual add
+// then k_gemm<LM> (final RMSNorm -> tied lm_head -> per-block argmax) and k_finalize (argmax over
+// blocks, token/position bookkeeping, next step's embedding gather).
+//
+// The GEMM core: weights are bf16 in 16x32 tiles stored in MFMA A-operand order (one 1 KiB tile =
+// one coalesced 16-B-per-lane wave load = one v_mfma_f32_16x16x32_bf16 operand).  Activations stay
+// fp32: each is split exactly into three bf16 terms (hi+mid+lo, 8+8+8 mantissa bits) staged in LDS
+// in B-operand order, so every product is exact and only the fp32 summation order differs from the
+// CPU oracle.  MFMA columns are the rows m of the step.
+#include "smi_common.h"
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+constexpr int kMaxRows = SMI_MAX_ROWS;
+constexpr int kHeadDim = 64;
+
+struct RowDesc {  // 16 bytes, lives in device memory
+  int32_t slot, pos, token, flags;
+};
+
+enum { PRO_PLAIN = 0, PRO_NORM = 1 };
+enum { EPI_RESID = 0, EPI_SWIGLU = 1, EPI_QKV = 2, EPI_LM = 3 };
+
+struct GemmP {
+  const uint4* W;   // [NT][KT][64] 16-byte lane pieces
+  int NT, KT, M, KC;  // n tiles, k tiles, rows, k tiles per LDS chunk
+  const RowDesc* rows;
+  const float* X;      // [M][K] f32
+  const float* gamma;  // [K] RMSNorm weight (PRO_NORM)
+  float eps;
+  float* Y;            // RESID: h [M][N]; SWIGLU: act [M][N/2]; QKV: q [M][q_dim]; LM: logits [M][V] or null
+  const float* bias;   // QKV bias [N] (arena order)
+  const float2* rope;  // [max_pos][32] (cos, sin)
+  void* kcache;        // this layer's K cache: [slot][kvh][max_pos][64]
+  void* vcache;
+  int q_dim, kv_dim, n_kv, max_pos;
+  int V;               // LM: true vocab size
+  float* pval;         // LM: [gridDim.x][32] per-block best logit
+  int* pidx;           // LM: [gridDim.x][32] per-block best index
+};
+
+// ------------------------------------------------------------------------------------------
+// GEMM: Y[m][n] = sum_k W[n][k] * X'[m][k]
+// ------------------------------------------------------------------------------------------
+template <int MT, int NTB, int NW, int PRO, int EPI, int KVF32>
+__global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int KT = p.KT, K = KT * 32, M = p.M, NT = p.NT;
+  const int nt0 = blockIdx.x * NTB;
+  // LDS map: [0, xs_bytes) activation splits (later aliased by the split-K reduction slab),
+  // then rstd[32] floats, then argmax scratch.
+  const int xs_bytes = p.KC * 192 * M;
+  const int red_bytes = NW * NTB * MT * 1024;
+  const int main_bytes = xs_bytes > red_bytes ? xs_bytes : red_bytes;
+  unsigned char* xs = smem;
+  float* rstd = (float*)(smem + main_bytes);
+  float* bestv = rstd + 32;               // [NTB][32]
+  int* besti = (int*)(bestv + NTB * 32);  // [NTB][32]
+
+  if (PRO == PRO_NORM) {
+    for (int m = wave; m < M; m += NW) {
+      const float4* xr = (const float4*)(p.X + (size_t)m * K);
+      float s = 0.f;
+      for (int i = lane; i < K / 4; i += 64) {
+        float4 v = xr[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      }
+      s = smi_wave_sum(s);
+      if (lane == 0) rstd[m] = 1.0f / sqrtf(s / (float)K + p.eps);
+    }
+    __syncthreads();
+  }
+
+  f32x4 acc[NTB][MT];
+#pragma unroll
+  for (int a = 0; a < NTB; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int mslot_bytes = M * 16;
+  for (int kc0 = 0; kc0 < KT; kc0 += p.KC) {
+    const int kcn = (KT - kc0) < p.KC ? (KT - kc0) : p.KC;
+    if (kc0) __syncthreads();
+    // ---- stage this chunk's activations as exact bf16 triples in MFMA B-operand order
+    const int octs = kcn * 4;
+    for (int u = tid; u < M * octs; u += NW * 64) {
+      const int m = u / octs, o = u - m * octs;
+      const int k = (kc0 * 4 + o) * 8;
+      const float4* src = (const float4*)(p.X + (size_t)m * K + k);
+      float4 a = src[0], b = src[1];
+      float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      if (PRO == PRO_NORM) {
+        const float r = rstd[m];
+        const float4* gp = (const float4*)(p.gamma + k);
+        float4 g0 = gp[0], g1 = gp[1];
+        float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = g[i] * (v[i] * r);  // weight * (x * rsqrt(var+eps)), MQ:251-252
+      }
+      uint32_t hi[8], mi[8], lo[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        hi[i] = smi_f32_to_bf16(v[i]);
+        float r1 = v[i] - smi_bf16_to_f32(hi[i]);
+        mi[i] = smi_f32_to_bf16(r1);
+        float r2 = r1 - smi_bf16_to_f32(mi[i]);
+        lo[i] = smi_f32_to_bf16(r2);
+      }
+      const int base = (((o >> 2) * 3) * 4 + (o & 3)) * mslot_bytes + m * 16;
+      *(uint4*)(xs + base) = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+      *(uint4*)(xs + base + 4 * mslot_bytes) = make_uint4(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16), mi[4] | (mi[5] << 16), mi[6] | (mi[7] << 16));
+      *(uint4*)(xs + base + 8 * mslot_bytes) = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+    }
+    __syncthreads();
+    // ---- stream weight tiles; each wave owns k tiles wave, wave+NW, ...
+    constexpr int U = 4;
+    const int k8 = lane >> 4;
+    for (int j0 = wave; j0 < kcn; j0 += NW * U) {
+      uint4 w[U][NTB];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int j = j0 + u * NW;
+        j = j < kcn ? j : kcn - 1;
+#pragma unroll
+        for (int nb = 0; nb < NTB; ++nb) {
+          int nt = nt0 + nb;
+          nt = nt < NT ? nt : NT - 1;
+          w[u][nb] = p.W[((size_t)nt * KT + kc0 + j) * 64 + lane];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int j = j0 + u * NW;
+        if (j < kcn) {
+          bf16x8 bf[3][MT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            int m = mt * 16 + (lane & 15);
+            m = m < M ? m : M - 1;
+            const unsigned char* bp = xs + ((j * 3) * 4 + k8) * mslot_bytes + m * 16;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) bf[s][mt] = *(const bf16x8*)(bp + s * 4 * mslot_bytes);
+          }
+#pragma unroll
+          for (int nb = 0; nb < NTB; ++nb) {
+            const bf16x8 a = __builtin_bit_cast(bf16x8, w[u][nb]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              acc[nb][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[2][mt], acc[nb][mt], 0, 0, 0);
+              acc[nb][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[1][mt], acc[nb][mt], 0, 0, 0);
+              acc[nb][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[0][mt], acc[nb][mt], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- split-K reduction across the block's waves (fixed order => deterministic)
+  __syncthreads();
+  float4* red = (float4*)smem;  // [NW][NTB][MT][64]
+#pragma unroll
+  for (int nb = 0; nb < NTB; ++nb)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      red[((wave * NTB + nb) * MT + mt) * 64 + lane] =
+          make_float4(acc[nb][mt][0], acc[nb][mt][1], acc[nb][mt][2], acc[nb][mt][3]);
+  if (EPI == EPI_LM) {
+    for (int i = tid; i < NTB * 32; i += NW * 64) { bestv[i] = -INFINITY; besti[i] = 0x7fffffff; }
+  }
+  __syncthreads();
+
+  const int N = NT * 16;
+  for (int nb = wave; nb < NTB; nb += NW) {
+    const int nt = nt0 + nb;
+    if (nt >= NT) continue;  // wave-uniform
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float4 s = red[((0 * NTB + nb) * MT + mt) * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) {
+        float4 t = red[((w * NTB + nb) * MT + mt) * 64 + lane];
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+      const int m = mt * 16 + (lane & 15);
+      const int n = nt * 16 + 4 * (lane >> 4);
+      const bool valid = m < M;
+      if (EPI == EPI_RESID) {
+        if (valid) {
+          float4* y = (float4*)(p.Y + (size_t)m * N + n);
+          float4 h = *y;
+          h.x += s.x; h.y += s.y; h.z += s.z; h.w += s.w;
+          *y = h;
+        }
+      } else if (EPI == EPI_SWIGLU) {
+        if (valid) {
+          // rows are (gate, up, gate, up): silu(g) * u, MQ:46-48
+          float2 o;
+          o.x = (s.x / (1.0f + expf(-s.x))) * s.y;
+          o.y = (s.z / (1.0f + expf(-s.z))) * s.w;
+          *(float2*)(p.Y + (size_t)m * (N / 2) + n / 2) = o;
+        }
+      } else if (EPI == EPI_QKV) {
+        if (valid) {
+          const float4 b = *(const float4*)(p.bias + n);
+          s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+          const RowDesc rd = p.rows[m];
+          if (n < p.q_dim + p.kv_dim) {
+            // rows inside a head are ordered (0,32,1,33,..): (s.x,s.y) and (s.z,s.w) are RoPE pairs
+            const int i0 = (n & 63) >> 1;
+            const float2 c0 = p.rope[(size_t)rd.pos * 32 + i0], c1 = p.rope[(size_t)rd.pos * 32 + i0 + 1];
+            float4 r;
+            r.x = __fadd_rn(__fmul_rn(s.x, c0.x), __fmul_rn(-s.y, c0.y));  // x1*cos + (-x2)*sin
+            r.y = __fadd_rn(__fmul_rn(s.y, c0.x), __fmul_rn(s.x, c0.y));   // x2*cos + x1*sin
+            r.z = __fadd_rn(__fmul_rn(s.z, c1.x), __fmul_rn(-s.w, c1.y));
+            r.w = __fadd_rn(__fmul_rn(s.w, c1.x), __fmul_rn(s.z, c1.y));
+            s = r;
+          }
+          if (n < p.q_dim) {
+            *(float4*)(p.Y + (size_t)m * p.q_dim + n) = s;
+          } else {
+            const bool isk = n < p.q_dim + p.kv_dim;
+            const int c = n - p.q_dim - (isk ? 0 : p.kv_dim);
+            const size_t off = (((size_t)rd.slot * p.n_kv + (c >> 6)) * p.max_pos + rd.pos) * 64 + (c & 63);
+            void* base = isk ? p.kcache : p.vcache;
+            if (KVF32) {
+              *(float4*)((float*)base + off) = s;
+            } else {
+              uint2 pk;
+              pk.x = smi_f32_to_bf16(s.x) | (smi_f32_to_bf16(s.y) << 16);
+              pk.y = smi_f32_to_bf16(s.z) | (smi_f32_to_bf16(s.w) << 16);
+              *(uint2*)((uint16_t*)base + off) = pk;
+            }
+          }
+        }
+      } else {  // EPI_LM
+        if (valid && p.Y) {
+          float* y = p.Y + (size_t)m * p.V + n;
+          if (n + 0 < p.V) y[0] = s.x;
+          if (n + 1 < p.V) y[1] = s.y;
+          if (n + 2 < p.V) y[2] = s.z;
+          if (n + 3 < p.V) y[3] = s.w;
+        }
+        // lane-local best over its 4 rows (ascending n, strict > keeps the lowest index on ties)
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.V && sv[r] > bv) { bv = sv[r]; bi = n + r; }
+        // combine the 4 lanes that share this m (lane, lane^16, lane^32, lane^48)
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+          float ov = __shfl_xor(bv, o, 64);
+          int oi = __shfl_xor(bi, o, 64);
+          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane < 16 && valid) { bestv[nb * 32 + m] = bv; besti[nb * 32 + m] = bi; }
+      }
+    }
+  }
+  if (EPI == EPI_LM) {
+    __syncthreads();
+    if (tid < M) {
+      float bv = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int nb = 0; nb < NTB; ++nb) {
+        float ov = bestv[nb * 32 + tid];
+        int oi = besti[nb * 32 + tid];
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      p.pval[(size_t)blockIdx.x * 32 + tid] = bv;
+      p.pidx[(size_t)blockIdx.x * 32 + tid] = bi;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Attention: one block per (query head, row).  softmax(q.K^T / 8) V over positions 0..pos.
+// q is pre-rotated fp32 in the arena's (0,32,1,33,..) order, K cached in the same order, so the
+// dot product is unchanged; V is cached in natural order.
+// ------------------------------------------------------------------------------------------
+struct AttnP {
+  const float* q;      // [M][q_dim]
+  const void* kcache;  // layer base
+  const void* vcache;
+  const RowDesc* rows;
+  float* out;          // [M][q_dim]
+  int q_dim, n_kv, group, max_pos;
+};
+
+template <int KVF32>
+__global__ __launch_bounds__(256) void k_attn(AttnP p) {
+  constexpr int LPT = KVF32 ? 16 : 8;   // lanes per token row (each lane 16 bytes)
+  constexpr int DPL = kHeadDim / LPT;   // dims per lane
+  constexpr int TPW = 64 / LPT;         // tokens per wave iteration
+  constexpr float NEG = -1e30f;
+  __shared__ float wm[4], wl[4], wo[4][kHeadDim];
+  const int head = blockIdx.x, m = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tl = lane / LPT, dl = lane % LPT;
+  const RowDesc rd = p.rows[m];
+  const int ctx = rd.pos + 1;
+  const int kvh = head / p.group;
+  const size_t rowbase = ((size_t)rd.slot * p.n_kv + kvh) * p.max_pos;
+
+  float qv[DPL];
+  {
+    const float* qp = p.q + (size_t)m * p.q_dim + head * kHeadDim + dl * DPL;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) qv[i] = qp[i] * 0.125f;  // head_dim^-0.5, exact
+  }
+  float mrun = NEG, lrun = 0.f, o[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) o[i] = 0.f;
+
+  for (int t0 = wave * TPW; t0 < ctx; t0 += 4 * TPW) {
+    const int t = t0 + tl;
+    const bool valid = t < ctx;
+    const size_t off = (rowbase + (valid ? t : ctx - 1)) * kHeadDim + dl * DPL;
+    float kf[DPL], vf[DPL];
+    if (KVF32) {
+      const float4 kk = *(const float4*)((const float*)p.kcache + off);
+      const float4 vv = *(const float4*)((const float*)p.vcache + off);
+      kf[0] = kk.x; kf[1] = kk.y; kf[2] = kk.z; kf[3] = kk.w;
+      vf[0] = vv.x; vf[1] = vv.y; vf[2] = vv.z; vf[3] = vv.w;
+    } else {
+      const uint4 kk = *(const uint4*)((const uint16_t*)p.kcache + off);
+      const uint4 vv = *(const uint4*)((const uint16_t*)p.vcache + off);
+      const uint32_t ku[4] = {kk.x, kk.y, kk.z, kk.w}, vu[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        kf[2 * i] = __uint_as_float(ku[i] << 16);
+        kf[2 * i + 1] = __uint_as_float(ku[i] & 0xffff0000u);
+        vf[2 * i] = __uint_as_float(vu[i] << 16);
+        vf[2 * i + 1] = __uint_as_float(vu[i] & 0xffff0000u);
+      }
+    }
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) d += qv[i] * kf[i];
+#pragma unroll
+    for (int s = 1; s < LPT; s <<= 1) d += __shfl_xor(d, s, 64);
+    if (valid) {
+      const float mn = fmaxf(mrun, d);
+      const float a = expf(mrun - mn), e = expf(d - mn);
+      lrun = lrun * a + e;
+#pragma unroll
+      for (int i = 0; i < DPL; ++i) o[i] = o[i] * a + e * vf[i];
+      mrun = mn;
+    }
+  }
+  // merge the token streams inside the wave
+#pragma unroll
+  for (int s = LPT; s < 64; s <<= 1) {
+    const float m2 = __shfl_xor(mrun, s, 64), l2 = __shfl_xor(lrun, s, 64);
+    const float mn = fmaxf(mrun, m2);
+    const float a1 = expf(mrun - mn), a2 = expf(m2 - mn);
+    lrun = lrun * a1 + l2 * a2;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+      const float o2 = __shfl_xor(o[i], s, 64);
+      o[i] = o[i] * a1 + o2 * a2;
+    }
+    mrun = mn;
+  }
+  if (tl == 0) {
+    if (dl == 0) { wm[wave] = mrun; wl[wave] = lrun; }
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) wo[wave][dl * DPL + i] = o[i];
+  }
+  __syncthreads();
+  if (tid < kHeadDim) {
+    float mn = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float a = expf(wm[w] - mn);
+      L += wl[w] * a;
+      O += wo[w][tid] * a;
+    }
+    p.out[(size_t)m * p.q_dim + head * kHeadDim + tid] = O / L;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Embedding gather from the tiled lm_head (tied embeddings): h[m][:] = E[token_m][:]
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lm_elem(const uint16_t* W, int KT, int n, int k) {
+  const size_t tile = (size_t)(n >> 4) * KT + (k >> 5);
+  const int in = (((k >> 3) & 3) * 16 + (n & 15)) * 8 + (k & 7);
+  return smi_bf16_to_f32(W[tile * 512 + in]);
+}
+
+__global__ void k_embed(const uint16_t* W, int KT, const RowDesc* rows, int M, float* h) {
+  const int K = KT * 32;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M * K; i += gridDim.x * blockDim.x) {
+    const int m = i / K, k = i - m * K;
+    h[i] = lm_elem(W, KT, rows[m].token, k);
+  }
+}
+
+struct FinP {
+  const float* pval;
+  const int* pidx;
+  int nblk, M, KT;
+  RowDesc* rows;
+  int64_t* hist;      // [max_steps][32]
+  int32_t* count;     // [32] tokens counted per sequence
+  int32_t* finished;  // [32]
+  int32_t* step;      // [1]
+  int64_t eos;
+  const uint16_t* Wlm;
+  float* h;
+  int max_steps;
+};
+
+__global__ __launch_bounds__(256) void k_finalize(FinP p) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  __shared__ int tok_s[kMaxRows];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int step = *p.step;
+  for (int m = 0; m < p.M; ++m) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < p.nblk; i += 256) {
+      const float v = p.pval[(size_t)i * 32 + m];
+      const int ix = p.pidx[(size_t)i * 32 + m];
+      if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+      tok_s[m] = bi;
+      if (step < p.max_steps) p.hist[(size_t)step * 32 + m] = bi;
+      if (!p.finished[m]) {
+        p.count[m] = step + 1;
+        if ((int64_t)bi == p.eos) p.finished[m] = 1;
+      }
+      RowDesc rd = p.rows[m];
+      rd.token = bi;
+      rd.pos += 1;
+      p.rows[m] = rd;
+    }
+    __syncthreads();
+  }
+  const int K = p.KT * 32;
+  for (int i = tid; i < p.M * K; i += 256) {
+    const int m = i / K, k = i - m * K;
+    p.h[i] = lm_elem(p.Wlm, p.KT, tok_s[m], k);
+  }
+  if (tid == 0) *p.step = step + 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct Layout {
+  size_t off[SMI_LLM_NUM_SECTIONS];   // per-layer sections: offset inside a layer block
+  size_t bytes[SMI_LLM_NUM_SECTIONS];
+  size_t layer_stride, layers_base, total;
+  int vpad;
+};
+
+bool cfg_ok(const smi_llm_cfg* c) {
+  if (!c) return false;
+  if (c->head_dim != kHeadDim || c->hidden_size <= 0 || c->hidden_size % 32) return false;
+  if (c->intermediate_size <= 0 || c->intermediate_size % 32) return false;
+  if (c->num_heads <= 0 || c->num_kv_heads <= 0 || c->num_heads % c->num_kv_heads) return false;
+  if (c->num_layers <= 0 || c->vocab_size <= 0) return false;
+  if (c->max_slots < 1 || c->max_slots > kMaxRows || c->max_positions < 2) return false;
+  if ((c->num_heads * c->head_dim) % 32) return false;
+  if (c->kv_dtype != 0 && c->kv_dtype != 1) return false;
+  return true;
+}
+
+Layout make_layout(const smi_llm_cfg* c) {
+  Layout L;
+  memset(&L, 0, sizeof(L));
+  const size_t H = c->hidden_size, Q = (size_t)c->num_heads * c->head_dim, KV = (size_t)c->num_kv_heads * c->head_dim;
+  const size_t I = c->intermediate_size;
+  L.vpad = (c->vocab_size + 15) / 16 * 16;
+  L.bytes[SMI_LLM_LN1] = H * 4;
+  L.bytes[SMI_LLM_WQKV] = (Q + 2 * KV) * H * 2;
+  L.bytes[SMI_LLM_BQKV] = (Q + 2 * KV) * 4;
+  L.bytes[SMI_LLM_WO] = H * Q * 2;
+  L.bytes[SMI_LLM_LN2] = H * 4;
+  L.bytes[SMI_LLM_WGU] = 2 * I * H * 2;
+  L.bytes[SMI_LLM_WD] = H * I * 2;
+  L.bytes[SMI_LLM_FINAL_NORM] = H * 4;
+  L.bytes[SMI_LLM_LM_HEAD] = (size_t)L.vpad * H * 2;
+  L.bytes[SMI_LLM_ROPE] = (size_t)c->max_positions * (kHeadDim / 2) * 8;
+  size_t o = 0;
+  for (int s = SMI_LLM_LN1; s <= SMI_LLM_WD; ++s) { L.off[s] = o; o += smi_align_up(L.bytes[s], 256); }
+  L.layer_stride = o;
+  size_t g = 0;
+  for (int s = SMI_LLM_FINAL_NORM; s <= SMI_LLM_ROPE; ++s) { L.off[s] = g; g += smi_align_up(L.bytes[s], 256); }
+  L.layers_base = g;
+  L.total = g + L.layer_stride * c->num_layers;
+  return L;
+}
+
+}  // namespace
+
+struct smi_llm {
+  smi_llm_cfg cfg;
+  Layout lay;
+  const unsigned char* arena;
+  int H, Q, KV, I, KTh, KTq, KTi, NTqkv, NTh, NTgu, NTlm;
+  // device scratch
+  float *h, *qbuf, *attn, *act;
+  RowDesc* rows;       // live decode rows [32]
+  RowDesc* plan;       // prefill plan
+  size_t plan_cap;     // rows
+  float* pval; int* pidx; int lm_blocks;
+  int64_t* hist; int32_t *count, *finished, *step;
+  void *kcache, *vcache; size_t kv_layer_elems;
+  int B; int64_t eos; int started;
+  int max_len, steps_launched;  // host-side bound on cache positions in use
+  int max_steps;
+  hipGraphExec_t graph; int graph_B;
+  hipEvent_t ev0, ev1;
+  // host staging
+  std::vector<RowDesc> host_rows;
+};
+
+namespace {
+
+template <int MT, int NTB, int NW, int PRO, int EPI>
+int launch_gemm_kv(const smi_llm* L, const GemmP& p, hipStream_t st) {
+  const int grid = (p.NT + NTB - 1) / NTB;
+  const int xs_bytes = p.KC * 192 * p.M;
+  const int red_bytes = NW * NTB * MT * 1024;
+  const size_t lds = (size_t)(xs_bytes > red_bytes ? xs_bytes : red_bytes) + 32 * 4 + NTB * 32 * 8;
+  if (L->cfg.kv_dtype)
+    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, PRO, EPI, 1>), dim3(grid), dim3(NW * 64), lds, st, p);
+  else
+    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, PRO, EPI, 0>), dim3(grid), dim3(NW * 64), lds, st, p);
+  SMI_LAUNCH_CHECK();
+  return SMI_OK;
+}
+
+template <int NTB, int NW, int PRO, int EPI>
+int launch_gemm(const smi_llm* L, GemmP p, hipStream_t st) {
+  // LDS chunking: activation splits cost 192 bytes per (row, k tile); keep them under 56 KiB
+  int kc = (56 * 1024) / (192 * p.M);
+  if (kc < 1) kc = 1;
+  p.KC = kc < p.KT ? kc : p.KT;
+  if (p.M > 16) return launch_gemm_kv<2, NTB, NW, PRO, EPI>(L, p, st);
+  return launch_gemm_kv<1, NTB, NW, PRO, EPI>(L, p, st);
+}
+
+const unsigned char* sec(const smi_llm* L, int s, int layer) {
+  if (s >= SMI_LLM_FINAL_NORM) return L->arena + L->lay.off[s];
+  return L->arena + L->lay.layers_base + (size_t)layer * L->lay.layer_stride + L->lay.off[s];
+}
+
+void* kv_layer(const smi_llm* L, void* base, int layer) {
+  const size_t esz = L->cfg.kv_dtype ? 4 : 2;
+  return (unsigned char*)base + (size_t)layer * L->kv_layer_elems * esz;
+}
+
+enum { KQKV = 0, KATTN, KO, KGU, KD, KLM, KFIN };
+
+int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, float* logits, hipStream_t st) {
+  const smi_llm_cfg& c = L->cfg;
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.M = M; p.rows = rows; p.eps = c.rms_eps;
+  switch (which) {
+    case KQKV:
+      p.W = (const uint4*)sec(L, SMI_LLM_WQKV, layer); p.NT = L->NTqkv; p.KT = L->KTh;
+      p.X = L->h; p.gamma = (const float*)sec(L, SMI_LLM_LN1, layer);
+      p.Y = L->qbuf; p.bias = (const float*)sec(L, SMI_LLM_BQKV, layer);
+      p.rope = (const float2*)sec(L, SMI_LLM_ROPE, 0);
+      p.kcache = kv_layer(L, L->kcache, layer); p.vcache = kv_layer(L, L->vcache, layer);
+      p.q_dim = L->Q; p.kv_dim = L->KV; p.n_kv = c.num_kv_heads; p.max_pos = c.max_positions;
+      return launch_gemm<1, 4, PRO_NORM, EPI_QKV>(L, p, st);
+    case KATTN: {
+      AttnP a;
+      a.q = L->qbuf; a.kcache = kv_layer(L, L->kcache, layer); a.vcache = kv_layer(L, L->vcache, layer);
+      a.rows = rows; a.out = L->attn; a.q_dim = L->Q; a.n_kv = c.num_kv_heads;
+      a.group = c.num_heads / c.num_kv_heads; a.max_pos = c.max_positions;
+      if (c.kv_dtype) hipLaunchKernelGGL(k_attn<1>, dim3(c.num_heads, M), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL(k_attn<0>, dim3(c.num_heads, M), dim3(256), 0, st, a);
+      SMI_LAUNCH_CHECK();
+      return SMI_OK;
+    }
+    case KO:
+      p.W = (const uint4*)sec(L, SMI_LLM_WO, layer); p.NT = L->NTh; p.KT = L->KTq;
+      p.X = L->attn; p.Y = L->h;
+      return launch_gemm<1, 4, PRO_PLAIN, EPI_RESID>(L, p, st);
+    case KGU:
+      p.W = (const uint4*)sec(L, SMI_LLM_WGU, layer); p.NT = L->NTgu; p.KT = L->KTh;
+      p.X = L->h; p.gamma = (const float*)sec(L, SMI_LLM_LN2, layer); p.Y = L->act;
+      return launch_gemm<2, 4, PRO_NORM, EPI_SWIGLU>(L, p, st);
+    case KD:
+      p.W = (const uint4*)sec(L, SMI_LLM_WD, layer); p.NT = L->NTh; p.KT = L->KTi;
+      p.X = L->act; p.Y = L->h;
+      return launch_gemm<1, 8, PRO_PLAIN, EPI_RESID>(L, p, st);
+    case KLM:
+      p.W = (const uint4*)sec(L, SMI_LLM_LM_HEAD, 0); p.NT = L->NTlm; p.KT = L->KTh;
+      p.X = L->h; p.gamma = (const float*)sec(L, SMI_LLM_FINAL_NORM, 0);
+      p.Y = logits; p.V = c.vocab_size; p.pval = L->pval; p.pidx = L->pidx;
+      return launch_gemm<4, 4, PRO_NORM, EPI_LM>(L, p, st);
+    case KFIN: {
+      FinP f;
+      f.pval = L->pval; f.pidx = L->pidx; f.nblk = L->lm_blocks; f.M = M; f.KT = L->KTh;
+      f.rows = L->rows; f.hist = L->hist; f.count = L->count; f.finished = L->finished; f.step = L->step;
+      f.eos = L->eos; f.Wlm = (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0); f.h = L->h; f.max_steps = L->max_steps;
+      hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, st, f);
+      SMI_LAUNCH_CHECK();
+      return SMI_OK;
+    }
+  }
+  smi_set_error("launch_one: bad kernel id %d", which);
+  return SMI_EINVAL;
+}
+
+int launch_embed(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
+  const int n = M * L->H;
+  hipLaunchKernelGGL(k_embed, dim3((n + 255) / 256), dim3(256), 0, st,
+                     (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0), L->KTh, rows, M, L->h);
+  SMI_LAUNCH_CHECK();
+  return SMI_OK;
+}
+
+// All layers for M rows.  kv_only_last: skip everything after the last layer's KV append
+// (prefill rows whose hidden state is never read).
+int launch_layers(smi_llm* L, const RowDesc* rows, int M, bool kv_only_last, hipStream_t st) {
+  int rc;
+  for (int l = 0; l < L->cfg.num_layers; ++l) {
+    if ((rc = launch_one(L, KQKV, l, rows, M, nullptr, st))) return rc;
+    if (kv_only_last && l == L->cfg.num_layers - 1) break;
+    if ((rc = launch_one(L, KATTN, l, rows, M, nullptr, st))) return rc;
+    if ((rc = launch_one(L, KO, l, rows, M, nullptr, st))) return rc;
+    if ((rc = launch_one(L, KGU, l, rows, M, nullptr, st))) return rc;
+    if ((rc = launch_one(L, KD, l, rows, M, nullptr, st))) return rc;
+  }
+  return SMI_OK;
+}
+
+int launch_step(smi_llm* L, int M, hipStream_t st) {
+  int rc;
+  if ((rc = launch_layers(L, L->rows, M, false, st))) return rc;
+  if ((rc = launch_one(L, KLM, 0, L->rows, M, nullptr, st))) return rc;
+  return launch_one(L, KFIN, 0, L->rows, M, nullptr, st);
+}
+
+int ensure_plan(smi_llm* L, size_t rows) {
+  if (rows <= L->plan_cap) return SMI_OK;
+  if (L->plan) (void)hipFree(L->plan);
+  L->plan = nullptr; L->plan_cap = 0;
+  size_t cap = rows + 1024;
+  if (hipMalloc((void**)&L->plan, cap * sizeof(RowDesc)) != hipSuccess) {
+    smi_set_error("hipMalloc(prefill plan, %zu rows) failed", cap);
+    return SMI_ENOMEM;
+  }
+  L->plan_cap = cap;
+  return SMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t smi_llm_arena_bytes(const smi_llm_cfg* cfg) {
+  if (!cfg_ok(cfg)) return 0;
+  return make_layout(cfg).total;
+}
+
+int smi_llm_arena_section(const smi_llm_cfg* cfg, int section, int layer, size_t* offset, size_t* bytes) {
+  SMI_REQUIRE(cfg_ok(cfg), "smi_llm_arena_section: invalid config");
+  SMI_REQUIRE(section >= 0 && section < SMI_LLM_NUM_SECTIONS, "bad section %d", section);
+  Layout L = make_layout(cfg);
+  if (section >= SMI_LLM_FINAL_NORM) {
+    SMI_REQUIRE(layer == 0, "global section takes layer 0");
+    if (offset) *offset = L.off[section];
+  } else {
+    SMI_REQUIRE(layer >= 0 && layer < cfg->num_layers, "bad layer %d", layer);
+    if (offset) *offset = L.layers_base + (size_t)layer * L.layer_stride + L.off[section];
+  }
+  if (bytes) *bytes = L.bytes[section];
+  return SMI_OK;
+}
+
+int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_bytes, smi_llm** out) {
+  SMI_REQUIRE(out, "smi_llm_create: out is null");
+  *out = nullptr;
+  SMI_REQUIRE(cfg_ok(cfg), "smi_llm_create: config outside the kernel contract (head_dim 64, hidden/intermediate %% 32, slots<=32)");
+  Layout lay = make_layout(cfg);
+  SMI_REQUIRE(arena_dev && arena_bytes >= lay.total, "smi_llm_create: arena too small (%zu < %zu)", arena_bytes, lay.total);
+  SMI_REQUIRE(((uintptr_t)arena_dev & 255) == 0, "smi_llm_create: arena must be 256-byte aligned");
+  smi_llm* L = new smi_llm();
+  L->cfg = *cfg; L->lay = lay; L->arena = (const unsigned char*)arena_dev;
+  L->H = cfg->hidden_size; L->Q = cfg->num_heads * cfg->head_dim; L->KV = cfg->num_kv_heads * cfg->head_dim;
+  L->I = cfg->intermediate_size;
+  L->KTh = L->H / 32; L->KTq = L->Q / 32; L->KTi = L->I / 32;
+  L->NTqkv = (L->Q + 2 * L->KV) / 16; L->NTh = L->H / 16; L->NTgu = 2 * L->I / 16; L->NTlm = lay.vpad / 16;
+  L->lm_blocks = (L->NTlm + 3) / 4;
+  L->max_steps = cfg->max_positions;
+  L->graph = nullptr; L->graph_B = 0; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->eos = -1;
+  const size_t esz = cfg->kv_dtype ? 4 : 2;
+  L->kv_layer_elems = (size_t)cfg->max_slots * cfg->num_kv_heads * cfg->max_positions * kHeadDim;
+  const size_t kvbytes = L->kv_layer_elems * esz * cfg->num_layers;
+#define SMI_ALLOC(ptr, bytes)                                                      \
+  if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) {                          \
+    smi_set_error("hipMalloc(%s, %zu bytes) failed", #ptr, (size_t)(bytes));       \
+    smi_llm_destroy(L);                                                            \
+    return SMI_ENOMEM;                                                             \
+  }
+  SMI_ALLOC(L->h, (size_t)kMaxRows * L->H * 4);
+  SMI_ALLOC(L->qbuf, (size_t)kMaxRows * L->Q * 4);
+  SMI_ALLOC(L->attn, (size_t)kMaxRows * L->Q * 4);
+  SMI_ALLOC(L->act, (size_t)kMaxRows * L->I * 4);
+  SMI_ALLOC(L->rows, kMaxRows * sizeof(RowDesc));
+  SMI_ALLOC(L->pval, (size_t)L->lm_blocks * 32 * 4);
+  SMI_ALLOC(L->pidx, (size_t)L->lm_blocks * 32 * 4);
+  SMI_ALLOC(L->hist, (size_t)L->max_steps * 32 * 8);
+  SMI_ALLOC(L->count, 32 * 4);
+  SMI_ALLOC(L->finished, 32 * 4);
+  SMI_ALLOC(L->step, 4);
+  SMI_ALLOC(L->kcache, kvbytes);
+  SMI_ALLOC(L->vcache, kvbytes);
+#undef SMI_ALLOC
+  if (hipMemset(L->kcache, 0, kvbytes) != hipSuccess || hipMemset(L->vcache, 0, kvbytes) != hipSuccess ||
+      hipMemset(L->h, 0, (size_t)kMaxRows * L->H * 4) != hipSuccess ||
+      hipMemset(L->act, 0, (size_t)kMaxRows * L->I * 4) != hipSuccess ||
+      hipMemset(L->attn, 0, (size_t)kMaxRows * L->Q * 4) != hipSuccess ||
+      hipMemset(L->qbuf, 0, (size_t)kMaxRows * L->Q * 4) != hipSuccess ||
+      hipMemset(L->rows, 0, kMaxRows * sizeof(RowDesc)) != hipSuccess ||
+      hipMemset(L->count, 0, 128) != hipSuccess || hipMemset(L->finished, 0, 128) != hipSuccess ||
+      hipMemset(L->step, 0, 4) != hipSuccess) {
+    smi_set_error("hipMemset of scratch failed");
+    smi_llm_destroy(L);
+    return SMI_EHIP;
+  }
+  if (hipEventCreate(&L->ev0) != hipSuccess || hipEventCreate(&L->ev1) != hipSuccess) {
+    smi_set_error("hipEventCreate failed");
+    smi_llm_destroy(L);
+    return SMI_EHIP;
+  }
+  *out = L;
+  return SMI_OK;
+}
+
+int smi_llm_destroy(smi_llm* L) {
+  if (!L) return SMI_OK;
+  if (L->graph) (void)hipGraphExecDestroy(L->graph);
+  void* ptrs[] = {L->h, L->qbuf, L->attn, L->act, L->rows, L->plan, L->pval, L->pidx, L->hist,
+                  L->count, L->finished, L->step, L->kcache, L->vcache};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  if (L->ev0) (void)hipEventDestroy(L->ev0);
+  if (L->ev1) (void)hipEventDestroy(L->ev1);
+  delete L;
+  return SMI_OK;
+}
+
+int smi_llm_prefill(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, int P_max, int64_t eos_id, void* stream) {
+  SMI_REQUIRE(L && ids && lens, "smi_llm_prefill: null argument");
+  SMI_REQUIRE(B >= 1 && B <= L->cfg.max_slots, "smi_llm_prefill: B=%d outside 1..%d", B, L->cfg.max_slots);
+  hipStream_t st = (hipStream_t)stream;
+  size_t total = 0;
+  for (int b = 0; b < B; ++b) {
+    SMI_REQUIRE(lens[b] >= 1 && lens[b] <= P_max, "smi_llm_prefill: lens[%d]=%d outside 1..%d", b, lens[b], P_max);
+    SMI_REQUIRE(lens[b] < L->cfg.max_positions, "smi_llm_prefill: prompt %d longer than max_positions", b);
+    for (int t = 0; t < lens[b]; ++t) {
+      const int64_t id = ids[(size_t)b * P_max + t];
+      SMI_REQUIRE(id >= 0 && id < L->cfg.vocab_size, "smi_llm_prefill: token id %lld out of range", (long long)id);
+    }
+    total += lens[b] - 1;
+  }
+  // plan: every prompt token except each sequence's last, packed 32 rows per chunk; then the
+  // B "last prompt token" rows, which run as the first regular step (lm_head + argmax).
+  const size_t nchunks = (total + kMaxRows - 1) / kMaxRows;
+  int rc;
+  if ((rc = ensure_plan(L, nchunks * kMaxRows + kMaxRows))) return rc;
+  L->host_rows.assign(nchunks * kMaxRows + kMaxRows, RowDesc{0, 0, 0, 0});
+  size_t r = 0;
+  for (int b = 0; b < B; ++b)
+    for (int t = 0; t + 1 < lens[b]; ++t) L->host_rows[r++] = RowDesc{b, t, (int32_t)ids[(size_t)b * P_max + t], 0};
+  for (int b = 0; b < B; ++b)
+    L->host_rows[nchunks * kMaxRows + b] = RowDesc{b, lens[b] - 1, (int32_t)ids[(size_t)b * P_max + lens[b] - 1], 1};
+  SMI_HIP(hipMemcpyAsync(L->plan, L->host_rows.data(), L->host_rows.size() * sizeof(RowDesc), hipMemcpyHostToDevice, st));
+  SMI_HIP(hipMemsetAsync(L->count, 0, 128, st));
+  SMI_HIP(hipMemsetAsync(L->finished, 0, 128, st));
+  SMI_HIP(hipMemsetAsync(L->step, 0, 4, st));
+  L->B = B; L->eos = eos_id; L->started = 1;
+  L->max_len = 0;
+  for (int b = 0; b < B; ++b) L->max_len = lens[b] > L->max_len ? lens[b] : L->max_len;
+  L->steps_launched = 1;
+  if (L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }  // eos / B are baked into the graph
+  for (size_t c = 0; c < nchunks; ++c) {
+    const int M = (int)((total - c * kMaxRows) < (size_t)kMaxRows ? (total - c * kMaxRows) : kMaxRows);
+    const RowDesc* rows = L->plan + c * kMaxRows;
+    if ((rc = launch_embed(L, rows, M, st))) return rc;
+    if ((rc = launch_layers(L, rows, M, true, st))) return rc;
+  }
+  SMI_HIP(hipMemcpyAsync(L->rows, L->plan + nchunks * kMaxRows, kMaxRows * sizeof(RowDesc), hipMemcpyDeviceToDevice, st));
+  if ((rc = launch_embed(L, L->rows, B, st))) return rc;
+  return launch_step(L, B, st);
+}
+
+int smi_llm_decode(smi_llm* L, int n_steps, void* stream) {
+  SMI_REQUIRE(L, "smi_llm_decode: null handle");
+  if (!L->started) { smi_set_error("smi_llm_decode before smi_llm_prefill"); return SMI_ESTATE; }
+  SMI_REQUIRE(n_steps >= 0, "smi_llm_decode: n_steps < 0");
+  SMI_REQUIRE(L->max_len + L->steps_launched + n_steps <= L->cfg.max_positions,
+              "smi_llm_decode: %d more steps would pass max_positions=%d (prompt %d, %d steps so far)", n_steps,
+              L->cfg.max_positions, L->max_len, L->steps_launched);
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (L->cfg.use_graph && n_steps > 0 && (!L->graph || L->graph_B != L->B)) {
+    if (L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }
+    hipStream_t cs;
+    SMI_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+      rc = launch_step(L, L->B, cs);
+      hipError_t e2 = hipStreamEndCapture(cs, &g);
+      if (rc == SMI_OK && e2 == hipSuccess && g) {
+        if (hipGraphInstantiate(&L->graph, g, nullptr, nullptr, 0) != hipSuccess) L->graph = nullptr;
+      }
+      if (g) (void)hipGraphDestroy(g);
+    }
+    (void)hipStreamDestroy(cs);
+    (void)hipGetLastError();
+    L->graph_B = L->B;
+    if (!L->graph) { smi_set_error("hipGraph capture of the decode step failed"); return SMI_EHIP; }
+  }
+  for (int s = 0; s < n_steps; ++s) {
+    if (L->cfg.use_graph) {
+      SMI_HIP(hipGraphLaunch(L->graph, st));
+    } else if ((rc = launch_step(L, L->B, st))) {
+      return rc;
+    }
+  }
+  L->steps_launched += n_steps;
+  return SMI_OK;
+}
+
+int smi_llm_all_done(smi_llm* L, int* all_done, void* stream) {
+  SMI_REQUIRE(L && all_done, "smi_llm_all_done: null argument");
+  int32_t fin[32];
+  SMI_HIP(hipMemcpyAsync(fin, L->finished, sizeof(fin), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  SMI_HIP(hipStreamSynchronize((hipStream_t)stream));
+  int d = 1;
+  for (int b = 0; b < L->B; ++b) d &= fin[b] != 0;
+  *all_done = d;
+  return SMI_OK;
+}
+
+int smi_llm_steps(smi_llm* L) {
+  if (!L) return SMI_EINVAL;
+  int32_t s = 0;
+  if (hipMemcpy(&s, L->step, 4, hipMemcpyDeviceToHost) != hipSuccess) return SMI_EHIP;
+  return s;
+}
+
+int smi_llm_get_tokens(smi_llm* L, int64_t* out, int32_t* lens, int cap, void* stream) {
+  SMI_REQUIRE(L && out && lens && cap >= 0, "smi_llm_get_tokens: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  int32_t cnt[32], step = 0;
+  SMI_HIP(hipMemcpyAsync(cnt, L->count, sizeof(cnt), hipMemcpyDeviceToHost, st));
+  SMI_HIP(hipMemcpyAsync(&step, L->step, 4, hipMemcpyDeviceToHost, st));
+  SMI_HIP(hipStreamSynchronize(st));
+  if (step > L->max_steps) step = L->max_steps;
+  std::vector<int64_t> hist((size_t)step * 32);
+  if (step) SMI_HIP(hipMemcpy(hist.data(), L->hist, hist.size() * 8, hipMemcpyDeviceToHost));
+  for (int b = 0; b < L->B; ++b) {
+    int n = cnt[b] < cap ? cnt[b] : cap;
+    if (n > step) n = step;
+    lens[b] = n;
+    for (int s = 0; s < n; ++s) out[(size_t)b * cap + s] = hist[(size_t)s * 32 + b];
+  }
+  return SMI_OK;
+}
+
+int smi_llm_forward_logits(smi_llm* L, const int64_t* ids, int S, float* logits_dev, void* stream) {
+  SMI_REQUIRE(L && ids && logits_dev, "smi_llm_forward_logits: null argument");
+  SMI_REQUIRE(S >= 1 && S < L->cfg.max_positions, "smi_llm_forward_logits: S=%d outside 1..max_positions-1", S);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nchunks = ((size_t)S + kMaxRows - 1) / kMaxRows;
+  int rc;
+  if ((rc = ensure_plan(L, nchunks * kMaxRows))) return rc;
+  L->host_rows.assign(nchunks * kMaxRows, RowDesc{0, 0, 0, 0});
+  for (int t = 0; t < S; ++t) {
+    SMI_REQUIRE(ids[t] >= 0 && ids[t] < L->cfg.vocab_size, "smi_llm_forward_logits: token id out of range");
+    L->host_rows[t] = RowDesc{0, t, (int32_t)ids[t], 1};
+  }
+  SMI_HIP(hipMemcpyAsync(L->plan, L->host_rows.data(), L->host_rows.size() * sizeof(RowDesc), hipMemcpyHostToDevice, st));
+  for (size_t c = 0; c < nchunks; ++c) {
+    const int M = (int)(((size_t)S - c * kMaxRows) < (size_t)kMaxRows ? ((size_t)S - c * kMaxRows) : kMaxRows);
+    const RowDesc* rows = L->plan + c * kMaxRows;
+    if ((rc = launch_embed(L, rows, M, st))) return rc;
+    if ((rc = launch_layers(L, rows, M, false, st))) return rc;
+    if ((rc = launch_one(L, KLM, 0, rows, M, logits_dev + c * kMaxRows * (size_t)L->cfg.vocab_size, st))) return rc;
+  }
+  L->started = 0;  // the cache now holds this sequence; a generate must prefill again
+  return SMI_OK;
+}
+
+int smi_llm_time_kernel(smi_llm* L, int kernel, int layer, int iters, float* ms_avg, void* stream) {
+  SMI_REQUIRE(L && ms_avg && iters > 0, "smi_llm_time_kernel: bad argument");
+  SMI_REQUIRE(kernel >= 0 && kernel <= 7, "smi_llm_time_kernel: kernel id %d", kernel);
+  if (!L->started) { smi_set_error("smi_llm_time_kernel needs a started generation (prefill first)"); return SMI_ESTATE; }
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (kernel == 7) {
+    if ((rc = smi_llm_decode(L, 1, stream))) return rc;  // builds the graph if needed
+    SMI_HIP(hipEventRecord(L->ev0, st));
+    if ((rc = smi_llm_decode(L, iters, stream))) return rc;
+    SMI_HIP(hipEventRecord(L->ev1, st));
+  } else {
+    const int nl = L->cfg.num_layers;
+    if (kernel == KFIN) {
+      SMI_REQUIRE(L->max_len + L->steps_launched + iters + 1 <= L->cfg.max_positions, "smi_llm_time_kernel: finalize probe would pass max_positions");
+      L->steps_launched += iters + 1;
+    }
+    if ((rc = launch_one(L, kernel, layer % nl, L->rows, L->B, nullptr, st))) return rc;
+    SMI_HIP(hipEventRecord(L->ev0, st));
+    for (int i = 0; i < iters; ++i) {
+      // walk the layers so the weights come from HBM, not from the Infinity Cache
+      const int l = kernel >= KLM ? 0 : (layer + 1 + i) % nl;
+      if ((rc = launch_one(L, kernel, l, L->rows, L->B, nullptr, st))) return rc;
+    }
+    SMI_HIP(hipEventRecord(L->ev1, st));
+  }
+  SMI_HIP(hipEventSynchronize(L->ev1));
+  float ms = 0.f;
+  SMI_HIP(hipEventElapsedTime(&ms, L->ev0, L->ev1));
+  *ms_avg = ms / iters;
+  return SMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+"""ctypes binding of ``libsparkmi.so`` (``include/sparkmi.h``).
+
+The library is built in-tree by ``spark-tts_amd/csrc/Makefile`` (``__graft_entry__.build()``).
+There is no fallback: a missing library raises at first use.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libsparkmi.so"
+
+SMI_MAX_ROWS = 32
+
+
+class SparkMIError(RuntimeError):
+    pass
+
+
+class LLMCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "vocab_size", "hidden_size", "num_layers", "num_heads", "num_kv_heads", "head_dim",
+        "intermediate_size", "max_slots", "max_positions", "kv_dtype", "use_graph")] + [("rms_eps", C.c_float)]
+
+
+class VocCfg(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in (
+        "vq_input_dim", "codebook_size", "codebook_dim",
+        "spk_out_dim", "spk_latent_dim", "spk_token_num", "fsq_dims")]
+        + [("fsq_levels", C.c_int32 * 8)]
+        + [(n, C.c_int32) for n in (
+            "pre_input_channels", "pre_dim", "pre_inter", "pre_layers", "pre_out_channels",
+            "pre_cond_dim", "pre_num_down", "pre_tanh_final", "dec_in", "dec_channels", "dec_nblocks")]
+        + [("dec_rates", C.c_int32 * 8), ("dec_ksizes", C.c_int32 * 8)]
+        + [("max_batch", C.c_int32), ("max_frames", C.c_int32)])
+
+
+# section ids of enum smi_llm_section
+(LLM_LN1, LLM_WQKV, LLM_BQKV, LLM_WO, LLM_LN2, LLM_WGU, LLM_WD,
+ LLM_FINAL_NORM, LLM_LM_HEAD, LLM_ROPE) = range(10)
+
+# every symbol include/sparkmi.h declares: (name, restype, argtypes)
+_VP, _I, _SZ = C.c_void_p, C.c_int, C.c_size_t
+_P = C.POINTER
+SYMBOLS = {
+    "smi_version": (_I, []),
+    "smi_last_error": (C.c_char_p, []),
+    "smi_device_check": (_I, [C.c_char_p, _I]),
+    "smi_llm_arena_bytes": (_SZ, [_P(LLMCfg)]),
+    "smi_llm_arena_section": (_I, [_P(LLMCfg), _I, _I, _P(_SZ), _P(_SZ)]),
+    "smi_llm_create": (_I, [_P(LLMCfg), _VP, _SZ, _P(_VP)]),
+    "smi_llm_destroy": (_I, [_VP]),
+    "smi_llm_prefill": (_I, [_VP, _P(C.c_int64), _P(C.c_int32), _I, _I, C.c_int64, _VP]),
+    "smi_llm_decode": (_I, [_VP, _I, _VP]),
+    "smi_llm_all_done": (_I, [_VP, _P(_I), _VP]),
+    "smi_llm_get_tokens": (_I, [_VP, _P(C.c_int64), _P(C.c_int32), _I, _VP]),
+    "smi_llm_forward_logits": (_I, [_VP, _P(C.c_int64), _I, _VP, _VP]),
+    "smi_llm_steps": (_I, [_VP]),
+    "smi_llm_time_kernel": (_I, [_VP, _I, _I, _I, _P(C.c_float), _VP]),
+    "smi_voc_arena_count": (_I, [_P(VocCfg)]),
+    "smi_voc_arena_entry": (_I, [_P(VocCfg), _I, C.c_char_p, _I, _P(_SZ), _P(_SZ), _P(C.c_int32)]),
+    "smi_voc_arena_bytes": (_SZ, [_P(VocCfg)]),
+    "smi_voc_create": (_I, [_P(VocCfg), _VP, _SZ, _P(_VP)]),
+    "smi_voc_destroy": (_I, [_VP]),
+    "smi_voc_forward": (_I, [_VP, _VP, _P(C.c_int32), _VP, _I, _I, _VP, _VP]),
+    "smi_voc_debug_stage": (_I, [_VP, _I, _VP, _SZ, _P(_SZ), _VP]),
+    "smi_voc_num_launches": (_I, [_VP]),
+    "smi_voc_time_launch": (_I, [_VP, _I, _I, _P(C.c_float), _P(C.c_double), C.c_char_p, _I, _VP]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the library; raises SparkMIError when it is not built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise SparkMIError(
+                f"{LIB_PATH} is missing: build it with `make -C spark-tts_amd/csrc` "
+                "(or __graft_entry__.build()). sparkmi has no CPU fallback.")
+        l = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)   # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        if l.smi_version() != 1:
+            raise SparkMIError(f"libsparkmi ABI version {l.smi_version()} != 1")
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().smi_last_error().decode(errors="replace")
+        raise SparkMIError(f"{what or 'libsparkmi'} failed (code {rc}): {msg}")
+
+
+def require_gfx950() -> str:
+    buf = C.create_string_buffer(128)
+    check(lib().smi_device_check(buf, 128), "smi_device_check")
+    return buf.value.decode()

@@ -1,0 +1,102 @@
+"""Weight-arena packing: checkpoint tensors -> the HBM layouts the HIP kernels stream.
+
+LLM (``smi_llm_*``): every matrix is bf16 in 16-row x 32-column tiles stored
+``[n_tile][k_tile][k8:4][n:16][8]`` -- one tile is 1 KiB, exactly one wave64 x 16-byte load and
+one ``v_mfma_f32_16x16x32_bf16`` A operand.  Row orders are chosen so epilogues stay in
+registers: q/k head rows as RoPE pairs (0,32,1,33,...), gate/up interleaved.  Section offsets
+come from the library itself (``smi_llm_arena_section``), so there is one source of truth.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Mapping
+
+import numpy as np
+
+from . import _lib
+from .config import LLMConfig
+from .weights import f32_to_bf16_bits
+
+
+def pack_tiles(w: np.ndarray) -> np.ndarray:
+    """[N, K] fp32 -> uint16 bf16 bits in MFMA A-operand tile order; N padded to 16 with zeros."""
+    n, k = w.shape
+    if k % 32:
+        raise ValueError(f"K={k} must be a multiple of 32")
+    npad = (n + 15) // 16 * 16
+    bits = f32_to_bf16_bits(w).reshape(n, k)
+    if npad != n:
+        bits = np.concatenate([bits, np.zeros((npad - n, k), np.uint16)], axis=0)
+    t = bits.reshape(npad // 16, 16, k // 32, 4, 8).transpose(0, 2, 3, 1, 4)
+    return np.ascontiguousarray(t).reshape(-1)
+
+
+def rope_pair_perm(n_heads: int, head_dim: int = 64) -> np.ndarray:
+    """Row permutation placing RoPE partners (d, d + head_dim/2) in adjacent rows of each head."""
+    half = head_dim // 2
+    p = np.arange(head_dim)
+    within = (p >> 1) + half * (p & 1)
+    return (np.arange(n_heads)[:, None] * head_dim + within[None, :]).reshape(-1)
+
+
+def rope_table(cfg: LLMConfig, max_positions: int) -> np.ndarray:
+    """(cos, sin) [max_positions][head_dim/2] float32, computed with the same torch ops as
+    transformers' Qwen2RotaryEmbedding (modeling_qwen2.py:81-102) so the bits match the oracle."""
+    import torch
+    d = cfg.head_dim
+    inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+    pos = torch.arange(max_positions, dtype=torch.float32)
+    freqs = pos[:, None] * inv_freq[None, :]
+    return torch.stack((freqs.cos(), freqs.sin()), dim=-1).numpy().astype(np.float32)
+
+
+def llm_cfg_struct(cfg: LLMConfig, max_slots: int, max_positions: int, kv_dtype: str,
+                   use_graph: bool) -> _lib.LLMCfg:
+    return _lib.LLMCfg(
+        vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_layers=cfg.num_hidden_layers,
+        num_heads=cfg.num_attention_heads, num_kv_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+        intermediate_size=cfg.intermediate_size, max_slots=max_slots, max_positions=max_positions,
+        kv_dtype={"bf16": 0, "f32": 1}[kv_dtype], use_graph=int(use_graph), rms_eps=cfg.rms_norm_eps)
+
+
+def pack_llm_arena(cfg: LLMConfig, weights: Mapping[str, np.ndarray], cs: _lib.LLMCfg) -> np.ndarray:
+    """Host uint8 image of the whole LLM arena (caller uploads it to the GPU)."""
+    lib = _lib.lib()
+    total = lib.smi_llm_arena_bytes(C.byref(cs))
+    if total == 0:
+        raise _lib.SparkMIError("smi_llm_arena_bytes: config outside the kernel contract")
+    arena = np.zeros(total, dtype=np.uint8)
+
+    def put(section: int, layer: int, data: np.ndarray) -> None:
+        off, nbytes = C.c_size_t(), C.c_size_t()
+        _lib.check(lib.smi_llm_arena_section(C.byref(cs), section, layer, C.byref(off), C.byref(nbytes)),
+                   "smi_llm_arena_section")
+        raw = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        if raw.size != nbytes.value:
+            raise ValueError(f"section {section} layer {layer}: {raw.size} bytes packed, {nbytes.value} expected")
+        arena[off.value: off.value + raw.size] = raw
+
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+    pq = rope_pair_perm(cfg.num_attention_heads, cfg.head_dim)
+    pk = rope_pair_perm(cfg.num_key_value_heads, cfg.head_dim)
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        wq, wk, wv = (f32(weights[p + f"self_attn.{n}_proj.weight"]) for n in "qkv")
+        bq, bk, bv = (f32(weights[p + f"self_attn.{n}_proj.bias"]) for n in "qkv")
+        put(_lib.LLM_LN1, i, f32(weights[p + "input_layernorm.weight"]))
+        put(_lib.LLM_WQKV, i, pack_tiles(np.concatenate([wq[pq], wk[pk], wv], axis=0)))
+        put(_lib.LLM_BQKV, i, np.concatenate([bq[pq], bk[pk], bv]))
+        put(_lib.LLM_WO, i, pack_tiles(f32(weights[p + "self_attn.o_proj.weight"])))
+        put(_lib.LLM_LN2, i, f32(weights[p + "post_attention_layernorm.weight"]))
+        g, u = f32(weights[p + "mlp.gate_proj.weight"]), f32(weights[p + "mlp.up_proj.weight"])
+        gu = np.empty((2 * g.shape[0], g.shape[1]), np.float32)
+        gu[0::2], gu[1::2] = g, u
+        put(_lib.LLM_WGU, i, pack_tiles(gu))
+        put(_lib.LLM_WD, i, pack_tiles(f32(weights[p + "mlp.down_proj.weight"])))
+    put(_lib.LLM_FINAL_NORM, 0, f32(weights["model.norm.weight"]))
+    head = "model.embed_tokens.weight" if cfg.tie_word_embeddings else "lm_head.weight"
+    if not cfg.tie_word_embeddings:
+        raise NotImplementedError("untied lm_head: the kernels gather embeddings from the lm_head tiles")
+    put(_lib.LLM_LM_HEAD, 0, pack_tiles(f32(weights[head])))
+    put(_lib.LLM_ROPE, 0, rope_table(cfg, cs.max_positions))
+    return arena

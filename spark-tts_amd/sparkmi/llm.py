@@ -1,0 +1,169 @@
+"""SparkLLM -- the speech-token generator behind ``AutoModelForCausalLM.generate`` as the
+reference calls it (``cli/SparkTTS.py:197-204``), running on the HIP kernels of ``smi_llm.hip``.
+
+``generate`` keeps the HF call shape (``input_ids`` (B, P), ``attention_mask``,
+``max_new_tokens``, ``do_sample``, ``eos_token_id``, ``pad_token_id``) and returns (B, P + N)
+ids, prompt included, exactly like the reference expects when it slices the prompt off at
+``cli/SparkTTS.py:207-210``.  Greedy (``do_sample=False``) only in this round.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Mapping, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .arena import llm_cfg_struct, pack_llm_arena
+from .config import LLMConfig
+
+
+class SparkLLM:
+    def __init__(self, cfg: LLMConfig, weights: Mapping[str, np.ndarray],
+                 device: Union[str, torch.device] = "cuda:0", max_slots: int = 1,
+                 max_positions: int = 4096, kv_dtype: str = "bf16", use_graph: bool = True,
+                 arena: Optional[torch.Tensor] = None):
+        cfg.validate()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.SparkMIError("SparkLLM runs on an MI355X only (device must be cuda:N); there is no CPU path")
+        self._lib = _lib.lib()
+        torch.cuda.set_device(self.device)
+        _lib.require_gfx950()
+        self.max_slots, self.max_positions = max_slots, max_positions
+        self._cs = llm_cfg_struct(cfg, max_slots, max_positions, kv_dtype, use_graph)
+        if arena is None:
+            host = pack_llm_arena(cfg, weights, self._cs)
+            arena = torch.from_numpy(host).to(self.device)
+        self.arena = arena  # uint8 device tensor; must outlive the handle
+        self._h = C.c_void_p()
+        _lib.check(self._lib.smi_llm_create(C.byref(self._cs), C.c_void_p(arena.data_ptr()),
+                                            arena.numel(), C.byref(self._h)), "smi_llm_create")
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self) -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.smi_llm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ generation
+    def prefill(self, prompts: Sequence[Sequence[int]], eos_token_id: Optional[int] = None) -> None:
+        B = len(prompts)
+        lens = np.array([len(p) for p in prompts], dtype=np.int32)
+        pmax = int(lens.max())
+        ids = np.zeros((B, pmax), dtype=np.int64)
+        for b, p in enumerate(prompts):
+            ids[b, : len(p)] = np.asarray(p, dtype=np.int64)
+        _lib.check(self._lib.smi_llm_prefill(
+            self._h, ids.ctypes.data_as(C.POINTER(C.c_int64)), lens.ctypes.data_as(C.POINTER(C.c_int32)),
+            B, pmax, -1 if eos_token_id is None else int(eos_token_id), self._stream()), "smi_llm_prefill")
+        self._B, self._lens = B, lens
+
+    def decode(self, n_steps: int) -> None:
+        _lib.check(self._lib.smi_llm_decode(self._h, int(n_steps), self._stream()), "smi_llm_decode")
+
+    def all_done(self) -> bool:
+        d = C.c_int(0)
+        _lib.check(self._lib.smi_llm_all_done(self._h, C.byref(d), self._stream()), "smi_llm_all_done")
+        return bool(d.value)
+
+    def tokens(self, cap: int) -> List[List[int]]:
+        out = np.zeros((self._B, cap), dtype=np.int64)
+        lens = np.zeros(self._B, dtype=np.int32)
+        _lib.check(self._lib.smi_llm_get_tokens(
+            self._h, out.ctypes.data_as(C.POINTER(C.c_int64)), lens.ctypes.data_as(C.POINTER(C.c_int32)),
+            cap, self._stream()), "smi_llm_get_tokens")
+        return [out[b, : lens[b]].tolist() for b in range(self._B)]
+
+    def generate_ids(self, prompts: Sequence[Sequence[int]], max_new_tokens: int,
+                     eos_token_id: Optional[int] = None, check_every: int = 32) -> List[List[int]]:
+        """Greedy generation for B ragged prompts; returns only the new ids per sequence
+        (eos included when emitted).  With no eos the whole run is enqueued without a host sync."""
+        if max_new_tokens < 1:
+            raise ValueError("max_new_tokens must be >= 1")
+        longest = max(len(p) for p in prompts)
+        if longest + max_new_tokens > self.max_positions:
+            raise ValueError(f"prompt ({longest}) + max_new_tokens ({max_new_tokens}) exceeds "
+                             f"max_positions ({self.max_positions})")
+        self.prefill(prompts, eos_token_id)
+        remaining = max_new_tokens - 1
+        if eos_token_id is None:
+            self.decode(remaining)
+        else:
+            while remaining > 0 and not self.all_done():
+                n = min(check_every, remaining)
+                self.decode(n)
+                remaining -= n
+        return self.tokens(max_new_tokens)
+
+    @torch.no_grad()
+    def generate(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                 max_new_tokens: int = 3000, do_sample: bool = False, eos_token_id: Optional[int] = None,
+                 pad_token_id: Optional[int] = None, **unused) -> torch.Tensor:
+        """HF-shaped entry.  ``attention_mask`` marks real tokens of right- or left-padded rows."""
+        if do_sample:
+            raise NotImplementedError(
+                "sampling (top-k/top-p/temperature) is not built yet; pass do_sample=False for the "
+                "greedy path (SURVEY section 8f item 2)")
+        ids = input_ids.detach().cpu().numpy().astype(np.int64)
+        if ids.ndim == 1:
+            ids = ids[None]
+        if attention_mask is not None:
+            msk = attention_mask.detach().cpu().numpy().astype(bool)
+            prompts = [ids[b][msk[b]].tolist() for b in range(ids.shape[0])]
+        else:
+            prompts = [ids[b].tolist() for b in range(ids.shape[0])]
+        new = self.generate_ids(prompts, max_new_tokens, eos_token_id)
+        pad = pad_token_id if pad_token_id is not None else (eos_token_id if eos_token_id is not None else 0)
+        n = max(len(t) for t in new)
+        out = np.full((ids.shape[0], ids.shape[1] + n), pad, dtype=np.int64)
+        out[:, : ids.shape[1]] = ids
+        for b, t in enumerate(new):
+            out[b, ids.shape[1]: ids.shape[1] + len(t)] = t
+        return torch.from_numpy(out).to(input_ids.device)
+
+    # ------------------------------------------------------------------ test / bench entries
+    def forward_logits(self, ids: Sequence[int]) -> torch.Tensor:
+        """Teacher-forced logits (S, V) for one sequence fed at positions 0..S-1."""
+        a = np.asarray(ids, dtype=np.int64)
+        out = torch.empty((a.shape[0], self.cfg.vocab_size), dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.smi_llm_forward_logits(
+            self._h, a.ctypes.data_as(C.POINTER(C.c_int64)), a.shape[0], C.c_void_p(out.data_ptr()),
+            self._stream()), "smi_llm_forward_logits")
+        return out
+
+    KERNELS = ("qkv", "attn", "o_proj", "gate_up", "down", "lm_head", "finalize", "step")
+
+    def time_kernel(self, name: str, iters: int = 48, layer: int = 0) -> float:
+        """Average milliseconds per launch of one decode-step kernel (HIP events on this stream)."""
+        ms = C.c_float(0)
+        _lib.check(self._lib.smi_llm_time_kernel(self._h, self.KERNELS.index(name), layer, iters,
+                                                 C.byref(ms), self._stream()), "smi_llm_time_kernel")
+        return float(ms.value)
+
+    # algorithmic bytes -------------------------------------------------------------------
+    def weight_bytes(self) -> dict:
+        c = self.cfg
+        h, q, kv, i = c.hidden_size, c.q_dim, c.kv_dim, c.intermediate_size
+        return {"qkv": 2 * (q + 2 * kv) * h, "o_proj": 2 * h * q, "gate_up": 2 * 2 * i * h, "down": 2 * h * i,
+                "lm_head": 2 * c.vocab_size * h}
+
+    def step_weight_bytes(self) -> int:
+        w = self.weight_bytes()
+        per_layer = w["qkv"] + w["o_proj"] + w["gate_up"] + w["down"]
+        return self.cfg.num_hidden_layers * per_layer + w["lm_head"]
+
+    def kv_bytes_per_token(self) -> int:
+        esz = 4 if self._cs.kv_dtype else 2
+        return self.cfg.num_hidden_layers * 2 * self.cfg.kv_dim * esz
