@@ -132,8 +132,11 @@ typedef struct smi_voc_cfg {
 /* The vocoder arena is a flat f32 buffer of tensors in the order smi_voc_arena_entry enumerates
  * (name = the reference state_dict key after remove_weight_norm, or a derived packed tensor). */
 int smi_voc_arena_count(const smi_voc_cfg* cfg);
+/* info: int32[6] = {packing kind (0 raw f32 copy, 1 Conv1d/Linear weight [Cout][Cin][K], 2 ConvTranspose1d
+ * weight [Cin][Cout][K]), Cout, Cin, K, stride, padding}.  Packed conv weights are laid out
+ * [phase][cout_tile:32][tap][cin_group:8][lane:64][4] = v_mfma_f32_32x32x2_f32 A operands (sparkmi/bicodec.py). */
 int smi_voc_arena_entry(const smi_voc_cfg* cfg, int index, char* name, int name_cap,
-                        size_t* offset, size_t* bytes, int32_t* packing);
+                        size_t* offset, size_t* bytes, int32_t* info);
 size_t smi_voc_arena_bytes(const smi_voc_cfg* cfg);
 
 int smi_voc_create(const smi_voc_cfg* cfg, const void* arena_dev, size_t arena_bytes, smi_voc** out);

@@ -1,13 +1,869 @@
-// placeholder until the vocoder kernels land (next commit)
+// smi_voc.hip -- BiCodec vocoder (detokenize path) for gfx950 (MI355X).
+//
+// Stands behind BiCodec.detokenize (sparktts/models/bicodec.py:171-189):
+//   quantizer.detokenize        sparktts/modules/vq/factorized_vector_quantize.py:154-167
+//   speaker_encoder.detokenize  sparktts/modules/speaker/speaker_encoder.py:107-112,
+//                               fsq/residual_fsq.py:112-199, fsq/finite_scalar_quantization.py:143-162
+//   prenet (Decoder)            sparktts/modules/encoder_decoder/feat_decoder.py:78-94,
+//                               blocks/vocos.py:65-110,324-335, blocks/samper.py:79-100 (ratio 1 => 3x)
+//   decoder (WaveGenerator)     sparktts/modules/encoder_decoder/wave_generator.py:29-88,
+//                               blocks/layers.py:33-67 (snake, ResidualUnit)
+//
+// Every dense contraction (Linear, Conv1d incl. dilated, ConvTranspose1d as polyphase taps) runs
+// through ONE implicit-GEMM kernel on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32: the
+// reference computes in fp32 and the parity bar is 1e-3 on the waveform).  Activations are
+// [B][C][T] fp32 with time contiguous; input tiles (+halo) are staged through LDS once per
+// 32-channel chunk and re-read per tap; weights are pre-packed in MFMA A-operand order so each
+// lane streams float4s.  Elementwise work is fused into the producing kernel's epilogue: bias,
+// per-utterance bias (d-vector), layer-scale, residual add, GELU / tanh, and the *next* layer's
+// Snake activation (written as a second output), so no standalone elementwise kernel exists.
+// Ragged batches: every kernel masks loads beyond the row's own length, so each row equals an
+// un-padded B=1 run of that row.
 #include "smi_common.h"
-extern "C" {
-int smi_voc_arena_count(const smi_voc_cfg*) { return 0; }
-int smi_voc_arena_entry(const smi_voc_cfg*, int, char*, int, size_t*, size_t*, int32_t*) { smi_set_error("vocoder not built"); return SMI_EINVAL; }
-size_t smi_voc_arena_bytes(const smi_voc_cfg*) { return 0; }
-int smi_voc_create(const smi_voc_cfg*, const void*, size_t, smi_voc**) { smi_set_error("vocoder not built"); return SMI_EINVAL; }
-int smi_voc_destroy(smi_voc*) { return SMI_OK; }
-int smi_voc_forward(smi_voc*, const int64_t*, const int32_t*, const int32_t*, int, int, float*, void*) { smi_set_error("vocoder not built"); return SMI_EINVAL; }
-int smi_voc_debug_stage(smi_voc*, int, float*, size_t, size_t*, void*) { smi_set_error("vocoder not built"); return SMI_EINVAL; }
-int smi_voc_num_launches(smi_voc*) { return 0; }
-int smi_voc_time_launch(smi_voc*, int, int, float*, double*, char*, int, void*) { smi_set_error("vocoder not built"); return SMI_EINVAL; }
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+namespace {
+
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2 };
+enum { PACK_RAW = 0, PACK_CONV = 1, PACK_CONVT = 2 };
+constexpr int kMaxTaps = 8;     // taps per phase
+constexpr int kMaxPhases = 8;   // ConvTranspose1d stride
+constexpr int kChunk = 32;      // input channels staged per LDS chunk
+
+struct ConvP {
+  const float* X;       // [B][Cin][xstride]
+  const float* W;       // packed, phase-major
+  const float* bias;    // [Cout] or null
+  const float* bbias;   // [B][Cout] per-utterance bias or null
+  const float* gamma;   // [Cout] layer scale or null
+  const float* R;       // residual [B][Cout][ystride] or null (may alias Y)
+  const float* alpha;   // [Cout] Snake alpha for Ys or null
+  float* Y;             // raw output or null
+  float* Ys;            // snake(Y, alpha) or null
+  const int* lens;      // [B] valid INPUT lengths
+  int Cin, CinP, Cout, S, act;
+  int xstride, ystride;
+  long long xb, yb;     // batch strides (floats)
+  int halo_l, xw;       // left halo, staged row width (floats)
+  float out_scale;
+  int ntaps[kMaxPhases];
+  int off[kMaxPhases][kMaxTaps];
+  long long wphase[kMaxPhases];  // float offset of each phase's weights
+};
+
+__device__ __forceinline__ float snake_f(float x, float a) {
+  const float s = sinf(a * x);
+  return x + (1.0f / (a + 1e-9f)) * (s * s);
 }
+__device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// QB: 32-wide time sub-tiles per wave.  KS: waves split the input channels of ONE 32-row output
+// tile (large C, short T) instead of owning a 32-row output tile each.
+template <int QB, bool KS>
+__global__ __launch_bounds__(256) void k_conv(ConvP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int QT = QB * 32;
+  const int b = blockIdx.z / p.S, phase = blockIdx.z - b * p.S;
+  const int q0 = blockIdx.x * QT;
+  const int len = p.lens[b];
+  if (q0 >= len) return;
+  const int ct = KS ? blockIdx.y : blockIdx.y * 4 + wave;
+  const bool live = ct * 32 < p.Cout;
+  const int ntap = p.ntaps[phase];
+  const int groups = p.CinP >> 3;
+  const float* Xb = p.X + (long long)b * p.xb;
+  const float4* Wp = (const float4*)(p.W + p.wphase[phase]) + (long long)ct * ntap * groups * 64;
+
+  f32x16 acc[QB];
+#pragma unroll
+  for (int i = 0; i < QB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int xw = p.xw;
+  for (int c0 = 0; c0 < p.CinP; c0 += kChunk) {
+    if (c0) __syncthreads();
+    for (int i = tid; i < kChunk * xw; i += 256) {
+      const int row = i / xw, col = i - row * xw;
+      const int ci = c0 + row, t = q0 - p.halo_l + col;
+      float v = 0.f;
+      if (ci < p.Cin && t >= 0 && t < len) v = Xb[(long long)ci * p.xstride + t];
+      lds[i] = v;
+    }
+    __syncthreads();
+    if (live) {
+      const int g0 = KS ? wave : 0, g1 = KS ? wave + 1 : 4;
+      for (int tap = 0; tap < ntap; ++tap) {
+        const int col0 = p.halo_l + p.off[phase][tap] + (lane & 31);
+        for (int g = g0; g < g1; ++g) {
+          if (c0 + g * 8 >= p.CinP) break;
+          const float4 wv = Wp[((long long)tap * groups + (c0 >> 3) + g) * 64 + lane];
+          const float wa[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float* xr = lds + (g * 8 + j * 2 + (lane >> 5)) * xw + col0;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+              acc[qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], xr[qb * 32], acc[qb], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  if (KS) {
+    // fixed-order reduction of the four waves' partial tiles, then each wave finishes 4 of the 16 rows-groups
+    __syncthreads();
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lds[((wave * QB + qb) * 16 + r) * 64 + lane] = acc[qb][r];
+    __syncthreads();
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = wave * 4 + rr;
+        float s = lds[((0 * QB + qb) * 16 + r) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) s += lds[((w * QB + qb) * 16 + r) * 64 + lane];
+        acc[qb][rr] = s;
+      }
+  }
+  if (!live) return;
+
+  const long long yboff = (long long)b * p.yb;
+  const int nreg = KS ? 4 : 16;
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int q = q0 + qb * 32 + (lane & 31);
+    if (q >= len) continue;
+    const int t = q * p.S + phase;
+#pragma unroll
+    for (int rr = 0; rr < nreg; ++rr) {
+      const int r = KS ? wave * 4 + rr : rr;
+      const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (co >= p.Cout) continue;
+      float y = acc[qb][rr];
+      if (p.bias) y += p.bias[co];
+      if (p.bbias) y += p.bbias[(long long)b * p.Cout + co];
+      if (p.act == ACT_GELU) y = gelu_f(y);
+      if (p.gamma) y = p.gamma[co] * y;
+      const long long o = yboff + (long long)co * p.ystride + t;
+      if (p.R) y = p.R[o] + y;
+      if (p.act == ACT_TANH) y = tanhf(y);
+      if (p.out_scale != 1.0f) y = (y + y) + y;  // SamplingBlock(ratio 1): x + x + x
+      if (p.Y) p.Y[o] = y;
+      if (p.Ys) p.Ys[o] = snake_f(y, p.alpha[co]);
+    }
+  }
+}
+
+// depthwise conv7 (optional) + LayerNorm / AdaLayerNorm over channels, eps 1e-6 (vocos.py:65-110)
+struct LnP {
+  const float* X;      // [B][C][stride]
+  float* Y;
+  const float* dww;    // [C][7] or null
+  const float* dwb;    // [C]
+  const float* w;      // LN weight [C] (plain) or null
+  const float* bsh;    // LN bias [C]
+  const float* ada;    // AdaLN: [B][ada_stride] with scale at +0, shift at +C; or null
+  const int* lens;
+  int C, stride, ada_stride;
+  long long bs;
+  int triple;          // 1: write 3x (SamplingBlock ratio 1 after final_layer_norm)
+};
+
+template <int CPT>  // channels per thread (C <= 8*CPT)
+__global__ __launch_bounds__(256) void k_dwln(LnP p) {
+  __shared__ float red[8][32];
+  const int tt = threadIdx.x & 31, cg = threadIdx.x >> 5;
+  const int b = blockIdx.y, t = blockIdx.x * 32 + tt;
+  const int len = p.lens[b];
+  const bool tv = t < len;
+  const float* Xb = p.X + (long long)b * p.bs;
+  float v[CPT];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = cg + 8 * i;
+    float x = 0.f;
+    if (c < p.C && tv) {
+      const float* xr = Xb + (long long)c * p.stride;
+      if (p.dww) {
+        x = 0.f;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          const int tj = t + j - 3;
+          const float xv = (tj >= 0 && tj < len) ? xr[tj] : 0.f;
+          x += p.dww[c * 7 + j] * xv;
+        }
+        x += p.dwb[c];
+      } else {
+        x = xr[t];
+      }
+    }
+    v[i] = x;
+    s += x;
+  }
+  red[cg][tt] = s;
+  __syncthreads();
+  float mean = 0.f;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) mean += red[g][tt];
+  mean /= (float)p.C;
+  __syncthreads();
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = cg + 8 * i;
+    if (c < p.C) { const float d = v[i] - mean; q += d * d; }
+  }
+  red[cg][tt] = q;
+  __syncthreads();
+  float var = 0.f;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) var += red[g][tt];
+  const float rstd = 1.0f / sqrtf(var / (float)p.C + 1e-6f);
+  if (!tv) return;
+  float* Yb = p.Y + (long long)b * p.bs;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = cg + 8 * i;
+    if (c >= p.C) continue;
+    float y = (v[i] - mean) * rstd;
+    if (p.ada) y = y * p.ada[(long long)b * p.ada_stride + c] + p.ada[(long long)b * p.ada_stride + p.C + c];
+    else y = y * p.w[c] + p.bsh[c];
+    if (p.triple) y = (y + y) + y;
+    Yb[(long long)c * p.stride + t] = y;
+  }
+}
+
+// codebook lookup: Z[b][d][t] = codebook[sem[b][t]][d]   (factorized_vector_quantize.py:160-167)
+__global__ void k_codebook(const int64_t* sem, int semstride, const float* cb, int D, int cbsize,
+                           const int* lens, float* Z, int zstride, long long zb) {
+  const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= lens[b]) return;
+  long long id = sem[(long long)b * semstride + t];
+  id = id < 0 ? 0 : (id >= cbsize ? cbsize - 1 : id);
+  for (int d = 0; d < D; ++d) Z[(long long)b * zb + (long long)d * zstride + t] = cb[id * D + d];
+}
+
+// FSQ index -> level codes -> Linear(nd -> latent), written d-major: out[b][d*Ntok + t]
+// (finite_scalar_quantization.py:143-162, residual_fsq.py:191-199, speaker_encoder.py:109-110)
+struct FsqP {
+  const int32_t* glob;  // [B][Ntok]
+  const float* W1;      // [latent][nd]
+  const float* b1;      // [latent]
+  float* out;           // [B][latent*Ntok]
+  int Ntok, latent, nd;
+  int levels[8];
+};
+__global__ void k_fsq(FsqP p) {
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < p.latent * p.Ntok; i += blockDim.x) {
+    const int d = i / p.Ntok, t = i - d * p.Ntok;
+    int idx = p.glob[b * p.Ntok + t];
+    float acc = 0.f;
+    int basis = 1;
+    for (int j = 0; j < p.nd; ++j) {
+      const int L = p.levels[j], half = L / 2;
+      const int lvl = (idx / basis) % L;
+      const float code = (float)(lvl - half) / (float)half;
+      acc += code * p.W1[d * p.nd + j];
+      basis *= L;
+    }
+    p.out[(long long)b * p.latent * p.Ntok + i] = acc + p.b1[d];
+  }
+}
+
+__global__ void k_zero_tail(float* wav, int stride, const int* lens, int hop) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < stride && t >= lens[b] * hop) wav[(long long)b * stride + t] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------
+// arena description
+// ------------------------------------------------------------------------------------------
+struct Entry {
+  std::string name;   // reference state_dict key (after remove_weight_norm); "cat:a|b|c" = rows concatenated
+  int kind;           // PACK_*
+  int Cout, Cin, K;   // logical dims (K taps)
+  int S, pad;         // ConvTranspose1d stride / padding
+  size_t offset, bytes;
+};
+
+struct ConvGeom {
+  int S;
+  int ntaps[kMaxPhases];
+  int off[kMaxPhases][kMaxTaps];
+  int tapk[kMaxPhases][kMaxTaps];   // kernel index j of each (phase, tap)
+  long long wphase[kMaxPhases];
+  int halo_l, halo_r;
+  long long floats;
+};
+
+inline int pad8(int c) { return (c + 7) / 8 * 8; }
+inline int pad32(int c) { return (c + 31) / 32 * 32; }
+
+// Conv1d (S = 1): tap j reads x[t + j*dil - pad].  ConvTranspose1d (stride S, padding pad):
+// out[q*S + r] += W[ci][co][j] * x[ci][(q*S + r + pad - j)/S] for j == (r + pad) mod S.
+ConvGeom conv_geom(int Cout, int Cin, int K, int dil, int pad, int S) {
+  ConvGeom g;
+  memset(&g, 0, sizeof(g));
+  g.S = S;
+  long long o = 0;
+  int lo = 0, hi = 0;
+  const long long per_tap = (long long)(pad32(Cout) / 32) * (pad8(Cin) / 8) * 256;
+  for (int r = 0; r < S; ++r) {
+    g.wphase[r] = o;
+    int n = 0;
+    if (S == 1) {
+      for (int j = 0; j < K; ++j) { g.off[r][n] = j * dil - pad; g.tapk[r][n] = j; ++n; }
+    } else {
+      const int j0 = (r + pad) % S, c = (r + pad) / S;
+      for (int i = 0; j0 + S * i < K; ++i) { g.off[r][n] = c - i; g.tapk[r][n] = j0 + S * i; ++n; }
+    }
+    g.ntaps[r] = n;
+    for (int i = 0; i < n; ++i) { lo = g.off[r][i] < lo ? g.off[r][i] : lo; hi = g.off[r][i] > hi ? g.off[r][i] : hi; }
+    o += per_tap * n;
+  }
+  g.halo_l = -lo; g.halo_r = hi; g.floats = o;
+  return g;
+}
+
+struct VocLayout {
+  std::vector<Entry> e;
+  size_t total;
+};
+
+bool voc_cfg_ok(const smi_voc_cfg* c) {
+  if (!c) return false;
+  if (c->vq_input_dim <= 0 || c->codebook_size <= 0 || c->codebook_dim <= 0) return false;
+  if (c->fsq_dims < 1 || c->fsq_dims > 8 || c->spk_token_num < 1 || c->spk_latent_dim < 1) return false;
+  if (c->pre_dim < 1 || c->pre_dim > 512 || c->pre_layers < 1 || c->pre_num_down < 0 || c->pre_num_down > 4) return false;
+  if (c->pre_out_channels != c->dec_in || c->spk_out_dim != c->dec_in || c->pre_input_channels != c->vq_input_dim) return false;
+  if (c->pre_cond_dim != c->spk_out_dim) return false;
+  if (c->dec_nblocks < 1 || c->dec_nblocks > 8 || c->dec_channels >> c->dec_nblocks < 1) return false;
+  for (int i = 0; i < c->dec_nblocks; ++i) {
+    const int k = c->dec_ksizes[i], s = c->dec_rates[i];
+    if (s < 1 || s > kMaxPhases || k < s || (k - s) % 2 || (k + s - 1) / s > kMaxTaps) return false;
+  }
+  if (c->max_batch < 1 || c->max_frames < 1) return false;
+  return true;
+}
+
+VocLayout voc_layout(const smi_voc_cfg* c) {
+  VocLayout L;
+  size_t o = 0;
+  auto add = [&](const std::string& name, int kind, int Cout, int Cin, int K, int S, int pad, size_t floats) {
+    Entry e{name, kind, Cout, Cin, K, S, pad, o, floats * 4};
+    L.e.push_back(e);
+    o += smi_align_up(floats * 4, 256);
+  };
+  auto raw = [&](const std::string& name, size_t n) { add(name, PACK_RAW, 0, 0, 0, 1, 0, n); };
+  auto conv = [&](const std::string& name, int Cout, int Cin, int K) {
+    add(name, PACK_CONV, Cout, Cin, K, 1, 0, (size_t)conv_geom(Cout, Cin, K, 1, 0, 1).floats);
+  };
+  const int D = c->pre_dim, I = c->pre_inter, Cc = c->pre_cond_dim;
+  raw("quantizer.codebook.weight", (size_t)c->codebook_size * c->codebook_dim);
+  conv("quantizer.out_project.weight", c->vq_input_dim, c->codebook_dim, 1);
+  raw("quantizer.out_project.bias", c->vq_input_dim);
+  raw("speaker_encoder.quantizer.project_out.weight", (size_t)c->spk_latent_dim * c->fsq_dims);
+  raw("speaker_encoder.quantizer.project_out.bias", c->spk_latent_dim);
+  conv("speaker_encoder.project.weight", c->spk_out_dim, c->spk_latent_dim * c->spk_token_num, 1);
+  raw("speaker_encoder.project.bias", c->spk_out_dim);
+  conv("prenet.linear_pre.weight", D, c->pre_input_channels, 1);
+  raw("prenet.linear_pre.bias", D);
+  std::string adaw = "cat:", adab = "cat:";
+  auto vocos = [&](const std::string& p, int nl, bool ada) {
+    conv(p + ".embed.weight", D, D, 7);
+    raw(p + ".embed.bias", D);
+    auto norm = [&](const std::string& n) {
+      if (ada) {
+        adaw += (adaw.size() > 4 ? "|" : "") + n + ".scale.weight|" + n + ".shift.weight";
+        adab += (adab.size() > 4 ? "|" : "") + n + ".scale.bias|" + n + ".shift.bias";
+      } else {
+        raw(n + ".weight", D);
+        raw(n + ".bias", D);
+      }
+    };
+    norm(p + ".norm");
+    for (int j = 0; j < nl; ++j) {
+      const std::string b = p + ".convnext." + std::to_string(j);
+      raw(b + ".dwconv.weight", (size_t)D * 7);
+      raw(b + ".dwconv.bias", D);
+      norm(b + ".norm");
+      conv(b + ".pwconv1.weight", I, D, 1);
+      raw(b + ".pwconv1.bias", I);
+      conv(b + ".pwconv2.weight", D, I, 1);
+      raw(b + ".pwconv2.bias", D);
+      raw(b + ".gamma", D);
+    }
+    raw(p + ".final_layer_norm.weight", D);
+    raw(p + ".final_layer_norm.bias", D);
+  };
+  for (int i = 0; i < c->pre_num_down; ++i) vocos("prenet.downsample." + std::to_string(i) + ".1", 2, false);
+  vocos("prenet.vocos_backbone", c->pre_layers, true);
+  const int nada = 1 + c->pre_layers;
+  conv(adaw, nada * 2 * D, Cc, 1);
+  raw(adab, (size_t)nada * 2 * D);
+  conv("prenet.linear.weight", c->pre_out_channels, D, 1);
+  raw("prenet.linear.bias", c->pre_out_channels);
+  int ch = c->dec_channels;
+  conv("decoder.model.0.weight", ch, c->dec_in, 7);
+  raw("decoder.model.0.bias", ch);
+  for (int i = 0; i < c->dec_nblocks; ++i) {
+    const int cin = ch >> i, cout = ch >> (i + 1), k = c->dec_ksizes[i], s = c->dec_rates[i];
+    const std::string b = "decoder.model." + std::to_string(i + 1) + ".block";
+    raw(b + ".0.alpha", cin);
+    add(b + ".1.weight", PACK_CONVT, cout, cin, k, s, (k - s) / 2, (size_t)conv_geom(cout, cin, k, 1, (k - s) / 2, s).floats);
+    raw(b + ".1.bias", cout);
+    for (int r = 0; r < 3; ++r) {
+      const std::string u = b + "." + std::to_string(r + 2) + ".block";
+      raw(u + ".0.alpha", cout);
+      conv(u + ".1.weight", cout, cout, 7);
+      raw(u + ".1.bias", cout);
+      raw(u + ".2.alpha", cout);
+      conv(u + ".3.weight", cout, cout, 1);
+      raw(u + ".3.bias", cout);
+    }
+  }
+  const int clast = ch >> c->dec_nblocks;
+  raw("decoder.model." + std::to_string(c->dec_nblocks + 1) + ".alpha", clast);
+  conv("decoder.model." + std::to_string(c->dec_nblocks + 2) + ".weight", 1, clast, 7);
+  raw("decoder.model." + std::to_string(c->dec_nblocks + 2) + ".bias", 1);
+  L.total = o;
+  return L;
+}
+
+struct Launch {
+  int kind;          // 0 conv, 1 dwln, 2 codebook, 3 fsq, 4 zero-tail
+  std::string name;
+  double flops;
+  ConvP cp; int qb; bool ks; dim3 grid; size_t lds;
+  LnP lp; int cpt;
+  // small kernels keep their args here
+  const int64_t* sem; int semstride; const float* cb; int D, cbsize; float* Z; int zstride; long long zb;
+  FsqP fp; int B;
+  float* wav; int wstride, hop, tmaxhop;
+  const int* lens;
+};
+
+}  // namespace
+
+struct smi_voc {
+  smi_voc_cfg cfg;
+  VocLayout lay;
+  const unsigned char* arena;
+  float* buf[4];        // activation ping-pong buffers [max_batch][maxC x maxL]
+  size_t buf_floats;    // per batch item
+  float* small;         // d-vector path + AdaLN params
+  int* lens_dev;        // [8][max_batch] valid lengths per resolution
+  float* dbg[8]; size_t dbg_floats[8]; int debug;
+  std::vector<Launch> prog;
+  std::vector<int32_t> host_lens;   // staging for the async H2D copy (must outlive the call)
+  int lastB, lastT;
+  hipEvent_t ev0, ev1;
+};
+
+namespace {
+
+const float* ent(const smi_voc* h, const std::string& name) {
+  for (const Entry& e : h->lay.e)
+    if (e.name == name) return (const float*)(h->arena + e.offset);
+  return nullptr;
+}
+
+int run_launch(const Launch& L, hipStream_t st) {
+  switch (L.kind) {
+    case 0:
+      if (L.ks) {
+        if (L.qb == 1) hipLaunchKernelGGL((k_conv<1, true>), L.grid, dim3(256), L.lds, st, L.cp);
+        else hipLaunchKernelGGL((k_conv<2, true>), L.grid, dim3(256), L.lds, st, L.cp);
+      } else {
+        if (L.qb == 1) hipLaunchKernelGGL((k_conv<1, false>), L.grid, dim3(256), L.lds, st, L.cp);
+        else hipLaunchKernelGGL((k_conv<2, false>), L.grid, dim3(256), L.lds, st, L.cp);
+      }
+      break;
+    case 1:
+      if (L.cpt <= 8) hipLaunchKernelGGL(k_dwln<8>, L.grid, dim3(256), 0, st, L.lp);
+      else if (L.cpt <= 16) hipLaunchKernelGGL(k_dwln<16>, L.grid, dim3(256), 0, st, L.lp);
+      else if (L.cpt <= 48) hipLaunchKernelGGL(k_dwln<48>, L.grid, dim3(256), 0, st, L.lp);
+      else hipLaunchKernelGGL(k_dwln<64>, L.grid, dim3(256), 0, st, L.lp);
+      break;
+    case 2:
+      hipLaunchKernelGGL(k_codebook, L.grid, dim3(128), 0, st, L.sem, L.semstride, L.cb, L.D, L.cbsize, L.lens, L.Z, L.zstride, L.zb);
+      break;
+    case 3:
+      hipLaunchKernelGGL(k_fsq, dim3(L.B), dim3(256), 0, st, L.fp);
+      break;
+    case 4:
+      hipLaunchKernelGGL(k_zero_tail, L.grid, dim3(256), 0, st, L.wav, L.wstride, L.lens, L.hop);
+      break;
+  }
+  SMI_LAUNCH_CHECK();
+  return SMI_OK;
+}
+
+// Build one conv launch.  X/Y strides are in floats; Lmax = padded INPUT length (time units).
+Launch make_conv(const smi_voc* h, const std::string& name, const std::string& wname, const char* bname,
+                 int Cout, int Cin, int K, int dil, int S, int pad, const float* X, int xstride, long long xb,
+                 float* Y, float* Ys, const float* alpha, const float* R, int ystride, long long yb,
+                 const int* lens, int B, int Lmax, int act) {
+  Launch L;
+  L.kind = 0; L.name = name;
+  ConvGeom g = conv_geom(Cout, Cin, K, dil, pad, S);
+  ConvP& p = L.cp;
+  memset(&p, 0, sizeof(p));
+  p.X = X; p.W = ent(h, wname); p.bias = bname ? ent(h, bname) : nullptr;
+  p.R = R; p.alpha = alpha; p.Y = Y; p.Ys = Ys; p.lens = lens;
+  p.Cin = Cin; p.CinP = pad8(Cin); p.Cout = Cout; p.S = S; p.act = act;
+  p.xstride = xstride; p.ystride = ystride; p.xb = xb; p.yb = yb;
+  p.out_scale = 1.0f;
+  for (int r = 0; r < S; ++r) {
+    p.ntaps[r] = g.ntaps[r];
+    p.wphase[r] = g.wphase[r];
+    for (int i = 0; i < g.ntaps[r]; ++i) p.off[r][i] = g.off[r][i];
+  }
+  const int cot = pad32(Cout) / 32;
+  // waves split the input channels when there are few time tiles and many channels
+  const int qb = (Lmax <= 32) ? 1 : 2;
+  const int qt = qb * 32, nq = (Lmax + qt - 1) / qt;
+  const long long blocks_cosplit = (long long)nq * ((cot + 3) / 4) * B * S;
+  L.ks = (blocks_cosplit < 512 || cot % 4 != 0) && Cin >= 8;
+  L.qb = qb;
+  p.halo_l = g.halo_l;
+  p.xw = qt + g.halo_l + g.halo_r;
+  L.grid = dim3(nq, L.ks ? cot : (cot + 3) / 4, B * S);
+  size_t lds = (size_t)kChunk * p.xw * 4;
+  const size_t red = L.ks ? (size_t)4 * qb * 16 * 64 * 4 : 0;
+  L.lds = lds > red ? lds : red;
+  double taps = 0;
+  for (int r = 0; r < S; ++r) taps += g.ntaps[r];
+  L.flops = 2.0 * Cout * Cin * taps * Lmax * B;   // all phases together cover S*Lmax outputs
+  return L;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smi_voc_arena_count(const smi_voc_cfg* cfg) {
+  if (!voc_cfg_ok(cfg)) return 0;
+  return (int)voc_layout(cfg).e.size();
+}
+
+size_t smi_voc_arena_bytes(const smi_voc_cfg* cfg) {
+  if (!voc_cfg_ok(cfg)) return 0;
+  return voc_layout(cfg).total;
+}
+
+int smi_voc_arena_entry(const smi_voc_cfg* cfg, int index, char* name, int name_cap, size_t* offset, size_t* bytes,
+                        int32_t* info) {
+  SMI_REQUIRE(voc_cfg_ok(cfg), "smi_voc_arena_entry: config outside the kernel contract");
+  VocLayout L = voc_layout(cfg);
+  SMI_REQUIRE(index >= 0 && index < (int)L.e.size(), "smi_voc_arena_entry: index %d out of range", index);
+  const Entry& e = L.e[index];
+  SMI_REQUIRE(name && name_cap > (int)e.name.size(), "smi_voc_arena_entry: name buffer too small (%zu needed)", e.name.size() + 1);
+  strcpy(name, e.name.c_str());
+  if (offset) *offset = e.offset;
+  if (bytes) *bytes = e.bytes;
+  if (info) { info[0] = e.kind; info[1] = e.Cout; info[2] = e.Cin; info[3] = e.K; info[4] = e.S; info[5] = e.pad; }
+  return SMI_OK;
+}
+
+int smi_voc_create(const smi_voc_cfg* cfg, const void* arena_dev, size_t arena_bytes, smi_voc** out) {
+  SMI_REQUIRE(out, "smi_voc_create: out is null");
+  *out = nullptr;
+  SMI_REQUIRE(voc_cfg_ok(cfg), "smi_voc_create: config outside the kernel contract");
+  VocLayout lay = voc_layout(cfg);
+  SMI_REQUIRE(arena_dev && arena_bytes >= lay.total, "smi_voc_create: arena too small (%zu < %zu)", arena_bytes, lay.total);
+  SMI_REQUIRE(((uintptr_t)arena_dev & 255) == 0, "smi_voc_create: arena must be 256-byte aligned");
+  smi_voc* h = new smi_voc();
+  h->cfg = *cfg; h->lay = lay; h->arena = (const unsigned char*)arena_dev;
+  h->lastB = h->lastT = 0; h->small = nullptr; h->lens_dev = nullptr; h->ev0 = h->ev1 = nullptr;
+  for (int i = 0; i < 4; ++i) h->buf[i] = nullptr;
+  for (int i = 0; i < 8; ++i) { h->dbg[i] = nullptr; h->dbg_floats[i] = 0; }
+  const char* dbg = getenv("SPARKMI_VOC_DEBUG");
+  h->debug = dbg && dbg[0] == '1';
+  // largest activation: channels x length over all stages
+  size_t mx = (size_t)cfg->vq_input_dim * cfg->max_frames;
+  mx = std::max(mx, (size_t)cfg->pre_inter * cfg->max_frames);
+  mx = std::max(mx, (size_t)cfg->dec_channels * cfg->max_frames);
+  size_t len = cfg->max_frames;
+  for (int i = 0; i < cfg->dec_nblocks; ++i) {
+    len *= cfg->dec_rates[i];
+    mx = std::max(mx, (size_t)(cfg->dec_channels >> (i + 1)) * len);
+  }
+  h->buf_floats = smi_align_up(mx, 64);
+  const size_t small_floats = (size_t)cfg->max_batch *
+      ((size_t)cfg->spk_latent_dim * cfg->spk_token_num + cfg->spk_out_dim + (size_t)(1 + cfg->pre_layers) * 2 * cfg->pre_dim + 64);
+  bool ok = true;
+  for (int i = 0; i < 4 && ok; ++i) ok = hipMalloc((void**)&h->buf[i], h->buf_floats * cfg->max_batch * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&h->small, small_floats * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&h->lens_dev, 8 * cfg->max_batch * 4 + 64) == hipSuccess;
+  if (ok && h->debug) {
+    for (int i = 0; i < 8 && ok; ++i) {
+      h->dbg_floats[i] = h->buf_floats * cfg->max_batch;
+      ok = hipMalloc((void**)&h->dbg[i], h->dbg_floats[i] * 4) == hipSuccess;
+    }
+  }
+  ok = ok && hipEventCreate(&h->ev0) == hipSuccess && hipEventCreate(&h->ev1) == hipSuccess;
+  if (!ok) {
+    smi_set_error("smi_voc_create: device allocation failed (%zu floats per activation buffer x %d)", h->buf_floats, cfg->max_batch);
+    smi_voc_destroy(h);
+    return SMI_ENOMEM;
+  }
+  *out = h;
+  return SMI_OK;
+}
+
+int smi_voc_destroy(smi_voc* h) {
+  if (!h) return SMI_OK;
+  for (int i = 0; i < 4; ++i) if (h->buf[i]) (void)hipFree(h->buf[i]);
+  for (int i = 0; i < 8; ++i) if (h->dbg[i]) (void)hipFree(h->dbg[i]);
+  if (h->small) (void)hipFree(h->small);
+  if (h->lens_dev) (void)hipFree(h->lens_dev);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  delete h;
+  return SMI_OK;
+}
+
+int smi_voc_forward(smi_voc* h, const int64_t* sem_dev, const int32_t* lens_host, const int32_t* glob_dev, int B, int T,
+                    float* wav_dev, void* stream) {
+  SMI_REQUIRE(h && sem_dev && lens_host && glob_dev && wav_dev, "smi_voc_forward: null argument");
+  const smi_voc_cfg& c = h->cfg;
+  SMI_REQUIRE(B >= 1 && B <= c.max_batch, "smi_voc_forward: B=%d outside 1..%d", B, c.max_batch);
+  SMI_REQUIRE(T >= 1 && T <= c.max_frames, "smi_voc_forward: T_max=%d outside 1..%d", T, c.max_frames);
+  hipStream_t st = (hipStream_t)stream;
+  // valid lengths at every resolution: lens_dev[s][b] = lens[b] * prod(rates[0..s))
+  std::vector<int32_t>& hl = h->host_lens;
+  hl.assign((size_t)8 * c.max_batch, 0);
+  for (int b = 0; b < B; ++b) {
+    SMI_REQUIRE(lens_host[b] >= 1 && lens_host[b] <= T, "smi_voc_forward: lens[%d]=%d outside 1..%d", b, lens_host[b], T);
+    int up = 1;
+    for (int s = 0; s <= c.dec_nblocks; ++s) {
+      hl[(size_t)s * c.max_batch + b] = lens_host[b] * up;
+      if (s < c.dec_nblocks) up *= c.dec_rates[s];
+    }
+    hl[(size_t)7 * c.max_batch + b] = 1;   // length-1 "sequences" for the d-vector GEMVs
+  }
+  SMI_HIP(hipMemcpyAsync(h->lens_dev, hl.data(), hl.size() * 4, hipMemcpyHostToDevice, st));
+  auto lens_at = [&](int s) { return (const int*)(h->lens_dev + (size_t)s * c.max_batch); };
+  const int* len1 = lens_at(7);
+  const int* len0 = lens_at(0);
+
+  std::vector<Launch>& P = h->prog;
+  P.clear();
+  const long long bs = (long long)h->buf_floats;
+  float* bufs[4] = {h->buf[0], h->buf[1], h->buf[2], h->buf[3]};
+  // a buffer that none of the listed live activations occupies
+  auto other = [&](std::initializer_list<const float*> used) -> float* {
+    for (float* f : bufs) {
+      bool u = false;
+      for (const float* q : used) u |= (q == f);
+      if (!u) return f;
+    }
+    return nullptr;
+  };
+  const int D = c.pre_dim, I = c.pre_inter;
+  const int nada = 1 + c.pre_layers;
+  // small scratch: [lat: B x (latent*Ntok)] [dvec: B x out] [ada: B x nada*2*D]
+  const int latn = c.spk_latent_dim * c.spk_token_num;
+  float* lat = h->small;
+  float* dvec = lat + (size_t)c.max_batch * latn;
+  float* ada = dvec + (size_t)c.max_batch * c.spk_out_dim;
+  const int ada_stride = nada * 2 * D;
+
+  // --- d-vector: FSQ codes -> latent -> project (speaker_encoder.py:107-112)
+  {
+    Launch L; L.kind = 3; L.name = "fsq_latent"; L.flops = 2.0 * B * latn * c.fsq_dims; L.B = B;
+    L.fp.glob = glob_dev; L.fp.W1 = ent(h, "speaker_encoder.quantizer.project_out.weight");
+    L.fp.b1 = ent(h, "speaker_encoder.quantizer.project_out.bias"); L.fp.out = lat;
+    L.fp.Ntok = c.spk_token_num; L.fp.latent = c.spk_latent_dim; L.fp.nd = c.fsq_dims;
+    for (int j = 0; j < 8; ++j) L.fp.levels[j] = j < c.fsq_dims ? c.fsq_levels[j] : 1;
+    P.push_back(L);
+  }
+  P.push_back(make_conv(h, "spk_project", "speaker_encoder.project.weight", "speaker_encoder.project.bias",
+                        c.spk_out_dim, latn, 1, 1, 1, 0, lat, 1, latn, dvec, nullptr, nullptr, nullptr, 1, c.spk_out_dim,
+                        len1, B, 1, ACT_NONE));
+  // all AdaLayerNorm scale/shift projections of the condition in one GEMM (vocos.py:105-108)
+  {
+    std::string wn, bn;
+    for (const Entry& e : h->lay.e) {
+      if (e.name.rfind("cat:", 0) == 0 && e.kind == PACK_CONV) wn = e.name;
+      if (e.name.rfind("cat:", 0) == 0 && e.kind == PACK_RAW) bn = e.name;
+    }
+    P.push_back(make_conv(h, "adaln_params", wn, bn.c_str(), ada_stride, c.pre_cond_dim, 1, 1, 1, 0, dvec, 1, c.spk_out_dim,
+                          ada, nullptr, nullptr, nullptr, 1, ada_stride, len1, B, 1, ACT_NONE));
+  }
+  // --- semantic tokens -> codebook rows -> out_project (factorized_vector_quantize.py:154-167)
+  float* zc = bufs[0];
+  {
+    Launch L; L.kind = 2; L.name = "codebook"; L.flops = 0;
+    L.sem = sem_dev; L.semstride = T; L.cb = ent(h, "quantizer.codebook.weight"); L.D = c.codebook_dim; L.cbsize = c.codebook_size;
+    L.lens = len0; L.Z = zc; L.zstride = T; L.zb = bs; L.grid = dim3((T + 127) / 128, B);
+    P.push_back(L);
+  }
+  float* zq = other({zc});
+  P.push_back(make_conv(h, "vq_out_project", "quantizer.out_project.weight", "quantizer.out_project.bias", c.vq_input_dim,
+                        c.codebook_dim, 1, 1, 1, 0, zc, T, bs, zq, nullptr, nullptr, nullptr, T, bs, len0, B, T, ACT_NONE));
+  if (h->debug) { Launch cp = P.back(); cp.cp.Y = h->dbg[0]; cp.name = "vq_out_project(dbg)"; P.push_back(cp); }
+  // --- prenet (feat_decoder.py:78-94)
+  float* cur = other({zq});
+  P.push_back(make_conv(h, "prenet.linear_pre", "prenet.linear_pre.weight", "prenet.linear_pre.bias", D, c.pre_input_channels, 1,
+                        1, 1, 0, zq, T, bs, cur, nullptr, nullptr, nullptr, T, bs, len0, B, T, ACT_NONE));
+  P.back().cp.out_scale = c.pre_num_down > 0 ? 3.0f : 1.0f;   // first SamplingBlock(ratio 1): 3x
+  int ada_idx = 0;
+  auto lnorm = [&](const std::string& name, const std::string& pfx, bool ada_norm, const float* dww, const float* dwb,
+                   const float* X, float* Y, int triple) {
+    Launch L; L.kind = 1; L.name = name; L.flops = (dww ? 14.0 : 0.0) * D * T * B + 8.0 * D * T * B;
+    LnP& p = L.lp; memset(&p, 0, sizeof(p));
+    p.X = X; p.Y = Y; p.dww = dww; p.dwb = dwb; p.lens = len0; p.C = D; p.stride = T; p.bs = bs; p.triple = triple;
+    if (ada_norm) { p.ada = ada + (size_t)ada_idx * 2 * D; p.ada_stride = ada_stride; ++ada_idx; }
+    else { p.w = ent(h, pfx + ".weight"); p.bsh = ent(h, pfx + ".bias"); }
+    L.cpt = (D + 7) / 8; L.grid = dim3((T + 31) / 32, B);
+    P.push_back(L);
+  };
+  // embed conv7 -> norm -> nl x ConvNeXt -> final LN (vocos.py:324-335); consumes cur, leaves result in cur
+  auto vocos = [&](const std::string& p, int nl, bool ada_norm, int triple_out) {
+    float* n = other({cur});          // conv / norm output
+    P.push_back(make_conv(h, p + ".embed", p + ".embed.weight", (p + ".embed.bias").c_str(), D, D, 7, 1, 1, 3, cur, T, bs, n,
+                          nullptr, nullptr, nullptr, T, bs, len0, B, T, ACT_NONE));
+    float* x = other({n});            // residual stream (cur is dead once embed has run)
+    lnorm(p + ".norm", p + ".norm", ada_norm, nullptr, nullptr, n, x, 0);
+    float* m = other({x, n});         // MLP hidden
+    for (int j = 0; j < nl; ++j) {
+      const std::string b = p + ".convnext." + std::to_string(j);
+      lnorm(b + ".dwconv+norm", b + ".norm", ada_norm, ent(h, b + ".dwconv.weight"), ent(h, b + ".dwconv.bias"), x, n, 0);
+      P.push_back(make_conv(h, b + ".pwconv1", b + ".pwconv1.weight", (b + ".pwconv1.bias").c_str(), I, D, 1, 1, 1, 0, n, T, bs, m,
+                            nullptr, nullptr, nullptr, T, bs, len0, B, T, ACT_GELU));
+      P.push_back(make_conv(h, b + ".pwconv2", b + ".pwconv2.weight", (b + ".pwconv2.bias").c_str(), D, I, 1, 1, 1, 0, m, T, bs, x,
+                            nullptr, nullptr, x, T, bs, len0, B, T, ACT_NONE));
+      P.back().cp.gamma = ent(h, b + ".gamma");
+    }
+    lnorm(p + ".final_layer_norm", p + ".final_layer_norm", false, nullptr, nullptr, x, n, triple_out);
+    cur = n;
+  };
+  for (int i = 0; i < c.pre_num_down; ++i)
+    vocos("prenet.downsample." + std::to_string(i) + ".1", 2, false, (i + 1 < c.pre_num_down) ? 1 : 0);
+  vocos("prenet.vocos_backbone", c.pre_layers, c.pre_cond_dim > 0, 0);
+  SMI_REQUIRE(!c.pre_tanh_final, "smi_voc_forward: use_tanh_at_final is not supported");
+  // prenet.linear, then + d_vector per utterance (bicodec.py:185-186)
+  float* x0 = other({cur});
+  P.push_back(make_conv(h, "prenet.linear+d", "prenet.linear.weight", "prenet.linear.bias", c.pre_out_channels, D, 1, 1, 1, 0, cur, T,
+                        bs, x0, nullptr, nullptr, nullptr, T, bs, len0, B, T, ACT_NONE));
+  P.back().cp.bbias = dvec;
+  if (h->debug) { Launch cp = P.back(); cp.cp.Y = h->dbg[1]; cp.name = "prenet.linear+d(dbg)"; P.push_back(cp); }
+  // --- WaveGenerator (wave_generator.py:56-88)
+  int ch = c.dec_channels;
+  int Lcur = T;
+  float* s_in = other({x0});   // snake'd input of the next ConvTranspose
+  {
+    const std::string a0 = "decoder.model.1.block.0.alpha";
+    P.push_back(make_conv(h, "decoder.conv_in", "decoder.model.0.weight", "decoder.model.0.bias", ch, c.dec_in, 7, 1, 1, 3, x0, T, bs,
+                          h->debug ? h->dbg[2] : nullptr, s_in, ent(h, a0), nullptr, T, bs, len0, B, T, ACT_NONE));
+  }
+  for (int i = 0; i < c.dec_nblocks; ++i) {
+    const int cin = ch >> i, cout = ch >> (i + 1), k = c.dec_ksizes[i], s = c.dec_rates[i];
+    const std::string b = "decoder.model." + std::to_string(i + 1) + ".block";
+    const int Lout = Lcur * s;
+    float* U = other({s_in});
+    float* US = other({s_in, U});
+    float* A = other({s_in, U, US});
+    // Snake (already applied by the producer) -> ConvTranspose1d: writes U (raw) and US = snake(U, unit0.alpha0)
+    P.push_back(make_conv(h, b + ".convT", b + ".1.weight", (b + ".1.bias").c_str(), cout, cin, k, 1, s, (k - s) / 2, s_in, Lcur, bs,
+                          U, US, ent(h, b + ".2.block.0.alpha"), nullptr, Lout, bs, lens_at(i), B, Lcur, ACT_NONE));
+    for (int r = 0; r < 3; ++r) {
+      const std::string u = b + "." + std::to_string(r + 2) + ".block";
+      const int dil = r == 0 ? 1 : (r == 1 ? 3 : 9);
+      // conv7(dilated) on snake(U); epilogue applies the unit's second Snake
+      P.push_back(make_conv(h, u + ".conv7", u + ".1.weight", (u + ".1.bias").c_str(), cout, cout, 7, dil, 1, 3 * dil, US, Lout, bs,
+                            nullptr, A, ent(h, u + ".2.alpha"), nullptr, Lout, bs, lens_at(i + 1), B, Lout, ACT_NONE));
+      // 1x1 + residual; second output = the NEXT consumer's Snake of the new U
+      std::string next_alpha;
+      if (r < 2) next_alpha = b + "." + std::to_string(r + 3) + ".block.0.alpha";
+      else if (i + 1 < c.dec_nblocks) next_alpha = "decoder.model." + std::to_string(i + 2) + ".block.0.alpha";
+      else next_alpha = "decoder.model." + std::to_string(c.dec_nblocks + 1) + ".alpha";
+      const bool last = r == 2;
+      float* rawout = last ? (h->debug ? h->dbg[3 + i] : nullptr) : U;
+      P.push_back(make_conv(h, u + ".conv1+res", u + ".3.weight", (u + ".3.bias").c_str(), cout, cout, 1, 1, 1, 0, A, Lout, bs,
+                            rawout, US, ent(h, next_alpha), U, Lout, bs, lens_at(i + 1), B, Lout, ACT_NONE));
+    }
+    s_in = US;
+    Lcur = Lout;
+  }
+  const int clast = ch >> c.dec_nblocks;
+  const int hop = Lcur / T;
+  {
+    const std::string n = "decoder.model." + std::to_string(c.dec_nblocks + 2);
+    // final conv7 -> tanh, written straight into the caller's waveform buffer [B][hop*T]
+    P.push_back(make_conv(h, "decoder.conv_out+tanh", n + ".weight", (n + ".bias").c_str(), 1, clast, 7, 1, 1, 3, s_in, Lcur, bs,
+                          wav_dev, nullptr, nullptr, nullptr, Lcur, Lcur, lens_at(c.dec_nblocks), B, Lcur, ACT_TANH));
+    Launch Z; Z.kind = 4; Z.name = "zero_tail"; Z.flops = 0; Z.wav = wav_dev; Z.wstride = Lcur; Z.lens = len0; Z.hop = hop;
+    Z.grid = dim3((Lcur + 255) / 256, B);
+    P.push_back(Z);
+  }
+  for (const Launch& L : P) {
+    if (L.kind == 0) {
+      SMI_REQUIRE(L.cp.W, "smi_voc_forward: arena entry for %s not found", L.name.c_str());
+      SMI_REQUIRE(L.lds <= 64 * 1024, "smi_voc_forward: %s needs %zu bytes of LDS", L.name.c_str(), L.lds);
+    }
+    int rc = run_launch(L, st);
+    if (rc) return rc;
+  }
+  h->lastB = B; h->lastT = T;
+  return SMI_OK;
+}
+
+int smi_voc_debug_stage(smi_voc* h, int stage, float* out_dev, size_t max_floats, size_t* n_floats, void* stream) {
+  SMI_REQUIRE(h && out_dev && n_floats, "smi_voc_debug_stage: null argument");
+  SMI_REQUIRE(h->lastB > 0, "smi_voc_debug_stage: no forward has run");
+  const smi_voc_cfg& c = h->cfg;
+  const float* src = nullptr;
+  size_t n = 0;
+  if (stage == -1) {   // d-vector [B][out_dim]
+    src = h->small + (size_t)c.max_batch * c.spk_latent_dim * c.spk_token_num;
+    n = (size_t)h->lastB * c.spk_out_dim;
+  } else {
+    SMI_REQUIRE(h->debug, "smi_voc_debug_stage: create the handle with SPARKMI_VOC_DEBUG=1");
+    SMI_REQUIRE(stage >= 0 && stage < 3 + c.dec_nblocks, "smi_voc_debug_stage: stage %d out of range", stage);
+    src = h->dbg[stage];
+    n = h->buf_floats * h->lastB;   // rows are [C][stride] inside each batch slot
+  }
+  SMI_REQUIRE(n <= max_floats, "smi_voc_debug_stage: output buffer too small (%zu > %zu)", n, max_floats);
+  SMI_HIP(hipMemcpyAsync(out_dev, src, n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  *n_floats = n;
+  return SMI_OK;
+}
+
+int smi_voc_num_launches(smi_voc* h) { return h ? (int)h->prog.size() : 0; }
+
+int smi_voc_time_launch(smi_voc* h, int index, int iters, float* ms_avg, double* flops, char* name, int name_cap, void* stream) {
+  SMI_REQUIRE(h && ms_avg && iters > 0, "smi_voc_time_launch: bad argument");
+  SMI_REQUIRE(index >= 0 && index < (int)h->prog.size(), "smi_voc_time_launch: index %d out of range", index);
+  hipStream_t st = (hipStream_t)stream;
+  const Launch& L = h->prog[index];
+  int rc = run_launch(L, st);
+  if (rc) return rc;
+  SMI_HIP(hipEventRecord(h->ev0, st));
+  for (int i = 0; i < iters; ++i)
+    if ((rc = run_launch(L, st))) return rc;
+  SMI_HIP(hipEventRecord(h->ev1, st));
+  SMI_HIP(hipEventSynchronize(h->ev1));
+  float ms = 0.f;
+  SMI_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *ms_avg = ms / iters;
+  if (flops) *flops = L.flops;
+  if (name && name_cap > 0) { strncpy(name, L.name.c_str(), (size_t)name_cap - 1); name[name_cap - 1] = 0; }
+  return SMI_OK;
+}
+
+}  // extern "C"

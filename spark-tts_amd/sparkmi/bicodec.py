@@ -1,0 +1,223 @@
+"""BiCodec detokenize on the HIP vocoder (``smi_voc.hip``), behind the reference's own seams:
+
+* ``BiCodecVocoder.detokenize(semantic_tokens, global_tokens)`` mirrors ``BiCodec.detokenize``
+  (``sparktts/models/bicodec.py:171-189``): (B, T) + (B, 1, Ntok) -> (B, 1, hop*T) tensor.
+* ``BiCodecTokenizer.detokenize(global_tokens, semantic_tokens)`` mirrors the facade
+  (``sparktts/models/audio_tokenizer.py:132-146``): (B, Ntok) + (B, T) -> squeezed numpy.
+
+Weight packing for the implicit-GEMM kernel lives here; section offsets and packing kinds come
+from the library (``smi_voc_arena_entry``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Dict, List, Mapping, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import BiCodecConfig, TopConfig
+from .weights import fold_weight_norm, load_bicodec_state
+
+PACK_RAW, PACK_CONV, PACK_CONVT = 0, 1, 2
+
+
+def voc_cfg_struct(cfg: BiCodecConfig, max_batch: int, max_frames: int) -> _lib.VocCfg:
+    cfg.validate()
+    s = _lib.VocCfg(
+        vq_input_dim=cfg.vq_input_dim, codebook_size=cfg.codebook_size, codebook_dim=cfg.codebook_dim,
+        spk_out_dim=cfg.spk_out_dim, spk_latent_dim=cfg.spk_latent_dim, spk_token_num=cfg.spk_token_num,
+        fsq_dims=len(cfg.fsq_levels),
+        pre_input_channels=cfg.pre_input_channels, pre_dim=cfg.pre_vocos_dim, pre_inter=cfg.pre_intermediate_dim,
+        pre_layers=cfg.pre_num_layers, pre_out_channels=cfg.pre_out_channels,
+        pre_cond_dim=cfg.pre_condition_dim or 0, pre_num_down=len(cfg.pre_sample_ratios),
+        pre_tanh_final=int(cfg.pre_use_tanh_at_final),
+        dec_in=cfg.dec_input_channel, dec_channels=cfg.dec_channels, dec_nblocks=len(cfg.dec_rates),
+        max_batch=max_batch, max_frames=max_frames)
+    for i, v in enumerate(cfg.fsq_levels):
+        s.fsq_levels[i] = v
+    for i, (r, k) in enumerate(zip(cfg.dec_rates, cfg.dec_kernel_sizes)):
+        s.dec_rates[i], s.dec_ksizes[i] = r, k
+    return s
+
+
+def conv_phases(K: int, S: int, pad: int):
+    """Kernel indices j of each output phase r of a ConvTranspose1d (stride S, padding pad):
+    out[q*S + r] takes taps j = j0 + S*i with j0 = (r + pad) mod S.  For S == 1: all taps."""
+    if S == 1:
+        return [list(range(K))]
+    return [list(range((r + pad) % S, K, S)) for r in range(S)]
+
+
+def pack_conv(w: np.ndarray, kind: int, S: int, pad: int) -> np.ndarray:
+    """Weights -> [phase][cout_tile][tap][cin_group][lane:64][4] floats, the A operand of
+    v_mfma_f32_32x32x2_f32: lane l, slot j holds A[co = 32*tile + (l & 31)][ci = 8*group + 2*j + (l >> 5)]."""
+    w = np.asarray(w, dtype=np.float32)
+    if w.ndim == 2:
+        w = w[:, :, None]
+    if kind == PACK_CONVT:
+        w = w.transpose(1, 0, 2)          # (Cin, Cout, K) -> (Cout, Cin, K)
+    cout, cin, K = w.shape
+    cop, cip = (cout + 31) // 32 * 32, (cin + 7) // 8 * 8
+    wp = np.zeros((cop, cip, K), np.float32)
+    wp[:cout, :cin] = w
+    out = []
+    for taps in conv_phases(K, S, pad):
+        a = wp[:, :, taps]                                    # (cop, cip, ntap)
+        a = a.reshape(cop // 32, 32, cip // 8, 4, 2, len(taps))   # [ct][row][g][j][half][tap]
+        a = a.transpose(0, 5, 2, 4, 1, 3)                     # [ct][tap][g][half][row][j]
+        out.append(np.ascontiguousarray(a).reshape(-1))       # lane = half*32 + row
+    return np.concatenate(out)
+
+
+def pack_voc_arena(cfg: BiCodecConfig, folded: Mapping[str, np.ndarray], cs: _lib.VocCfg) -> np.ndarray:
+    lib = _lib.lib()
+    n = lib.smi_voc_arena_count(C.byref(cs))
+    total = lib.smi_voc_arena_bytes(C.byref(cs))
+    if n <= 0 or total == 0:
+        raise _lib.SparkMIError("smi_voc_arena_count: config outside the kernel contract")
+    arena = np.zeros(total // 4, dtype=np.float32)
+    name = C.create_string_buffer(8192)
+    for i in range(n):
+        off, nb = C.c_size_t(), C.c_size_t()
+        info = (C.c_int32 * 6)()
+        _lib.check(lib.smi_voc_arena_entry(C.byref(cs), i, name, 8192, C.byref(off), C.byref(nb), info),
+                   "smi_voc_arena_entry")
+        key = name.value.decode()
+        if key.startswith("cat:"):
+            t = np.concatenate([np.asarray(folded[k], np.float32) for k in key[4:].split("|")], axis=0)
+        else:
+            t = np.asarray(folded[key], np.float32)
+        kind, cout, cin, K, S, pad = list(info)
+        data = t.reshape(-1) if kind == PACK_RAW else pack_conv(t, kind, S, pad)
+        if data.size * 4 != nb.value:
+            raise ValueError(f"{key}: packed {data.size * 4} bytes, library expects {nb.value}")
+        arena[off.value // 4: off.value // 4 + data.size] = data
+    return arena
+
+
+class BiCodecVocoder:
+    """The vocoder half of BiCodec on one MI355X."""
+
+    def __init__(self, cfg: BiCodecConfig, state: Mapping[str, np.ndarray],
+                 device: Union[str, torch.device] = "cuda:0", max_batch: int = 1, max_frames: int = 512,
+                 state_is_folded: bool = False):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.SparkMIError("BiCodecVocoder runs on an MI355X only (device must be cuda:N); there is no CPU path")
+        self._lib = _lib.lib()
+        torch.cuda.set_device(self.device)
+        _lib.require_gfx950()
+        self.max_batch, self.max_frames = max_batch, max_frames
+        self._cs = voc_cfg_struct(cfg, max_batch, max_frames)
+        folded = state if state_is_folded else fold_weight_norm(dict(state))
+        self.arena = torch.from_numpy(pack_voc_arena(cfg, folded, self._cs)).to(self.device)
+        self._h = C.c_void_p()
+        _lib.check(self._lib.smi_voc_create(C.byref(self._cs), C.c_void_p(self.arena.data_ptr()),
+                                            self.arena.numel() * 4, C.byref(self._h)), "smi_voc_create")
+        self.hop = cfg.hop
+
+    def _stream(self) -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.smi_voc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @torch.no_grad()
+    def detokenize(self, semantic_tokens: torch.Tensor, global_tokens: torch.Tensor,
+                   lengths: Optional[Sequence[int]] = None) -> torch.Tensor:
+        """(B, T) semantic ids + (B, 1, Ntok) global ids -> (B, 1, hop*T) float32 on the device.
+        ``lengths`` (frames per row) makes the batch ragged: each row then equals an un-padded
+        run of that row alone, and its samples beyond hop*length are zero."""
+        sem = semantic_tokens.to(self.device, torch.int64).contiguous()
+        if sem.ndim == 1:
+            sem = sem[None]
+        B, T = sem.shape
+        glob = global_tokens.to(self.device, torch.int32).reshape(B, -1).contiguous()
+        if glob.shape[1] != self.cfg.spk_token_num:
+            raise ValueError(f"expected {self.cfg.spk_token_num} global tokens per row, got {glob.shape[1]}")
+        lens = np.full(B, T, np.int32) if lengths is None else np.asarray(lengths, np.int32)
+        wav = torch.empty((B, 1, self.hop * T), dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.smi_voc_forward(
+            self._h, C.c_void_p(sem.data_ptr()), lens.ctypes.data_as(C.POINTER(C.c_int32)),
+            C.c_void_p(glob.data_ptr()), B, T, C.c_void_p(wav.data_ptr()), self._stream()), "smi_voc_forward")
+        self._keep = (sem, glob)   # inputs must stay alive until the stream has consumed them
+        return wav
+
+    # ------------------------------------------------------------------ test / bench entries
+    def debug_stage(self, stage: int, channels: int, length: int, batch: int) -> torch.Tensor:
+        """Stage activation of the last forward as (B, C, L).  -1 = d-vector (returns (B, out_dim));
+        stages >= 0 need SPARKMI_VOC_DEBUG=1 at construction: 0 z_q, 1 prenet+d, 2 conv_in, 3+i block i."""
+        n = C.c_size_t()
+        if stage == -1:
+            out = torch.empty(batch * self.cfg.spk_out_dim, dtype=torch.float32, device=self.device)
+            _lib.check(self._lib.smi_voc_debug_stage(self._h, -1, C.c_void_p(out.data_ptr()), out.numel(),
+                                                     C.byref(n), self._stream()), "smi_voc_debug_stage")
+            return out.view(batch, -1)
+        big = self._dbg_floats() * batch
+        out = torch.empty(big, dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.smi_voc_debug_stage(self._h, stage, C.c_void_p(out.data_ptr()), big, C.byref(n),
+                                                 self._stream()), "smi_voc_debug_stage")
+        per = n.value // batch
+        return out.view(batch, per)[:, : channels * length].reshape(batch, channels, length)
+
+    def _dbg_floats(self) -> int:
+        c, T = self.cfg, self.max_frames
+        mx = max(c.vq_input_dim * T, c.pre_intermediate_dim * T, c.dec_channels * T)
+        L = T
+        for i, r in enumerate(c.dec_rates):
+            L *= r
+            mx = max(mx, (c.dec_channels >> (i + 1)) * L)
+        return (mx + 63) // 64 * 64
+
+    def launches(self) -> int:
+        return int(self._lib.smi_voc_num_launches(self._h))
+
+    def time_launch(self, index: int, iters: int = 10):
+        ms, fl = C.c_float(0), C.c_double(0)
+        name = C.create_string_buffer(256)
+        _lib.check(self._lib.smi_voc_time_launch(self._h, index, iters, C.byref(ms), C.byref(fl), name, 256,
+                                                 self._stream()), "smi_voc_time_launch")
+        return name.value.decode(), float(ms.value), float(fl.value)
+
+
+class BiCodecTokenizer:
+    """Drop-in for the detokenize half of ``sparktts.models.audio_tokenizer.BiCodecTokenizer``.
+    ``tokenize`` (voice-clone prompt encode: wav2vec2 + encoder + speaker encoder) is the next row
+    of SURVEY section 8f and is not built in this round."""
+
+    def __init__(self, model_dir: Optional[Path] = None, device: Union[str, torch.device] = None,
+                 cfg: Optional[BiCodecConfig] = None, state: Optional[Mapping[str, np.ndarray]] = None,
+                 max_batch: int = 1, max_frames: int = 3000, **kwargs):
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self.model_dir = model_dir
+        if cfg is None:
+            bdir = Path(model_dir) / "BiCodec"
+            cfg = BiCodecConfig.from_yaml(bdir / "config.yaml")
+            state = load_bicodec_state(bdir)
+            self.config = TopConfig.from_yaml(Path(model_dir) / "config.yaml")
+        else:
+            self.config = TopConfig()
+        self.model = BiCodecVocoder(cfg, state, self.device, max_batch=max_batch, max_frames=max_frames)
+
+    def tokenize(self, audio_path: str):
+        raise NotImplementedError(
+            "voice-clone prompt encoding (wav2vec2 + BiCodec encoder + speaker encoder) is not built yet "
+            "(SURVEY section 8f item 1); pass gender/pitch/speed for controllable TTS")
+
+    def detokenize(self, global_tokens: torch.Tensor, semantic_tokens: torch.Tensor) -> np.ndarray:
+        """(B, Ntok) global ids, (B, T) semantic ids -> waveform: (hop*T,) for B == 1 else (B, hop*T)."""
+        global_tokens = global_tokens.unsqueeze(1)
+        wav_rec = self.model.detokenize(semantic_tokens, global_tokens)
+        return wav_rec.detach().squeeze().cpu().numpy()

@@ -90,3 +90,57 @@ def test_no_cpu_fallback():
     if not torch.cuda.is_available():
         with pytest.raises(_lib.SparkMIError):
             _lib.require_gfx950()
+
+
+def test_voc_arena_layout_and_packing():
+    import ctypes as Cc
+    from sparkmi import bicodec
+    l = _lib.lib()
+    for cfg in (C.tiny_bicodec(), C.spark_0p5b_bicodec()):
+        cs = bicodec.voc_cfg_struct(cfg, 2, 64)
+        n = l.smi_voc_arena_count(Cc.byref(cs))
+        assert n > 50
+        names = set()
+        name = Cc.create_string_buffer(8192)
+        end = 0
+        for i in range(n):
+            off, nb = Cc.c_size_t(), Cc.c_size_t()
+            info = (Cc.c_int32 * 6)()
+            assert l.smi_voc_arena_entry(Cc.byref(cs), i, name, 8192, Cc.byref(off), Cc.byref(nb), info) == 0
+            assert off.value >= end and off.value % 256 == 0
+            end = off.value + nb.value
+            names.add(name.value.decode())
+        assert end <= l.smi_voc_arena_bytes(Cc.byref(cs))
+        assert "decoder.model.0.weight" in names and "quantizer.codebook.weight" in names
+    cfg = C.tiny_bicodec()
+    sd = W.fold_weight_norm(W.bicodec_detok_state(cfg))
+    cs = bicodec.voc_cfg_struct(cfg, 1, 32)
+    a = bicodec.pack_voc_arena(cfg, sd, cs)
+    assert a.dtype == np.float32 and a.size * 4 == l.smi_voc_arena_bytes(Cc.byref(cs))
+    # every parameter detokenize touches was consumed by the arena
+    used = set()
+    name = Cc.create_string_buffer(8192)
+    for i in range(l.smi_voc_arena_count(Cc.byref(cs))):
+        l.smi_voc_arena_entry(Cc.byref(cs), i, name, 8192, None, None, None)
+        k = name.value.decode()
+        used.update(k[4:].split("|") if k.startswith("cat:") else [k])
+    assert used == set(sd.keys())
+
+
+def test_pack_conv_layouts():
+    from sparkmi.bicodec import pack_conv, conv_phases, PACK_CONV, PACK_CONVT
+    rng = np.random.default_rng(1)
+    w = rng.standard_normal((40, 12, 7)).astype(np.float32)       # Conv1d (Cout, Cin, K)
+    p = pack_conv(w, PACK_CONV, 1, 0).reshape(2, 7, 2, 64, 4)     # [ct][tap][g][lane][j]
+    for (co, ci, k) in [(0, 0, 0), (33, 11, 6), (39, 5, 3), (31, 8, 2)]:
+        lane = (ci % 8 % 2) * 32 + co % 32
+        assert p[co // 32, k, ci // 8, lane, (ci % 8) // 2] == w[co, ci, k]
+    assert not p[1, :, :, 8:32, :].any() and not p[:, :, 1, :, 2:].any()   # zero padding rows / channels
+    # ConvTranspose1d k=11, s=5, pad=3: phases have 3 or 2 taps
+    assert [len(t) for t in conv_phases(11, 5, 3)] == [2, 2, 3, 2, 2]
+    wt = rng.standard_normal((8, 32, 11)).astype(np.float32)      # (Cin, Cout, K)
+    pt = pack_conv(wt, PACK_CONVT, 5, 3)
+    assert pt.size == 11 * 1 * 1 * 256
+    taps0 = conv_phases(11, 5, 3)[0]
+    first = pt[: len(taps0) * 256].reshape(len(taps0), 64, 4)
+    assert first[1, 32 + 7, 2] == wt[5, 7, taps0[1]]              # lane 39: co 7, half 1; j=2 -> ci 5

@@ -1,0 +1,125 @@
+"""GPU parity of the HIP vocoder (through the C ABI) against the CPU oracle and the vectors the
+reference's own modules produced.  Contractions run on the exact-fp32 matrix pipe, so the bound
+written here (1e-4 on a waveform in [-1, 1]; north_star allows 1e-3) is summation-order noise."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.bicodec_ref import BiCodecDetokRef
+from sparkmi import config as C, weights as W
+
+pytestmark = pytest.mark.gpu
+
+WAV_ATOL = 1e-4
+
+
+def _voc(cfg, sd, **kw):
+    from sparkmi.bicodec import BiCodecVocoder
+    return BiCodecVocoder(cfg, sd, device="cuda:0", **kw)
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg = C.tiny_bicodec()
+    sd = W.bicodec_detok_state(cfg)
+    return cfg, sd, BiCodecDetokRef(cfg, W.fold_weight_norm(sd))
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_waveform_matches_reference_vectors(tiny, golden_dir, case):
+    cfg, sd, _ = tiny
+    g = np.load(os.path.join(golden_dir, "vocoder_tiny.npz"))
+    voc = _voc(cfg, sd, max_frames=160)
+    wav = voc.detokenize(torch.from_numpy(g[f"c{case}_semantic"]), torch.from_numpy(g[f"c{case}_global"])).cpu().numpy()
+    assert wav.shape == g[f"c{case}_wav"].shape
+    err = np.abs(wav - g[f"c{case}_wav"]).max()
+    assert err < WAV_ATOL, f"max |wav diff| {err}"
+    d = voc.debug_stage(-1, 0, 0, 1).cpu().numpy()
+    assert np.abs(d - g[f"c{case}_d_vector"]).max() < 1e-5
+
+
+def test_intermediate_stages_match_reference_vectors(tiny, golden_dir, monkeypatch):
+    monkeypatch.setenv("SPARKMI_VOC_DEBUG", "1")
+    cfg, sd, _ = tiny
+    g = np.load(os.path.join(golden_dir, "vocoder_tiny.npz"))
+    voc = _voc(cfg, sd, max_frames=64)
+    T = g["c0_semantic"].shape[1]
+    voc.detokenize(torch.from_numpy(g["c0_semantic"]), torch.from_numpy(g["c0_global"]))
+    zq = voc.debug_stage(0, cfg.vq_input_dim, T, 1).cpu().numpy()
+    assert np.abs(zq - g["c0_z_q"]).max() < 1e-5
+    x0 = voc.debug_stage(1, cfg.dec_input_channel, T, 1).cpu().numpy()
+    assert np.abs(x0 - g["c0_prenet_plus_d"]).max() < 1e-4
+    L, ch = T, cfg.dec_channels
+    s0 = voc.debug_stage(2, ch, L, 1).cpu().numpy()
+    assert np.abs(s0 - g["c0_wavegen0"]).max() < 2e-4
+    for i, r in enumerate(cfg.dec_rates):
+        L *= r
+        si = voc.debug_stage(3 + i, ch >> (i + 1), L, 1).cpu().numpy()
+        assert np.abs(si - g[f"c0_wavegen{i + 1}"]).max() < 5e-4, f"block {i}"
+
+
+def test_ragged_batch_equals_unpadded_rows(tiny):
+    cfg, sd, ref = tiny
+    rng = np.random.Generator(np.random.PCG64(77))
+    lens = [33, 1, 70, 8, 64]
+    B, T = len(lens), max(lens)
+    sem = rng.integers(0, cfg.codebook_size, size=(B, T))
+    glob = rng.integers(0, 4096, size=(B, 1, cfg.spk_token_num))
+    voc = _voc(cfg, sd, max_batch=B, max_frames=80)
+    wav = voc.detokenize(torch.from_numpy(sem), torch.from_numpy(glob), lengths=lens).cpu().numpy()
+    one = _voc(cfg, sd, max_batch=1, max_frames=80)
+    for b, n in enumerate(lens):
+        solo = one.detokenize(torch.from_numpy(sem[b:b + 1, :n]), torch.from_numpy(glob[b:b + 1])).cpu().numpy()
+        assert np.array_equal(wav[b, 0, : n * cfg.hop], solo[0, 0]), f"row {b} differs from its un-padded run"
+        assert not wav[b, 0, n * cfg.hop:].any()
+        oracle = ref.detokenize(torch.from_numpy(sem[b:b + 1, :n]), torch.from_numpy(glob[b:b + 1])).numpy()
+        assert np.abs(solo - oracle).max() < WAV_ATOL
+
+
+def test_facade_and_determinism(tiny):
+    from sparkmi.bicodec import BiCodecTokenizer
+    cfg, sd, ref = tiny
+    tok = BiCodecTokenizer(device="cuda:0", cfg=cfg, state=sd, max_frames=64)
+    rng = np.random.Generator(np.random.PCG64(5))
+    sem = torch.from_numpy(rng.integers(0, cfg.codebook_size, size=(1, 21)))
+    glob = torch.from_numpy(rng.integers(0, 4096, size=(1, cfg.spk_token_num)))
+    a = tok.detokenize(glob, sem)
+    b = tok.detokenize(glob, sem)
+    assert a.shape == (21 * cfg.hop,) and a.dtype == np.float32
+    assert np.array_equal(a, b)
+    assert np.abs(a - ref.detokenize_numpy(glob, sem)).max() < WAV_ATOL
+    with pytest.raises(NotImplementedError):
+        tok.tokenize("x.wav")
+
+
+def test_bad_arguments_are_reported(tiny):
+    from sparkmi._lib import SparkMIError
+    cfg, sd, _ = tiny
+    voc = _voc(cfg, sd, max_batch=1, max_frames=16)
+    with pytest.raises(SparkMIError):
+        voc.detokenize(torch.zeros((1, 17), dtype=torch.long), torch.zeros((1, 1, cfg.spk_token_num), dtype=torch.long))
+    with pytest.raises(SparkMIError):
+        voc.detokenize(torch.zeros((2, 4), dtype=torch.long), torch.zeros((2, 1, cfg.spk_token_num), dtype=torch.long))
+
+
+def test_full_size_0p5b_against_reference_vectors(golden_dir):
+    """Spark-TTS-0.5B BiCodec shape, synthetic weights: 150 frames -> 48 000 samples."""
+    cfg = C.spark_0p5b_bicodec()
+    sd = W.bicodec_detok_state(cfg)
+    g = np.load(os.path.join(golden_dir, "vocoder_full.npz"))
+    voc = _voc(cfg, sd, max_batch=2, max_frames=160)
+    for case in (0, 1):
+        wav = voc.detokenize(torch.from_numpy(g[f"c{case}_semantic"]), torch.from_numpy(g[f"c{case}_global"])).cpu().numpy()
+        err = np.abs(wav - g[f"c{case}_wav"]).max()
+        assert err < 1e-3, f"case {case}: max |wav diff| {err}"   # north_star bound
+        assert err < WAV_ATOL * 3, f"case {case}: max |wav diff| {err}"
+    # the two as one ragged batch
+    T = 150
+    sem = np.zeros((2, T), np.int64)
+    sem[0], sem[1, :23] = g["c0_semantic"][0], g["c1_semantic"][0]
+    glob = np.concatenate([g["c0_global"], g["c1_global"]])
+    wav = voc.detokenize(torch.from_numpy(sem), torch.from_numpy(glob), lengths=[150, 23]).cpu().numpy()
+    assert np.abs(wav[0] - g["c0_wav"][0]).max() < 3e-4
+    assert np.abs(wav[1, :, : 23 * 320] - g["c1_wav"][0]).max() < 3e-4
