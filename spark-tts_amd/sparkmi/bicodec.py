@@ -103,7 +103,7 @@ class BiCodecVocoder:
 
     def __init__(self, cfg: BiCodecConfig, state: Mapping[str, np.ndarray],
                  device: Union[str, torch.device] = "cuda:0", max_batch: int = 1, max_frames: int = 512,
-                 state_is_folded: bool = False):
+                 state_is_folded: bool = False, arena: Optional[torch.Tensor] = None):
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -113,8 +113,10 @@ class BiCodecVocoder:
         _lib.require_gfx950()
         self.max_batch, self.max_frames = max_batch, max_frames
         self._cs = voc_cfg_struct(cfg, max_batch, max_frames)
-        folded = state if state_is_folded else fold_weight_norm(dict(state))
-        self.arena = torch.from_numpy(pack_voc_arena(cfg, folded, self._cs)).to(self.device)
+        if arena is None:
+            folded = state if state_is_folded else fold_weight_norm(dict(state))
+            arena = torch.from_numpy(pack_voc_arena(cfg, folded, self._cs)).to(self.device)
+        self.arena = arena   # float32 device tensor; must outlive the handle
         self._h = C.c_void_p()
         _lib.check(self._lib.smi_voc_create(C.byref(self._cs), C.c_void_p(self.arena.data_ptr()),
                                             self.arena.numel() * 4, C.byref(self._h)), "smi_voc_create")

@@ -1,0 +1,82 @@
+"""Multi-GPU: one process per MI355X, utterances sharded across ranks, no data-path collective.
+
+The only collective is the start-up broadcast of the two weight arenas from rank 0 (RCCL over
+xGMI when the backend is "nccl"; the same code runs over gloo on CPU tensors in the tests).
+Utterances are independent (the reference has no cross-utterance state: cli/SparkTTS.py:157-236),
+so each rank synthesises its own shard and rank 0 gathers the waveforms over host memory.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def arena_sizes(cs_llm, cs_voc) -> Tuple[int, int]:
+    """(LLM arena bytes, vocoder arena floats) from the library's own layout functions."""
+    from . import _lib
+    l = _lib.lib()
+    return int(l.smi_llm_arena_bytes(C.byref(cs_llm))), int(l.smi_voc_arena_bytes(C.byref(cs_voc))) // 4
+
+
+def broadcast_arenas(llm_arena: Optional[torch.Tensor], voc_arena: Optional[torch.Tensor], sizes: Tuple[int, int],
+                     device: torch.device, rank: int, world: int):
+    """Rank 0 passes its arenas, the others pass None; returns (llm_arena, voc_arena, milliseconds)."""
+    if rank != 0:
+        llm_arena = torch.empty(sizes[0], dtype=torch.uint8, device=device)
+        voc_arena = torch.empty(sizes[1], dtype=torch.float32, device=device)
+    if world == 1:
+        return llm_arena, voc_arena, 0.0
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    dist.barrier()
+    t0 = time.perf_counter()
+    dist.broadcast(llm_arena, src=0)
+    dist.broadcast(voc_arena, src=0)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    dist.barrier()
+    return llm_arena, voc_arena, (time.perf_counter() - t0) * 1e3
+
+
+def shard_indices(lengths: Sequence[int], rank: int, world: int) -> List[int]:
+    """Utterance indices for `rank`: longest first, dealt round-robin (serpentine) so every rank
+    gets a similar amount of audio."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    mine = []
+    for pos, idx in enumerate(order):
+        rnd, k = divmod(pos, world)
+        owner = k if rnd % 2 == 0 else world - 1 - k
+        if owner == rank:
+            mine.append(idx)
+    return mine
+
+
+def synthesize_sharded(requests: Sequence[dict], est_lengths: Sequence[int], synth: Callable[[List[dict]], List[np.ndarray]],
+                       rank: int, world: int, batch: int = 1) -> Optional[List[np.ndarray]]:
+    """Run `synth` on this rank's shard (in groups of `batch`); rank 0 returns every waveform in
+    request order, other ranks return None."""
+    mine = shard_indices(est_lengths, rank, world)
+    out = []
+    for i in range(0, len(mine), batch):
+        grp = mine[i: i + batch]
+        wavs = synth([requests[j] for j in grp])
+        out.extend(zip(grp, wavs))
+    if world == 1:
+        res = [None] * len(requests)
+        for j, w in out:
+            res[j] = w
+        return res
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(out, gathered, dst=0)
+    if rank != 0:
+        return None
+    res = [None] * len(requests)
+    for part in gathered:
+        for j, w in part:
+            res[j] = w
+    return res

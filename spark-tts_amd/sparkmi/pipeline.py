@@ -1,0 +1,178 @@
+"""SparkTTS -- drop-in for the reference pipeline class (``cli/SparkTTS.py``) on one MI355X.
+
+Same constructor and ``inference()`` signature, same attributes (``device``, ``model_dir``,
+``configs``, ``sample_rate``, ``tokenizer``, ``model``, ``audio_tokenizer``), same prompt
+strings, same token parsing, same float32 numpy waveform.  The two heavy calls run on the HIP
+kernels: ``self.model.generate`` (``SparkLLM``) and ``self.audio_tokenizer.detokenize``
+(``BiCodecTokenizer``).  Keyword-only additions: ``do_sample``, ``max_new_tokens``,
+``prompt_tokens`` (pre-computed prompt audio tokens) and ``inference_batch``.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .bicodec import BiCodecTokenizer
+from .config import LLMConfig, TopConfig
+from .llm import SparkLLM
+from .pipeline_text import (GENDER_MAP, LEVELS_MAP, TASK_TOKEN_MAP, build_clone_prompt,
+                            build_control_prompt, parse_global, parse_semantic)
+from .weights import load_llm_state
+
+
+class _TokenMap:
+    """id -> bicodec index tables read from the tokenizer's own vocabulary, used to skip the
+    decode + regex round trip of ``cli/SparkTTS.py:213-228`` when it provably gives the same
+    answer (every generated id is either a bicodec token or a special token)."""
+
+    def __init__(self, tokenizer):
+        import re
+        self.sem: Dict[int, int] = {}
+        self.glob: Dict[int, int] = {}
+        rs, rg = re.compile(r"^<\|bicodec_semantic_(\d+)\|>$"), re.compile(r"^<\|bicodec_global_(\d+)\|>$")
+        for tok, idx in tokenizer.get_vocab().items():
+            m = rs.match(tok)
+            if m:
+                self.sem[idx] = int(m.group(1))
+                continue
+            m = rg.match(tok)
+            if m:
+                self.glob[idx] = int(m.group(1))
+        self.special = set(int(i) for i in getattr(tokenizer, "all_special_ids", []) or [])
+
+    def fast_parse(self, ids: Sequence[int]) -> Optional[Tuple[List[int], List[int]]]:
+        sem, glob = [], []
+        for i in ids:
+            if i in self.sem:
+                sem.append(self.sem[i])
+            elif i in self.glob:
+                glob.append(self.glob[i])
+            elif i not in self.special:
+                return None   # ordinary text token: fall back to the reference's decode + regex
+        return sem, glob
+
+
+class SparkTTS:
+    """Spark-TTS for text-to-speech generation (MI355X-native hot path)."""
+
+    def __init__(self, model_dir: Path, device: torch.device = torch.device("cuda:0"), *,
+                 max_batch: int = 1, max_positions: int = 4096, kv_dtype: str = "bf16",
+                 max_frames: int = 3000):
+        self.device = torch.device(device)
+        self.model_dir = model_dir
+        top = TopConfig.from_yaml(Path(model_dir) / "config.yaml")
+        self.configs = {"sample_rate": top.sample_rate, "ref_segment_duration": top.ref_segment_duration,
+                        "latent_hop_length": top.latent_hop_length, "volume_normalize": top.volume_normalize}
+        self.sample_rate = self.configs["sample_rate"]
+        self._max_batch, self._max_positions, self._kv_dtype, self._max_frames = max_batch, max_positions, kv_dtype, max_frames
+        self._initialize_inference()
+
+    def _initialize_inference(self):
+        """Tokenizer (HF, host side), LLM and audio tokenizer (both on the HIP kernels)."""
+        from transformers import AutoTokenizer
+        llm_dir = Path(self.model_dir) / "LLM"
+        self.tokenizer = AutoTokenizer.from_pretrained(str(llm_dir))
+        cfg = LLMConfig.from_json(llm_dir / "config.json")
+        gen_cfg = llm_dir / "generation_config.json"
+        self._eos = cfg.eos_token_id
+        if gen_cfg.exists():
+            import json
+            e = json.loads(gen_cfg.read_text()).get("eos_token_id", self._eos)
+            self._eos = e[0] if isinstance(e, list) else e
+        if self._eos is None:
+            self._eos = self.tokenizer.eos_token_id
+        self.model = SparkLLM(cfg, load_llm_state(llm_dir), self.device, max_slots=self._max_batch,
+                              max_positions=self._max_positions, kv_dtype=self._kv_dtype)
+        self.audio_tokenizer = BiCodecTokenizer(self.model_dir, device=self.device, max_batch=self._max_batch,
+                                                max_frames=self._max_frames)
+        self._map = _TokenMap(self.tokenizer)
+
+    # ------------------------------------------------------------------ prompts
+    def process_prompt(self, text: str, prompt_speech_path: Path, prompt_text: str = None,
+                       prompt_tokens: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[str, torch.Tensor]:
+        """Voice-cloning prompt.  Returns (prompt string, global token ids (1, 1, Ntok))."""
+        if prompt_tokens is not None:
+            global_token_ids, semantic_token_ids = prompt_tokens
+        else:
+            global_token_ids, semantic_token_ids = self.audio_tokenizer.tokenize(prompt_speech_path)
+        global_token_ids = torch.as_tensor(global_token_ids)
+        semantic_token_ids = torch.as_tensor(semantic_token_ids)
+        inputs = build_clone_prompt(text, global_token_ids.reshape(-1).tolist(),
+                                    semantic_token_ids.reshape(-1).tolist(), prompt_text)
+        return inputs, global_token_ids
+
+    def process_prompt_control(self, gender: str, pitch: str, speed: str, text: str):
+        """Voice-creation prompt (gender: female | male; pitch/speed: very_low .. very_high)."""
+        return build_control_prompt(gender, pitch, speed, text)
+
+    # ------------------------------------------------------------------ inference
+    def _parse(self, new_ids: Sequence[int]) -> Tuple[List[int], List[int]]:
+        fast = self._map.fast_parse(new_ids)
+        if fast is not None:
+            return fast
+        predicts = self.tokenizer.batch_decode([list(new_ids)], skip_special_tokens=True)[0]
+        return parse_semantic(predicts), parse_global(predicts)
+
+    @torch.no_grad()
+    def inference(self, text: str, prompt_speech_path: Path = None, prompt_text: str = None,
+                  gender: str = None, pitch: str = None, speed: str = None,
+                  temperature: float = 0.8, top_k: float = 50, top_p: float = 0.95, *,
+                  do_sample: bool = True, max_new_tokens: int = 3000, seed: Optional[int] = None,
+                  prompt_tokens: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> np.ndarray:
+        """Text (+ optional prompt audio / style labels) -> float32 waveform at ``sample_rate``."""
+        return self.inference_batch([dict(text=text, prompt_speech_path=prompt_speech_path, prompt_text=prompt_text,
+                                          gender=gender, pitch=pitch, speed=speed, prompt_tokens=prompt_tokens)],
+                                    temperature=temperature, top_k=top_k, top_p=top_p, do_sample=do_sample,
+                                    max_new_tokens=max_new_tokens, seed=seed)[0]
+
+    @torch.no_grad()
+    def inference_batch(self, requests: Sequence[dict], temperature: float = 0.8, top_k: float = 50,
+                        top_p: float = 0.95, *, do_sample: bool = True, max_new_tokens: int = 3000,
+                        seed: Optional[int] = None) -> List[np.ndarray]:
+        """Several independent utterances in one ragged batch (<= max_batch).  Each result equals
+        the single-utterance call for that request (greedy)."""
+        if len(requests) > self._max_batch:
+            raise ValueError(f"{len(requests)} requests > max_batch={self._max_batch}")
+        prompts, globals_ = [], []
+        for r in requests:
+            if r.get("gender") is not None:
+                prompts.append(self.process_prompt_control(r["gender"], r.get("pitch"), r.get("speed"), r["text"]))
+                globals_.append(None)
+            else:
+                p, g = self.process_prompt(r["text"], r.get("prompt_speech_path"), r.get("prompt_text"),
+                                           r.get("prompt_tokens"))
+                prompts.append(p)
+                globals_.append(g)
+        ids = [self.tokenizer([p], return_tensors="pt").input_ids[0].tolist() for p in prompts]
+        if do_sample:
+            new = self.model.generate_ids(ids, max_new_tokens, self._eos, do_sample=True, temperature=temperature,
+                                          top_k=int(top_k), top_p=float(top_p), seed=seed)
+        else:
+            new = self.model.generate_ids(ids, max_new_tokens, self._eos)
+        sems, globs, lens = [], [], []
+        ntok = self.audio_tokenizer.model.cfg.spk_token_num
+        for b, toks in enumerate(new):
+            sem, glob = self._parse(toks)
+            if globals_[b] is None:
+                g = torch.tensor(glob, dtype=torch.long)
+            else:
+                g = torch.as_tensor(globals_[b]).reshape(-1).long()
+            if g.numel() != ntok:
+                raise ValueError(f"request {b}: {g.numel()} global tokens generated, the speaker encoder needs {ntok}")
+            if not sem:
+                raise ValueError(f"request {b}: the model generated no semantic tokens")
+            sems.append(sem)
+            globs.append(g)
+            lens.append(len(sem))
+        T = max(lens)
+        sem_t = torch.zeros((len(sems), T), dtype=torch.long)
+        for b, s in enumerate(sems):
+            sem_t[b, : len(s)] = torch.tensor(s)
+        wav = self.audio_tokenizer.model.detokenize(sem_t, torch.stack(globs).unsqueeze(1), lengths=lens)
+        wav = wav.squeeze(1).cpu().numpy()
+        hop = self.audio_tokenizer.model.hop
+        return [wav[b, : lens[b] * hop].copy() for b in range(len(sems))]
