@@ -51,17 +51,39 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores() -> int:
+    """CPU cores this process may actually use (affinity mask and cgroup quota, not the box total)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline(llm_cfg, voc_cfg, prompt, glob, n_tokens):
     """The oracle (CPU restatement pinned to the reference by tests/golden) on the host cores."""
     from oracle.llm_ref import Qwen2Ref
     from oracle.bicodec_ref import BiCodecDetokRef
     from sparkmi import weights as W
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: building fp32 oracle weights ({cores} cores)")
     t0 = time.time()
     ref = Qwen2Ref(llm_cfg, W.SyntheticLLM(llm_cfg))
     voc = BiCodecDetokRef(voc_cfg, W.fold_weight_norm(W.bicodec_detok_state(voc_cfg)))
     build_s = time.time() - t0
+    log(f"cpu_baseline: weights ready in {build_s:.1f}s; generating {n_tokens} tokens")
     t0 = time.time()
     toks = ref.generate_greedy(prompt, n_tokens)
     t_llm = time.time() - t0
@@ -109,6 +131,9 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     arch = _lib.require_gfx950()
+    torch.set_num_threads(host_cores())
+    if rank == 0:
+        log(f"device {arch}, world {world}, host cores {host_cores()}: building synthetic weights")
 
     llm_cfg, voc_cfg = C.spark_0p5b_llm(), C.spark_0p5b_bicodec()
     B, P, N = a.batch, a.prompt_len, a.new_tokens
@@ -162,8 +187,12 @@ def main():
             voc_ms.append(ev[2].elapsed_time(ev[3]))
         return out, toks
 
+    if rank == 0:
+        log(f"weights packed in {t_build:.1f}s, broadcast {bcast_ms:.1f} ms; warm-up")
     for _ in range(a.warmup):
         wav, toks = step()
+    if rank == 0:
+        log("timed region")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -202,6 +231,7 @@ def main():
     }
 
     if rank == 0:
+        log(f"timed: {el:.3f}s for {a.steps} steps -> {value:.0f} samples/s; probing kernels")
         # ---- roofline: decode step is HBM-bound; algorithmic bytes = weights once + KV read + KV write
         wb = llm.step_weight_bytes()
         kvb = llm.kv_bytes_per_token()
@@ -249,6 +279,7 @@ def main():
         else:
             res["roofline"] = dict(res["roofline_step"])
         if not a.no_cpu_baseline and world == 1:
+            log("gpu side done; timing the CPU oracle")
             res["cpu_baseline"] = cpu_baseline(llm_cfg, voc_cfg, prompts[0], globs[0], a.cpu_tokens)
             res["gpu_over_cpu_rtf"] = res["cpu_baseline"]["rtf"] / res["rtf"]
         print(json.dumps(res))

@@ -46,7 +46,7 @@ const char* smi_last_error(void);
 int smi_device_check(char* name, int n);
 
 /* ------------------------------------------------------------------------------------------
- * LLM: Qwen2 decoder-only LM, greedy generation with a KV cache.
+ * LLM: Qwen2 decoder-only LM, greedy or sampled generation with a KV cache.
  * ---------------------------------------------------------------------------------------- */
 typedef struct smi_llm smi_llm;
 
@@ -92,7 +92,13 @@ int smi_llm_destroy(smi_llm* h);
  *   eos_id:    a sequence stops counting tokens after emitting it; pass -1 to never stop.       */
 int smi_llm_prefill(smi_llm* h, const int64_t* ids_host, const int32_t* lens_host, int B, int P_max,
                     int64_t eos_id, void* stream);
-/* Run n_steps more greedy decode steps for all B sequences (finished ones keep stepping; their
+/* Token selection for the following prefill/decode calls.  do_sample = 0: greedy argmax (lowest id
+ * on ties, like torch.argmax).  do_sample = 1: the reference's default at cli/SparkTTS.py:197-204 --
+ * temperature, then top-k (1..256), then nucleus top-p, one multinomial draw per step from a
+ * Philox stream keyed by (seed, step, row): reproducible per seed, statistically (not bitwise)
+ * equivalent to transformers' sampler. */
+int smi_llm_set_sampling(smi_llm* h, int do_sample, float temperature, int top_k, float top_p, uint64_t seed);
+/* Run n_steps more decode steps for all B sequences (finished ones keep stepping; their
  * tokens are not counted).  Asynchronous. */
 int smi_llm_decode(smi_llm* h, int n_steps, void* stream);
 /* Synchronises the stream; *all_done = 1 when every sequence has emitted eos. */

@@ -420,7 +420,126 @@ __global__ void k_embed(const uint16_t* W, int KT, const RowDesc* rows, int M, f
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Sampling (the reference's default: do_sample=True, top_k=50, top_p=0.95, temperature=0.8 at
+// cli/SparkTTS.py:166-168,197-204).  Restates the HF warper chain: logits / T -> keep top k ->
+// nucleus (drop the low tail whose cumulative probability <= 1 - top_p, keep >= 1) -> softmax ->
+// one multinomial draw.  The draw uses a counter-based Philox4x32-10 stream keyed by
+// (seed; step, row), so a run is reproducible but not bit-identical to torch.multinomial.
+// ------------------------------------------------------------------------------------------
+struct SampleP {
+  const float* logits;  // [M][V]
+  int V, top_k;
+  float inv_temp, top_p;
+  unsigned long long seed;
+  const int32_t* step;
+  int* tok;             // [32] sampled token per row
+};
+
+__device__ __forceinline__ uint32_t sortable(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+__device__ inline uint32_t philox_u32(unsigned long long seed, uint32_t c0, uint32_t c1) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  uint32_t x0 = c0, x1 = c1, x2 = 0x5eed5eedu, x3 = 0;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * x0, p1 = (unsigned long long)0xCD9E8D57u * x2;
+    const uint32_t y0 = (uint32_t)(p1 >> 32) ^ x1 ^ k0, y1 = (uint32_t)p1;
+    const uint32_t y2 = (uint32_t)(p0 >> 32) ^ x3 ^ k1, y3 = (uint32_t)p0;
+    x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return x0;
+}
+
+constexpr int kSampleCap = 256;  // top_k upper bound
+
+__global__ __launch_bounds__(1024) void k_sample(SampleP p) {
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned int s_prefix, s_need, s_cnt;
+  __shared__ float cv[kSampleCap], sv[kSampleCap];
+  __shared__ int ci[kSampleCap], si[kSampleCap];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const float* lg = p.logits + (size_t)m * p.V;
+  // radix select: key of the k-th largest logit
+  if (tid == 0) { s_prefix = 0; s_need = (unsigned)p.top_k; }
+  __syncthreads();
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const uint32_t prefix = s_prefix;
+    const uint32_t mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    for (int i = tid; i < p.V; i += 1024) {
+      const uint32_t k = sortable(lg[i]);
+      if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned need = s_need;
+      int b = 255;
+      for (; b > 0; --b) {
+        if (hist[b] >= need) break;
+        need -= hist[b];
+      }
+      s_need = need;                       // rank inside bin b
+      s_prefix = prefix | ((uint32_t)b << shift);
+    }
+    __syncthreads();
+  }
+  const uint32_t thr = s_prefix;           // exact key of the k-th largest
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  for (int i = tid; i < p.V; i += 1024) {
+    const float v = lg[i];
+    if (sortable(v) >= thr) {
+      const unsigned pos = atomicAdd(&s_cnt, 1u);
+      if (pos < kSampleCap) { cv[pos] = v; ci[pos] = i; }
+    }
+  }
+  __syncthreads();
+  const int n = s_cnt < (unsigned)kSampleCap ? (int)s_cnt : kSampleCap;
+  // rank sort: descending value, ascending index on ties
+  if (tid < n) {
+    const float v = cv[tid];
+    const int ix = ci[tid];
+    int r = 0;
+    for (int j = 0; j < n; ++j) r += (cv[j] > v) || (cv[j] == v && ci[j] < ix);
+    sv[r] = v; si[r] = ix;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int k = n < p.top_k ? n : p.top_k;
+    // softmax over the top-k of logits / T (fp32, like the warpers), then the nucleus cut
+    const float mx = sv[0] * p.inv_temp;
+    float sum = 0.f;
+    for (int i = 0; i < k; ++i) { cv[i] = expf(sv[i] * p.inv_temp - mx); sum += cv[i]; }
+    float tail = 0.f;
+    int keep = 1;
+    // ascending cumulative probability: token i is dropped when sum_{j>=i} p_j <= 1 - top_p
+    for (int i = k - 1; i >= 1; --i) {
+      tail += cv[i] / sum;
+      if (tail > 1.0f - p.top_p) { keep = i + 1; break; }
+    }
+    float ksum = 0.f;
+    for (int i = 0; i < keep; ++i) ksum += cv[i];
+    const uint32_t r = philox_u32(p.seed, (uint32_t)*p.step, (uint32_t)m);
+    const float u = (float)(r >> 8) * (1.0f / 16777216.0f) * ksum;
+    float acc = 0.f;
+    int pick = keep - 1;
+    for (int i = 0; i < keep; ++i) {
+      acc += cv[i];
+      if (u < acc) { pick = i; break; }
+    }
+    p.tok[m] = si[pick];
+  }
+}
+
 struct FinP {
+  const int* tok;       // non-null: tokens already chosen by k_sample
   const float* pval;
   const int* pidx;
   int nblk, M, KT;
@@ -444,7 +563,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinP p) {
   for (int m = 0; m < p.M; ++m) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = tid; i < p.nblk; i += 256) {
+    for (int i = tid; i < (p.tok ? 0 : p.nblk); i += 256) {
       const float v = p.pval[(size_t)i * 32 + m];
       const int ix = p.pidx[(size_t)i * 32 + m];
       if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
@@ -460,6 +579,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinP p) {
     if (tid == 0) {
       for (int w = 1; w < 4; ++w)
         if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+      if (p.tok) bi = p.tok[m];
       tok_s[m] = bi;
       if (step < p.max_steps) p.hist[(size_t)step * 32 + m] = bi;
       if (!p.finished[m]) {
@@ -546,6 +666,9 @@ struct smi_llm {
   void *kcache, *vcache; size_t kv_layer_elems;
   int B; int64_t eos; int started;
   int max_len, steps_launched;  // host-side bound on cache positions in use
+  // sampling state (smi_llm_set_sampling)
+  int do_sample, top_k; float temperature, top_p; unsigned long long seed;
+  float* logits; int* tok;
   int max_steps;
   hipGraphExec_t graph; int graph_B;
   hipEvent_t ev0, ev1;
@@ -630,10 +753,20 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
     case KLM:
       p.W = (const uint4*)sec(L, SMI_LLM_LM_HEAD, 0); p.NT = L->NTlm; p.KT = L->KTh;
       p.X = L->h; p.gamma = (const float*)sec(L, SMI_LLM_FINAL_NORM, 0);
-      p.Y = logits; p.V = c.vocab_size; p.pval = L->pval; p.pidx = L->pidx;
+      p.Y = logits ? logits : (L->do_sample ? L->logits : nullptr);
+      p.V = c.vocab_size; p.pval = L->pval; p.pidx = L->pidx;
       return launch_gemm<4, 4, PRO_NORM, EPI_LM>(L, p, st);
     case KFIN: {
       FinP f;
+      f.tok = nullptr;
+      if (L->do_sample) {
+        SampleP sp;
+        sp.logits = L->logits; sp.V = c.vocab_size; sp.top_k = L->top_k; sp.inv_temp = 1.0f / L->temperature;
+        sp.top_p = L->top_p; sp.seed = L->seed; sp.step = L->step; sp.tok = L->tok;
+        hipLaunchKernelGGL(k_sample, dim3(M), dim3(1024), 0, st, sp);
+        SMI_LAUNCH_CHECK();
+        f.tok = L->tok;
+      }
       f.pval = L->pval; f.pidx = L->pidx; f.nblk = L->lm_blocks; f.M = M; f.KT = L->KTh;
       f.rows = L->rows; f.hist = L->hist; f.count = L->count; f.finished = L->finished; f.step = L->step;
       f.eos = L->eos; f.Wlm = (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0); f.h = L->h; f.max_steps = L->max_steps;
@@ -728,6 +861,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->NTqkv = (L->Q + 2 * L->KV) / 16; L->NTh = L->H / 16; L->NTgu = 2 * L->I / 16; L->NTlm = lay.vpad / 16;
   L->lm_blocks = (L->NTlm + 3) / 4;
   L->max_steps = cfg->max_positions;
+  L->do_sample = 0; L->top_k = 50; L->temperature = 0.8f; L->top_p = 0.95f; L->seed = 0; L->logits = nullptr; L->tok = nullptr;
   L->graph = nullptr; L->graph_B = 0; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->eos = -1;
   const size_t esz = cfg->kv_dtype ? 4 : 2;
   L->kv_layer_elems = (size_t)cfg->max_slots * cfg->num_kv_heads * cfg->max_positions * kHeadDim;
@@ -749,6 +883,8 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   SMI_ALLOC(L->count, 32 * 4);
   SMI_ALLOC(L->finished, 32 * 4);
   SMI_ALLOC(L->step, 4);
+  SMI_ALLOC(L->logits, (size_t)kMaxRows * cfg->vocab_size * 4);
+  SMI_ALLOC(L->tok, 32 * 4);
   SMI_ALLOC(L->kcache, kvbytes);
   SMI_ALLOC(L->vcache, kvbytes);
 #undef SMI_ALLOC
@@ -777,12 +913,26 @@ int smi_llm_destroy(smi_llm* L) {
   if (!L) return SMI_OK;
   if (L->graph) (void)hipGraphExecDestroy(L->graph);
   void* ptrs[] = {L->h, L->qbuf, L->attn, L->act, L->rows, L->plan, L->pval, L->pidx, L->hist,
-                  L->count, L->finished, L->step, L->kcache, L->vcache};
+                  L->count, L->finished, L->step, L->kcache, L->vcache, L->logits, L->tok};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (L->ev0) (void)hipEventDestroy(L->ev0);
   if (L->ev1) (void)hipEventDestroy(L->ev1);
   delete L;
+  return SMI_OK;
+}
+
+int smi_llm_set_sampling(smi_llm* L, int do_sample, float temperature, int top_k, float top_p, uint64_t seed) {
+  SMI_REQUIRE(L, "smi_llm_set_sampling: null handle");
+  if (do_sample) {
+    SMI_REQUIRE(temperature > 0.f, "smi_llm_set_sampling: temperature must be > 0");
+    SMI_REQUIRE(top_k >= 1 && top_k <= kSampleCap, "smi_llm_set_sampling: top_k must be in 1..%d", kSampleCap);
+    SMI_REQUIRE(top_p > 0.f && top_p <= 1.f, "smi_llm_set_sampling: top_p must be in (0, 1]");
+    if (top_k > L->cfg.vocab_size) top_k = L->cfg.vocab_size;
+  }
+  L->do_sample = do_sample ? 1 : 0;
+  L->temperature = temperature; L->top_k = top_k; L->top_p = top_p; L->seed = seed;
+  if (L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }   // parameters are baked into the graph
   return SMI_OK;
 }
 

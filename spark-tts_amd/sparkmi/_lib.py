@@ -53,6 +53,7 @@ SYMBOLS = {
     "smi_llm_create": (_I, [_P(LLMCfg), _VP, _SZ, _P(_VP)]),
     "smi_llm_destroy": (_I, [_VP]),
     "smi_llm_prefill": (_I, [_VP, _P(C.c_int64), _P(C.c_int32), _I, _I, C.c_int64, _VP]),
+    "smi_llm_set_sampling": (_I, [_VP, _I, C.c_float, _I, C.c_float, C.c_uint64]),
     "smi_llm_decode": (_I, [_VP, _I, _VP]),
     "smi_llm_all_done": (_I, [_VP, _P(_I), _VP]),
     "smi_llm_get_tokens": (_I, [_VP, _P(C.c_int64), _P(C.c_int32), _I, _VP]),
@@ -81,6 +82,10 @@ def lib() -> C.CDLL:
             raise SparkMIError(
                 f"{LIB_PATH} is missing: build it with `make -C spark-tts_amd/csrc` "
                 "(or __graft_entry__.build()). sparkmi has no CPU fallback.")
+        # libsparkmi needs libamdhip64; PyTorch-ROCm ships its own copy and must own the process's
+        # HIP runtime (streams and device memory are shared), so torch is loaded first and the
+        # library then binds to the runtime that is already resident.
+        import torch  # noqa: F401
         l = C.CDLL(str(LIB_PATH))
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)   # AttributeError here = header/library mismatch

@@ -86,10 +86,21 @@ class SparkLLM:
             cap, self._stream()), "smi_llm_get_tokens")
         return [out[b, : lens[b]].tolist() for b in range(self._B)]
 
+    def set_sampling(self, do_sample: bool, temperature: float = 0.8, top_k: int = 50, top_p: float = 0.95,
+                     seed: Optional[int] = None) -> None:
+        if seed is None:
+            seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0]) if do_sample else 0
+        _lib.check(self._lib.smi_llm_set_sampling(self._h, int(bool(do_sample)), float(temperature), int(top_k),
+                                                  float(top_p), int(seed) & (2 ** 64 - 1)), "smi_llm_set_sampling")
+
     def generate_ids(self, prompts: Sequence[Sequence[int]], max_new_tokens: int,
-                     eos_token_id: Optional[int] = None, check_every: int = 32) -> List[List[int]]:
-        """Greedy generation for B ragged prompts; returns only the new ids per sequence
-        (eos included when emitted).  With no eos the whole run is enqueued without a host sync."""
+                     eos_token_id: Optional[int] = None, check_every: int = 32, do_sample: bool = False,
+                     temperature: float = 0.8, top_k: int = 50, top_p: float = 0.95,
+                     seed: Optional[int] = None) -> List[List[int]]:
+        """Generation for B ragged prompts; returns only the new ids per sequence (eos included
+        when emitted).  Greedy by default; ``do_sample`` selects the reference's temperature /
+        top-k / top-p sampler.  With no eos the whole run is enqueued without a host sync."""
+        self.set_sampling(do_sample, temperature, top_k, top_p, seed)
         if max_new_tokens < 1:
             raise ValueError("max_new_tokens must be >= 1")
         longest = max(len(p) for p in prompts)
@@ -110,12 +121,9 @@ class SparkLLM:
     @torch.no_grad()
     def generate(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                  max_new_tokens: int = 3000, do_sample: bool = False, eos_token_id: Optional[int] = None,
-                 pad_token_id: Optional[int] = None, **unused) -> torch.Tensor:
+                 pad_token_id: Optional[int] = None, temperature: float = 1.0, top_k: int = 50,
+                 top_p: float = 1.0, seed: Optional[int] = None, **unused) -> torch.Tensor:
         """HF-shaped entry.  ``attention_mask`` marks real tokens of right- or left-padded rows."""
-        if do_sample:
-            raise NotImplementedError(
-                "sampling (top-k/top-p/temperature) is not built yet; pass do_sample=False for the "
-                "greedy path (SURVEY section 8f item 2)")
         ids = input_ids.detach().cpu().numpy().astype(np.int64)
         if ids.ndim == 1:
             ids = ids[None]
@@ -124,7 +132,8 @@ class SparkLLM:
             prompts = [ids[b][msk[b]].tolist() for b in range(ids.shape[0])]
         else:
             prompts = [ids[b].tolist() for b in range(ids.shape[0])]
-        new = self.generate_ids(prompts, max_new_tokens, eos_token_id)
+        new = self.generate_ids(prompts, max_new_tokens, eos_token_id, do_sample=do_sample, temperature=temperature,
+                                top_k=top_k, top_p=top_p, seed=seed)
         pad = pad_token_id if pad_token_id is not None else (eos_token_id if eos_token_id is not None else 0)
         n = max(len(t) for t in new)
         out = np.full((ids.shape[0], ids.shape[1] + n), pad, dtype=np.int64)

@@ -73,8 +73,55 @@ def test_hf_shaped_generate_and_eos(tiny):
     stop = free.index(eos) + 1
     assert new[:stop] == free[:stop] and len(new) == stop
     assert Qwen2Ref(cfg, syn).generate_greedy(prompt, 20, eos_ids=[eos]) == new
-    with pytest.raises(NotImplementedError):
-        llm.generate(ids, do_sample=True)
+
+
+def _expected_sampling_probs(logits, temperature, top_k, top_p):
+    """transformers' warper chain (TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper)
+    restated with torch ops: returns the full-vocabulary probability vector."""
+    z = logits / temperature
+    kth = torch.topk(z, top_k).values[-1]
+    z = z.masked_fill(z < kth, float("-inf"))
+    sl, si = torch.sort(z, descending=False)
+    cum = sl.softmax(-1).cumsum(-1)
+    remove = cum <= (1 - top_p)
+    remove[-1:] = False
+    z = z.masked_fill(remove.scatter(0, si, remove), float("-inf"))
+    return z.softmax(-1)
+
+
+def test_sampling_distribution_matches_the_warper_chain(tiny):
+    cfg, syn = tiny
+    prompt = [5, 17, 200, 33, 9, 410, 77]
+    T, K, P = 0.8, 50, 0.95
+    logits = Qwen2Ref(cfg, syn, kv_dtype="bf16").forward(prompt, last_only=True)[0]
+    want = _expected_sampling_probs(logits, T, K, P).numpy()
+    llm = _llm(cfg, syn, max_slots=32, max_positions=64)
+    counts = np.zeros(cfg.vocab_size)
+    n = 0
+    for seed in range(128):
+        for t in llm.generate_ids([prompt] * 32, 1, do_sample=True, temperature=T, top_k=K, top_p=P, seed=seed):
+            counts[t[0]] += 1
+            n += 1
+    assert (counts[want == 0] == 0).all(), "sampled a token outside the top-k / nucleus set"
+    tv = 0.5 * np.abs(counts / n - want).sum()
+    assert tv < 0.08, f"total variation distance {tv}"
+    assert (counts > 0).sum() > 5
+
+
+def test_sampling_is_seeded_and_top_k_1_is_greedy(tiny):
+    cfg, syn = tiny
+    prompt = [3, 1, 4, 1, 5, 9, 2, 6]
+    llm = _llm(cfg, syn, max_positions=96)
+    greedy = llm.generate_ids([prompt], 24)[0]
+    assert llm.generate_ids([prompt], 24, do_sample=True, top_k=1, seed=9)[0] == greedy
+    a = llm.generate_ids([prompt], 24, do_sample=True, seed=1234)[0]
+    b = llm.generate_ids([prompt], 24, do_sample=True, seed=1234)[0]
+    c = llm.generate_ids([prompt], 24, do_sample=True, seed=4321)[0]
+    assert a == b and a != c and a != greedy
+    assert llm.generate_ids([prompt], 24)[0] == greedy     # switching back to greedy works
+    from sparkmi._lib import SparkMIError
+    with pytest.raises(SparkMIError):
+        llm.generate_ids([prompt], 4, do_sample=True, top_k=1000)
 
 
 def test_ragged_batch_equals_single_sequence_runs(tiny):

@@ -1,0 +1,105 @@
+"""End-to-end: the SparkTTS drop-in on a synthetic model directory (real loading code: HF
+tokenizer files, config.json / config.yaml, bf16 safetensors, weight-norm folding) against an
+oracle pipeline assembled from the same tokenizer + the CPU oracle LLM + regex + the CPU oracle
+vocoder, i.e. the steps of cli/SparkTTS.py:187-234."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.bicodec_ref import BiCodecDetokRef
+from oracle.llm_ref import Qwen2Ref
+from sparkmi import weights as W
+from sparkmi.pipeline_text import build_clone_prompt, parse_semantic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model_dir(tmp_path_factory):
+    from sparkmi import synthetic
+    d = tmp_path_factory.mktemp("spark_synth")
+    cfgs = synthetic.make_model_dir(d)
+    return d, cfgs
+
+
+def _oracle_inference(d, cfgs, text, glob, prompt_sem, prompt_text, max_new):
+    from transformers import AutoTokenizer
+    lcfg, vcfg = cfgs
+    tok = AutoTokenizer.from_pretrained(str(d / "LLM"))
+    prompt = build_clone_prompt(text, glob, prompt_sem, prompt_text)
+    ids = tok([prompt], return_tensors="pt").input_ids[0].tolist()
+    llm = Qwen2Ref(lcfg, W.load_llm_state(d / "LLM"), kv_dtype="bf16")
+    new = llm.generate_greedy(ids, max_new, eos_ids=[tok.eos_token_id])
+    sem = parse_semantic(tok.batch_decode([new], skip_special_tokens=True)[0])
+    voc = BiCodecDetokRef(vcfg, W.fold_weight_norm(W.load_bicodec_state(d / "BiCodec")))
+    wav = voc.detokenize_numpy(torch.tensor([glob]), torch.tensor([sem]))
+    return wav, sem, new
+
+
+def test_attributes_and_prompt_builders(model_dir):
+    from sparkmi.pipeline import SparkTTS
+    d, (lcfg, vcfg) = model_dir
+    tts = SparkTTS(d, torch.device("cuda:0"), max_positions=512, max_frames=256)
+    for a in ("device", "model_dir", "configs", "sample_rate", "tokenizer", "model", "audio_tokenizer"):
+        assert hasattr(tts, a)
+    assert tts.sample_rate == 16000 and tts.configs["sample_rate"] == 16000
+    p = tts.process_prompt_control("female", "moderate", "high", "hi")
+    assert p == ("<|task_controllable_tts|><|start_content|>hi<|end_content|><|start_style_label|>"
+                 "<|gender_0|><|pitch_label_2|><|speed_label_3|><|end_style_label|>")
+    with pytest.raises(AssertionError):
+        tts.process_prompt_control("alien", "low", "low", "x")
+    g = torch.arange(vcfg.spk_token_num).reshape(1, 1, -1)
+    s, gid = tts.process_prompt("abc", None, "pt", prompt_tokens=(g, torch.tensor([[4, 5]])))
+    assert s.endswith("<|start_semantic_token|><|bicodec_semantic_4|><|bicodec_semantic_5|>") and gid is not None
+    with pytest.raises(NotImplementedError):
+        tts.process_prompt("abc", "missing.wav")      # prompt audio encode is the next row
+
+
+@pytest.mark.parametrize("prompt_text", [None, "spoken before"])
+def test_clone_mode_inference_matches_oracle_pipeline(model_dir, prompt_text):
+    from sparkmi.pipeline import SparkTTS
+    d, cfgs = model_dir
+    lcfg, vcfg = cfgs
+    rng = np.random.Generator(np.random.PCG64(11))
+    glob = rng.integers(0, 4096, size=vcfg.spk_token_num).tolist()
+    psem = rng.integers(0, vcfg.codebook_size, size=9).tolist()
+    tts = SparkTTS(d, torch.device("cuda:0"), max_positions=512, max_frames=256)
+    ptoks = (torch.tensor(glob).reshape(1, 1, -1), torch.tensor([psem]))
+    wav = tts.inference("The quick brown fox.", prompt_text=prompt_text, prompt_tokens=ptoks, do_sample=False,
+                        max_new_tokens=48)
+    want, sem, new = _oracle_inference(d, cfgs, "The quick brown fox.", glob, psem, prompt_text, 48)
+    assert len(sem) >= 1
+    assert wav.dtype == np.float32 and wav.shape == want.shape == (len(sem) * vcfg.hop,)
+    assert np.abs(wav - want).max() < 1e-3          # north_star bound on the fp32 waveform
+    assert np.abs(wav - want).max() < 2e-4
+
+
+def test_batch_equals_singles_and_sampling_runs(model_dir):
+    from sparkmi.pipeline import SparkTTS
+    d, (lcfg, vcfg) = model_dir
+    rng = np.random.Generator(np.random.PCG64(12))
+    reqs = []
+    for i in range(3):
+        glob = torch.from_numpy(rng.integers(0, 4096, size=(1, 1, vcfg.spk_token_num)))
+        reqs.append(dict(text=f"utterance number {i} " * (i + 1), prompt_tokens=(glob, torch.zeros((1, 0), dtype=torch.long))))
+    tts = SparkTTS(d, torch.device("cuda:0"), max_batch=3, max_positions=512, max_frames=256)
+    batch = tts.inference_batch(reqs, do_sample=False, max_new_tokens=40)
+    for i, r in enumerate(reqs):
+        one = tts.inference(r["text"], prompt_tokens=r["prompt_tokens"], do_sample=False, max_new_tokens=40)
+        assert np.array_equal(one, batch[i])
+    # reference default (sampling): runs, is reproducible per seed, and differs across seeds
+    a = tts.inference(reqs[0]["text"], prompt_tokens=reqs[0]["prompt_tokens"], max_new_tokens=40, seed=5)
+    b = tts.inference(reqs[0]["text"], prompt_tokens=reqs[0]["prompt_tokens"], max_new_tokens=40, seed=5)
+    c = tts.inference(reqs[0]["text"], prompt_tokens=reqs[0]["prompt_tokens"], max_new_tokens=40, seed=6)
+    assert np.array_equal(a, b)
+    assert a.shape != c.shape or not np.array_equal(a, c)
+
+
+def test_control_mode_needs_the_speaker_tokens(model_dir):
+    """With random weights the LM does not emit exactly 32 global tokens; the reference would fail
+    inside the FSQ reshape -- here the mismatch is reported explicitly."""
+    from sparkmi.pipeline import SparkTTS
+    d, _ = model_dir
+    tts = SparkTTS(d, torch.device("cuda:0"), max_positions=512, max_frames=256)
+    with pytest.raises(ValueError, match="global tokens"):
+        tts.inference("hello", gender="male", pitch="low", speed="high", do_sample=False, max_new_tokens=16)
