@@ -89,7 +89,7 @@ def cpu_baseline(llm_cfg, voc_cfg, prompt, glob, n_tokens):
     t_llm = time.time() - t0
     sem = torch.tensor([[t % voc_cfg.codebook_size for t in toks]])
     t0 = time.time()
-    wav = voc.detokenize(sem, torch.as_tensor(glob)[None])
+    wav = voc.detokenize(sem, torch.as_tensor(glob)[None, None])
     t_voc = time.time() - t0
     samples = wav.shape[-1]
     total = t_llm + t_voc
