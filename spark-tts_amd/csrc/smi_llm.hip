@@ -60,7 +60,25 @@ struct GemmP {
 // ------------------------------------------------------------------------------------------
 // GEMM: Y[m][n] = sum_k W[n][k] * X'[m][k]
 // ------------------------------------------------------------------------------------------
-template <int MT, int NTB, int NW, int PRO, int EPI, int KVF32>
+// exact 3-way bf16 split of 8 fp32 values, written as three 16-byte B-operand pieces
+__device__ __forceinline__ void split_store(const float (&v)[8], unsigned char* dst, int plane_bytes) {
+  uint32_t hi[8], mi[8], lo[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    hi[i] = smi_f32_to_bf16(v[i]);
+    const float r1 = v[i] - smi_bf16_to_f32(hi[i]);
+    mi[i] = smi_f32_to_bf16(r1);
+    const float r2 = r1 - smi_bf16_to_f32(mi[i]);
+    lo[i] = smi_f32_to_bf16(r2);
+  }
+  *(uint4*)(dst) = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+  *(uint4*)(dst + plane_bytes) = make_uint4(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16), mi[4] | (mi[5] << 16), mi[6] | (mi[7] << 16));
+  *(uint4*)(dst + 2 * plane_bytes) = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+}
+
+// MT m-tiles of 16 rows, NTB 16-row weight tiles per block, NW waves (split K), U weight tiles per
+// wave kept in flight per batch.
+template <int MT, int NTB, int NW, int U, int PRO, int EPI, int KVF32>
 __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -75,8 +93,77 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
   float* rstd = (float*)(smem + main_bytes);
   float* bestv = rstd + 32;               // [NTB][32]
   int* besti = (int*)(bestv + NTB * 32);  // [NTB][32]
+  const int mslot_bytes = M * 16;
+  const int plane = 4 * mslot_bytes;      // bytes between the hi / mid / lo planes of one k tile
+  const bool single = p.KC >= KT;         // the whole K fits in LDS at once (small M)
+  constexpr int MAXO = 2;                 // octets per lane in the one-pass norm prologue => K <= 1024
+  const bool onepass = single && (PRO == PRO_PLAIN || (K >> 3) <= 64 * MAXO);
 
-  if (PRO == PRO_NORM) {
+  // (1) The weights do not depend on the activations: put the first batch of tiles in flight
+  //     before touching anything else, so their HBM latency overlaps the prologue.
+  uint4 w[U][NTB];
+  const int kcn0 = KT < p.KC ? KT : p.KC;
+  auto load_batch = [&](int kc0, int kcn, int j0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int j = j0 + u * NW;
+      j = j < kcn ? j : kcn - 1;
+#pragma unroll
+      for (int nb = 0; nb < NTB; ++nb) {
+        int nt = nt0 + nb;
+        nt = nt < NT ? nt : NT - 1;
+        w[u][nb] = p.W[((size_t)nt * KT + kc0 + j) * 64 + lane];
+      }
+    }
+  };
+  if (wave < kcn0) load_batch(0, kcn0, wave);
+
+  // (2) prologue
+  if (onepass) {
+    if (PRO == PRO_NORM) {
+      // one pass: wave w owns rows w, w+NW, ..: load the row once, reduce, scale, split, store
+      const int KO = K >> 3;
+      for (int m = wave; m < M; m += NW) {
+        float v[MAXO][8], g[MAXO][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXO; ++i) {
+          const int o = lane + 64 * i;
+          if (o < KO) {
+            const float4* src = (const float4*)(p.X + (size_t)m * K + o * 8);
+            const float4* gp = (const float4*)(p.gamma + o * 8);
+            const float4 a = src[0], b = src[1], g0 = gp[0], g1 = gp[1];
+            v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w;
+            v[i][4] = b.x; v[i][5] = b.y; v[i][6] = b.z; v[i][7] = b.w;
+            g[i][0] = g0.x; g[i][1] = g0.y; g[i][2] = g0.z; g[i][3] = g0.w;
+            g[i][4] = g1.x; g[i][5] = g1.y; g[i][6] = g1.z; g[i][7] = g1.w;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
+          }
+        }
+        ss = smi_wave_sum(ss);
+        const float r = 1.0f / sqrtf(ss / (float)K + p.eps);
+#pragma unroll
+        for (int i = 0; i < MAXO; ++i) {
+          const int o = lane + 64 * i;
+          if (o < KO) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = g[i][e] * (v[i][e] * r);  // weight * (x * rsqrt(var+eps)), MQ:251-252
+            split_store(v[i], xs + (((o >> 2) * 3) * 4 + (o & 3)) * mslot_bytes + m * 16, plane);
+          }
+        }
+      }
+    } else {
+      const int octs = KT * 4;
+      for (int u = tid; u < M * octs; u += NW * 64) {
+        const int m = u / octs, o = u - m * octs;
+        const float4* src = (const float4*)(p.X + (size_t)m * K + o * 8);
+        const float4 a = src[0], b = src[1];
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        split_store(v, xs + (((o >> 2) * 3) * 4 + (o & 3)) * mslot_bytes + m * 16, plane);
+      }
+    }
+  } else if (PRO == PRO_NORM) {
     for (int m = wave; m < M; m += NW) {
       const float4* xr = (const float4*)(p.X + (size_t)m * K);
       float s = 0.f;
@@ -96,57 +183,34 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
 #pragma unroll
     for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int mslot_bytes = M * 16;
   for (int kc0 = 0; kc0 < KT; kc0 += p.KC) {
     const int kcn = (KT - kc0) < p.KC ? (KT - kc0) : p.KC;
-    if (kc0) __syncthreads();
-    // ---- stage this chunk's activations as exact bf16 triples in MFMA B-operand order
-    const int octs = kcn * 4;
-    for (int u = tid; u < M * octs; u += NW * 64) {
-      const int m = u / octs, o = u - m * octs;
-      const int k = (kc0 * 4 + o) * 8;
-      const float4* src = (const float4*)(p.X + (size_t)m * K + k);
-      float4 a = src[0], b = src[1];
-      float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-      if (PRO == PRO_NORM) {
-        const float r = rstd[m];
-        const float4* gp = (const float4*)(p.gamma + k);
-        float4 g0 = gp[0], g1 = gp[1];
-        float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    if (!onepass) {
+      if (kc0) __syncthreads();
+      // stage this chunk's activations as exact bf16 triples in MFMA B-operand order
+      const int octs = kcn * 4;
+      for (int u = tid; u < M * octs; u += NW * 64) {
+        const int m = u / octs, o = u - m * octs;
+        const int k = (kc0 * 4 + o) * 8;
+        const float4* src = (const float4*)(p.X + (size_t)m * K + k);
+        float4 a = src[0], b = src[1];
+        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        if (PRO == PRO_NORM) {
+          const float r = rstd[m];
+          const float4* gp = (const float4*)(p.gamma + k);
+          float4 g0 = gp[0], g1 = gp[1];
+          float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = g[i] * (v[i] * r);  // weight * (x * rsqrt(var+eps)), MQ:251-252
+          for (int i = 0; i < 8; ++i) v[i] = g[i] * (v[i] * r);
+        }
+        split_store(v, xs + (((o >> 2) * 3) * 4 + (o & 3)) * mslot_bytes + m * 16, plane);
       }
-      uint32_t hi[8], mi[8], lo[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        hi[i] = smi_f32_to_bf16(v[i]);
-        float r1 = v[i] - smi_bf16_to_f32(hi[i]);
-        mi[i] = smi_f32_to_bf16(r1);
-        float r2 = r1 - smi_bf16_to_f32(mi[i]);
-        lo[i] = smi_f32_to_bf16(r2);
-      }
-      const int base = (((o >> 2) * 3) * 4 + (o & 3)) * mslot_bytes + m * 16;
-      *(uint4*)(xs + base) = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
-      *(uint4*)(xs + base + 4 * mslot_bytes) = make_uint4(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16), mi[4] | (mi[5] << 16), mi[6] | (mi[7] << 16));
-      *(uint4*)(xs + base + 8 * mslot_bytes) = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
     }
     __syncthreads();
     // ---- stream weight tiles; each wave owns k tiles wave, wave+NW, ...
-    constexpr int U = 4;
     const int k8 = lane >> 4;
     for (int j0 = wave; j0 < kcn; j0 += NW * U) {
-      uint4 w[U][NTB];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        int j = j0 + u * NW;
-        j = j < kcn ? j : kcn - 1;
-#pragma unroll
-        for (int nb = 0; nb < NTB; ++nb) {
-          int nt = nt0 + nb;
-          nt = nt < NT ? nt : NT - 1;
-          w[u][nb] = p.W[((size_t)nt * KT + kc0 + j) * 64 + lane];
-        }
-      }
+      if (kc0 != 0 || j0 != wave) load_batch(kc0, kcn, j0);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int j = j0 + u * NW;
@@ -158,7 +222,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
             m = m < M ? m : M - 1;
             const unsigned char* bp = xs + ((j * 3) * 4 + k8) * mslot_bytes + m * 16;
 #pragma unroll
-            for (int s = 0; s < 3; ++s) bf[s][mt] = *(const bf16x8*)(bp + s * 4 * mslot_bytes);
+            for (int s = 0; s < 3; ++s) bf[s][mt] = *(const bf16x8*)(bp + s * plane);
           }
 #pragma unroll
           for (int nb = 0; nb < NTB; ++nb) {
@@ -309,13 +373,17 @@ struct AttnP {
   int q_dim, n_kv, group, max_pos;
 };
 
+constexpr int kAttnWaves = 16;
+
 template <int KVF32>
-__global__ __launch_bounds__(256) void k_attn(AttnP p) {
+__global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
   constexpr int LPT = KVF32 ? 16 : 8;   // lanes per token row (each lane 16 bytes)
   constexpr int DPL = kHeadDim / LPT;   // dims per lane
-  constexpr int TPW = 64 / LPT;         // tokens per wave iteration
+  constexpr int TPW = 64 / LPT;         // tokens per wave per pass
+  constexpr int TPB = kAttnWaves * TPW; // tokens per block per pass
+  constexpr int UNR = 4;                // passes whose K/V loads are issued together
   constexpr float NEG = -1e30f;
-  __shared__ float wm[4], wl[4], wo[4][kHeadDim];
+  __shared__ float wm[kAttnWaves], wl[kAttnWaves], wo[kAttnWaves][kHeadDim];
   const int head = blockIdx.x, m = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tl = lane / LPT, dl = lane % LPT;
@@ -334,40 +402,51 @@ __global__ __launch_bounds__(256) void k_attn(AttnP p) {
 #pragma unroll
   for (int i = 0; i < DPL; ++i) o[i] = 0.f;
 
-  for (int t0 = wave * TPW; t0 < ctx; t0 += 4 * TPW) {
-    const int t = t0 + tl;
-    const bool valid = t < ctx;
-    const size_t off = (rowbase + (valid ? t : ctx - 1)) * kHeadDim + dl * DPL;
-    float kf[DPL], vf[DPL];
-    if (KVF32) {
-      const float4 kk = *(const float4*)((const float*)p.kcache + off);
-      const float4 vv = *(const float4*)((const float*)p.vcache + off);
-      kf[0] = kk.x; kf[1] = kk.y; kf[2] = kk.z; kf[3] = kk.w;
-      vf[0] = vv.x; vf[1] = vv.y; vf[2] = vv.z; vf[3] = vv.w;
-    } else {
-      const uint4 kk = *(const uint4*)((const uint16_t*)p.kcache + off);
-      const uint4 vv = *(const uint4*)((const uint16_t*)p.vcache + off);
-      const uint32_t ku[4] = {kk.x, kk.y, kk.z, kk.w}, vu[4] = {vv.x, vv.y, vv.z, vv.w};
+  for (int t0 = wave * TPW + tl; t0 < ctx + tl; t0 += TPB * UNR) {   // wave-uniform trip count
+    uint4 kr[UNR], vr[UNR];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        kf[2 * i] = __uint_as_float(ku[i] << 16);
-        kf[2 * i + 1] = __uint_as_float(ku[i] & 0xffff0000u);
-        vf[2 * i] = __uint_as_float(vu[i] << 16);
-        vf[2 * i + 1] = __uint_as_float(vu[i] & 0xffff0000u);
+    for (int u = 0; u < UNR; ++u) {
+      const int t = t0 + u * TPB;
+      const size_t off = (rowbase + (t < ctx ? t : ctx - 1)) * kHeadDim + dl * DPL;
+      if (KVF32) {
+        kr[u] = *(const uint4*)((const float*)p.kcache + off);
+        vr[u] = *(const uint4*)((const float*)p.vcache + off);
+      } else {
+        kr[u] = *(const uint4*)((const uint16_t*)p.kcache + off);
+        vr[u] = *(const uint4*)((const uint16_t*)p.vcache + off);
       }
     }
-    float d = 0.f;
 #pragma unroll
-    for (int i = 0; i < DPL; ++i) d += qv[i] * kf[i];
+    for (int u = 0; u < UNR; ++u) {
+      const int t = t0 + u * TPB;
+      const bool valid = t < ctx;
+      float kf[DPL], vf[DPL];
+      const uint32_t ku[4] = {kr[u].x, kr[u].y, kr[u].z, kr[u].w}, vu[4] = {vr[u].x, vr[u].y, vr[u].z, vr[u].w};
+      if (KVF32) {
 #pragma unroll
-    for (int s = 1; s < LPT; s <<= 1) d += __shfl_xor(d, s, 64);
-    if (valid) {
-      const float mn = fmaxf(mrun, d);
-      const float a = expf(mrun - mn), e = expf(d - mn);
-      lrun = lrun * a + e;
+        for (int i = 0; i < 4; ++i) { kf[i % DPL] = __uint_as_float(ku[i]); vf[i % DPL] = __uint_as_float(vu[i]); }
+      } else {
 #pragma unroll
-      for (int i = 0; i < DPL; ++i) o[i] = o[i] * a + e * vf[i];
-      mrun = mn;
+        for (int i = 0; i < 4; ++i) {
+          kf[(2 * i) % DPL] = __uint_as_float(ku[i] << 16);
+          kf[(2 * i + 1) % DPL] = __uint_as_float(ku[i] & 0xffff0000u);
+          vf[(2 * i) % DPL] = __uint_as_float(vu[i] << 16);
+          vf[(2 * i + 1) % DPL] = __uint_as_float(vu[i] & 0xffff0000u);
+        }
+      }
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < DPL; ++i) d += qv[i] * kf[i];
+#pragma unroll
+      for (int s = 1; s < LPT; s <<= 1) d += __shfl_xor(d, s, 64);
+      if (valid) {
+        const float mn = fmaxf(mrun, d);
+        const float a = expf(mrun - mn), e = expf(d - mn);
+        lrun = lrun * a + e;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) o[i] = o[i] * a + e * vf[i];
+        mrun = mn;
+      }
     }
   }
   // merge the token streams inside the wave
@@ -391,10 +470,12 @@ __global__ __launch_bounds__(256) void k_attn(AttnP p) {
   }
   __syncthreads();
   if (tid < kHeadDim) {
-    float mn = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    float mn = wm[0];
+#pragma unroll
+    for (int w = 1; w < kAttnWaves; ++w) mn = fmaxf(mn, wm[w]);
     float L = 0.f, O = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < kAttnWaves; ++w) {
       const float a = expf(wm[w] - mn);
       L += wl[w] * a;
       O += wo[w][tid] * a;
@@ -678,28 +759,28 @@ struct smi_llm {
 
 namespace {
 
-template <int MT, int NTB, int NW, int PRO, int EPI>
+template <int MT, int NTB, int NW, int U, int PRO, int EPI>
 int launch_gemm_kv(const smi_llm* L, const GemmP& p, hipStream_t st) {
   const int grid = (p.NT + NTB - 1) / NTB;
   const int xs_bytes = p.KC * 192 * p.M;
   const int red_bytes = NW * NTB * MT * 1024;
   const size_t lds = (size_t)(xs_bytes > red_bytes ? xs_bytes : red_bytes) + 32 * 4 + NTB * 32 * 8;
   if (L->cfg.kv_dtype)
-    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, PRO, EPI, 1>), dim3(grid), dim3(NW * 64), lds, st, p);
+    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, PRO, EPI, 1>), dim3(grid), dim3(NW * 64), lds, st, p);
   else
-    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, PRO, EPI, 0>), dim3(grid), dim3(NW * 64), lds, st, p);
+    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, PRO, EPI, 0>), dim3(grid), dim3(NW * 64), lds, st, p);
   SMI_LAUNCH_CHECK();
   return SMI_OK;
 }
 
-template <int NTB, int NW, int PRO, int EPI>
+template <int NTB, int NW, int U, int PRO, int EPI>
 int launch_gemm(const smi_llm* L, GemmP p, hipStream_t st) {
   // LDS chunking: activation splits cost 192 bytes per (row, k tile); keep them under 56 KiB
   int kc = (56 * 1024) / (192 * p.M);
   if (kc < 1) kc = 1;
   p.KC = kc < p.KT ? kc : p.KT;
-  if (p.M > 16) return launch_gemm_kv<2, NTB, NW, PRO, EPI>(L, p, st);
-  return launch_gemm_kv<1, NTB, NW, PRO, EPI>(L, p, st);
+  if (p.M > 16) return launch_gemm_kv<2, NTB, NW, (U > 4 ? 4 : U), PRO, EPI>(L, p, st);
+  return launch_gemm_kv<1, NTB, NW, U, PRO, EPI>(L, p, st);
 }
 
 const unsigned char* sec(const smi_llm* L, int s, int layer) {
@@ -727,35 +808,35 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       p.rope = (const float2*)sec(L, SMI_LLM_ROPE, 0);
       p.kcache = kv_layer(L, L->kcache, layer); p.vcache = kv_layer(L, L->vcache, layer);
       p.q_dim = L->Q; p.kv_dim = L->KV; p.n_kv = c.num_kv_heads; p.max_pos = c.max_positions;
-      return launch_gemm<1, 4, PRO_NORM, EPI_QKV>(L, p, st);
+      return launch_gemm<1, 4, 8, PRO_NORM, EPI_QKV>(L, p, st);
     case KATTN: {
       AttnP a;
       a.q = L->qbuf; a.kcache = kv_layer(L, L->kcache, layer); a.vcache = kv_layer(L, L->vcache, layer);
       a.rows = rows; a.out = L->attn; a.q_dim = L->Q; a.n_kv = c.num_kv_heads;
       a.group = c.num_heads / c.num_kv_heads; a.max_pos = c.max_positions;
-      if (c.kv_dtype) hipLaunchKernelGGL(k_attn<1>, dim3(c.num_heads, M), dim3(256), 0, st, a);
-      else hipLaunchKernelGGL(k_attn<0>, dim3(c.num_heads, M), dim3(256), 0, st, a);
+      if (c.kv_dtype) hipLaunchKernelGGL(k_attn<1>, dim3(c.num_heads, M), dim3(kAttnWaves * 64), 0, st, a);
+      else hipLaunchKernelGGL(k_attn<0>, dim3(c.num_heads, M), dim3(kAttnWaves * 64), 0, st, a);
       SMI_LAUNCH_CHECK();
       return SMI_OK;
     }
     case KO:
       p.W = (const uint4*)sec(L, SMI_LLM_WO, layer); p.NT = L->NTh; p.KT = L->KTq;
       p.X = L->attn; p.Y = L->h;
-      return launch_gemm<1, 4, PRO_PLAIN, EPI_RESID>(L, p, st);
+      return launch_gemm<1, 4, 8, PRO_PLAIN, EPI_RESID>(L, p, st);
     case KGU:
       p.W = (const uint4*)sec(L, SMI_LLM_WGU, layer); p.NT = L->NTgu; p.KT = L->KTh;
       p.X = L->h; p.gamma = (const float*)sec(L, SMI_LLM_LN2, layer); p.Y = L->act;
-      return launch_gemm<2, 4, PRO_NORM, EPI_SWIGLU>(L, p, st);
+      return launch_gemm<2, 4, 8, PRO_NORM, EPI_SWIGLU>(L, p, st);
     case KD:
       p.W = (const uint4*)sec(L, SMI_LLM_WD, layer); p.NT = L->NTh; p.KT = L->KTi;
       p.X = L->act; p.Y = L->h;
-      return launch_gemm<1, 8, PRO_PLAIN, EPI_RESID>(L, p, st);
+      return launch_gemm<1, 16, 5, PRO_PLAIN, EPI_RESID>(L, p, st);
     case KLM:
       p.W = (const uint4*)sec(L, SMI_LLM_LM_HEAD, 0); p.NT = L->NTlm; p.KT = L->KTh;
       p.X = L->h; p.gamma = (const float*)sec(L, SMI_LLM_FINAL_NORM, 0);
       p.Y = logits ? logits : (L->do_sample ? L->logits : nullptr);
       p.V = c.vocab_size; p.pval = L->pval; p.pidx = L->pidx;
-      return launch_gemm<4, 4, PRO_NORM, EPI_LM>(L, p, st);
+      return launch_gemm<4, 4, 4, PRO_NORM, EPI_LM>(L, p, st);
     case KFIN: {
       FinP f;
       f.tok = nullptr;
