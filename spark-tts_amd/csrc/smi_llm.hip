@@ -55,6 +55,7 @@ struct GemmP {
   int V;               // LM: true vocab size
   float* pval;         // LM: [gridDim.x][32] per-block best logit
   int* pidx;           // LM: [gridDim.x][32] per-block best index
+  unsigned long long* stamps;  // diagnostics: [gridDim.x][8] s_memrealtime stamps (100 MHz) or null
 };
 
 // ------------------------------------------------------------------------------------------
@@ -84,6 +85,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int KT = p.KT, K = KT * 32, M = p.M, NT = p.NT;
   const int nt0 = blockIdx.x * NTB;
+#define SMI_STAMP(i) do { if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  SMI_STAMP(0);
   // LDS map: [0, xs_bytes) activation splits (later aliased by the split-K reduction slab),
   // then rstd[32] floats, then argmax scratch.
   const int xs_bytes = p.KC * 192 * M;
@@ -117,6 +120,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
     }
   };
   if (wave < kcn0) load_batch(0, kcn0, wave);
+  SMI_STAMP(1);
 
   // (2) prologue
   if (onepass) {
@@ -182,6 +186,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
   for (int a = 0; a < NTB; ++a)
 #pragma unroll
     for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  SMI_STAMP(2);
 
   for (int kc0 = 0; kc0 < KT; kc0 += p.KC) {
     const int kcn = (KT - kc0) < p.KC ? (KT - kc0) : p.KC;
@@ -207,6 +212,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
       }
     }
     __syncthreads();
+    SMI_STAMP(3);
     // ---- stream weight tiles; each wave owns k tiles wave, wave+NW, ...
     const int k8 = lane >> 4;
     for (int j0 = wave; j0 < kcn; j0 += NW * U) {
@@ -240,6 +246,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
   }
 
   // ---- split-K reduction across the block's waves (fixed order => deterministic)
+  if (p.stamps) { asm volatile("" :: "v"(acc[0][0][0])); }
+  SMI_STAMP(4);
   __syncthreads();
   float4* red = (float4*)smem;  // [NW][NTB][MT][64]
 #pragma unroll
@@ -252,6 +260,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
     for (int i = tid; i < NTB * 32; i += NW * 64) { bestv[i] = -INFINITY; besti[i] = 0x7fffffff; }
   }
   __syncthreads();
+  SMI_STAMP(5);
 
   const int N = NT * 16;
   for (int nb = wave; nb < NTB; nb += NW) {
@@ -342,6 +351,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
       }
     }
   }
+  SMI_STAMP(6);
   if (EPI == EPI_LM) {
     __syncthreads();
     if (tid < M) {
@@ -750,6 +760,7 @@ struct smi_llm {
   // sampling state (smi_llm_set_sampling)
   int do_sample, top_k; float temperature, top_p; unsigned long long seed;
   float* logits; int* tok;
+  unsigned long long* stamps; int stamps_on;
   int max_steps;
   hipGraphExec_t graph; int graph_B;
   hipEvent_t ev0, ev1;
@@ -800,6 +811,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
   GemmP p;
   memset(&p, 0, sizeof(p));
   p.M = M; p.rows = rows; p.eps = c.rms_eps;
+  p.stamps = L->stamps_on ? L->stamps : nullptr;
   switch (which) {
     case KQKV:
       p.W = (const uint4*)sec(L, SMI_LLM_WQKV, layer); p.NT = L->NTqkv; p.KT = L->KTh;
@@ -942,7 +954,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->NTqkv = (L->Q + 2 * L->KV) / 16; L->NTh = L->H / 16; L->NTgu = 2 * L->I / 16; L->NTlm = lay.vpad / 16;
   L->lm_blocks = (L->NTlm + 3) / 4;
   L->max_steps = cfg->max_positions;
-  L->do_sample = 0; L->top_k = 50; L->temperature = 0.8f; L->top_p = 0.95f; L->seed = 0; L->logits = nullptr; L->tok = nullptr;
+  L->do_sample = 0; L->top_k = 50; L->temperature = 0.8f; L->top_p = 0.95f; L->seed = 0; L->logits = nullptr; L->tok = nullptr; L->stamps = nullptr; L->stamps_on = 0;
   L->graph = nullptr; L->graph_B = 0; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->eos = -1;
   const size_t esz = cfg->kv_dtype ? 4 : 2;
   L->kv_layer_elems = (size_t)cfg->max_slots * cfg->num_kv_heads * cfg->max_positions * kHeadDim;
@@ -966,6 +978,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   SMI_ALLOC(L->step, 4);
   SMI_ALLOC(L->logits, (size_t)kMaxRows * cfg->vocab_size * 4);
   SMI_ALLOC(L->tok, 32 * 4);
+  SMI_ALLOC(L->stamps, (size_t)4096 * 8 * 8);
   SMI_ALLOC(L->kcache, kvbytes);
   SMI_ALLOC(L->vcache, kvbytes);
 #undef SMI_ALLOC
@@ -994,7 +1007,7 @@ int smi_llm_destroy(smi_llm* L) {
   if (!L) return SMI_OK;
   if (L->graph) (void)hipGraphExecDestroy(L->graph);
   void* ptrs[] = {L->h, L->qbuf, L->attn, L->act, L->rows, L->plan, L->pval, L->pidx, L->hist,
-                  L->count, L->finished, L->step, L->kcache, L->vcache, L->logits, L->tok};
+                  L->count, L->finished, L->step, L->kcache, L->vcache, L->logits, L->tok, L->stamps};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (L->ev0) (void)hipEventDestroy(L->ev0);
@@ -1159,6 +1172,33 @@ int smi_llm_forward_logits(smi_llm* L, const int64_t* ids, int S, float* logits_
     if ((rc = launch_one(L, KLM, 0, rows, M, logits_dev + c * kMaxRows * (size_t)L->cfg.vocab_size, st))) return rc;
   }
   L->started = 0;  // the cache now holds this sequence; a generate must prefill again
+  return SMI_OK;
+}
+
+// Diagnostics: one launch of a decode-step GEMM kernel with in-kernel s_memrealtime stamps
+// (10 ns ticks); out[0..7) = mean over blocks of (stamp i - earliest stamp 0), out[7] = blocks.
+int smi_llm_debug_stamps(smi_llm* L, int kernel, int layer, double* out) {
+  SMI_REQUIRE(L && out && L->started, "smi_llm_debug_stamps: needs a started generation");
+  SMI_REQUIRE(kernel == KQKV || kernel == KO || kernel == KGU || kernel == KD || kernel == KLM, "smi_llm_debug_stamps: GEMM kernels only");
+  const int grids[] = {L->NTqkv, 0, L->NTh, (L->NTgu + 1) / 2, L->NTh, 0};
+  const int nblk = kernel == KLM ? L->lm_blocks : grids[kernel];
+  SMI_REQUIRE(nblk <= 4096, "smi_llm_debug_stamps: grid too large");
+  SMI_HIP(hipMemset(L->stamps, 0, (size_t)4096 * 64));
+  L->stamps_on = 1;
+  int rc = launch_one(L, kernel, layer, L->rows, L->B, nullptr, 0);
+  L->stamps_on = 0;
+  if (rc) return rc;
+  SMI_HIP(hipDeviceSynchronize());
+  std::vector<unsigned long long> h((size_t)nblk * 8);
+  SMI_HIP(hipMemcpy(h.data(), L->stamps, h.size() * 8, hipMemcpyDeviceToHost));
+  unsigned long long t0 = ~0ull;
+  for (int b = 0; b < nblk; ++b) t0 = h[(size_t)b * 8] < t0 ? h[(size_t)b * 8] : t0;
+  for (int i = 0; i < 7; ++i) {
+    double s = 0;
+    for (int b = 0; b < nblk; ++b) s += (double)(h[(size_t)b * 8 + i] - t0);
+    out[i] = s / nblk * 0.01;   // microseconds
+  }
+  out[7] = nblk;
   return SMI_OK;
 }
 
