@@ -46,9 +46,45 @@ __device__ __forceinline__ uint32_t smi_f32_to_bf16(float f) {
   uint32_t u = __float_as_uint(f);
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
-__device__ __forceinline__ float smi_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane sums on the DPP path (one VALU op per step, no LDS crossbar round trip).
+template <int CTRL>
+__device__ __forceinline__ float smi_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// sum over aligned groups of 8 / 16 lanes; every lane of the group gets the result
+__device__ __forceinline__ float smi_sum8(float v) {
+  v += smi_dpp<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += smi_dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += smi_dpp<0x141>(v);   // row_half_mirror
   return v;
+}
+__device__ __forceinline__ float smi_sum16(float v) {
+  v = smi_sum8(v);
+  v += smi_dpp<0x140>(v);   // row_mirror
+  return v;
+}
+__device__ __forceinline__ float smi_readlane(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// whole-wave sum (fixed association order => deterministic); the result is wave-uniform
+__device__ __forceinline__ float smi_wave_sum(float v) {
+  v = smi_sum16(v);
+  return (smi_readlane(v, 0) + smi_readlane(v, 16)) + (smi_readlane(v, 32) + smi_readlane(v, 48));
+}
+// touch [ptr, ptr+bytes) so it is resident in the Infinity Cache for a later kernel
+__device__ __forceinline__ void smi_prefetch_range(const void* ptr, size_t bytes, int worker, int nworkers) {
+  const uint4* q = (const uint4*)ptr;
+  const size_t n = bytes >> 4;
+  uint32_t acc = 0;
+  size_t i = (size_t)worker;
+  for (; i + 7 * (size_t)nworkers < n; i += 8 * (size_t)nworkers) {
+    uint4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = q[i + (size_t)u * nworkers];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc ^= v[u].x;
+  }
+  for (; i < n; i += nworkers) acc ^= q[i].x;
+  asm volatile("" ::"v"(acc));
 }
 #endif

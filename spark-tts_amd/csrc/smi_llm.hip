@@ -56,6 +56,9 @@ struct GemmP {
   float* pval;         // LM: [gridDim.x][32] per-block best logit
   int* pidx;           // LM: [gridDim.x][32] per-block best index
   unsigned long long* stamps;  // diagnostics: [gridDim.x][8] s_memrealtime stamps (100 MHz) or null
+  int work_blocks;             // blocks >= work_blocks only prefetch [pf_ptr, pf_ptr + pf_bytes) into the Infinity Cache
+  const void* pf_ptr;
+  size_t pf_bytes;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -78,11 +81,19 @@ __device__ __forceinline__ void split_store(const float (&v)[8], unsigned char* 
 }
 
 // MT m-tiles of 16 rows, NTB 16-row weight tiles per block, NW waves (split K), U weight tiles per
-// wave kept in flight per batch.
-template <int MT, int NTB, int NW, int U, int PRO, int EPI, int KVF32>
-__global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
+// wave kept in flight per batch.  PF: issue the first weight batch before the prologue.  ACC3: one
+// accumulator chain per bf16 split term (3x shorter dependent MFMA chains), summed (lo+mid)+hi.
+// The k-tile -> wave map (kt mod NW), the chain structure and the reduction order do not depend on
+// M, so a row's result is bit-identical whatever else is in the batch.
+template <int MT, int NTB, int NW, int U, int PRO, int EPI, int KVF32, bool PF, bool ACC3>
+__global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k_gemm(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= p.work_blocks) {   // helper blocks: warm the cache for a later kernel
+    smi_prefetch_range(p.pf_ptr, p.pf_bytes, ((int)blockIdx.x - p.work_blocks) * NW * 64 + tid,
+                       ((int)gridDim.x - p.work_blocks) * NW * 64);
+    return;
+  }
   const int KT = p.KT, K = KT * 32, M = p.M, NT = p.NT;
   const int nt0 = blockIdx.x * NTB;
 #define SMI_STAMP(i) do { if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
   const bool onepass = single && (PRO == PRO_PLAIN || (K >> 3) <= 64 * MAXO);
 
   // (1) The weights do not depend on the activations: put the first batch of tiles in flight
-  //     before touching anything else, so their HBM latency overlaps the prologue.
+  //     before touching anything else, so their latency overlaps the prologue.
   uint4 w[U][NTB];
   const int kcn0 = KT < p.KC ? KT : p.KC;
   auto load_batch = [&](int kc0, int kcn, int j0) {
@@ -119,7 +130,22 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
       }
     }
   };
-  if (wave < kcn0) load_batch(0, kcn0, wave);
+  if (PF && wave < kcn0) load_batch(0, kcn0, wave);
+  // epilogue operands that do not depend on the GEMM: fetch them now as well
+  const int em = lane & 15;                 // this lane's row inside an m-tile
+  RowDesc erd[MT];
+  float4 epre[MT];
+  if (wave < NTB && nt0 + wave < NT) {
+    const int n = (nt0 + wave) * 16 + 4 * (lane >> 4);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mt * 16 + em;
+      if (m < M) {
+        if (EPI == EPI_QKV) { erd[mt] = p.rows[m]; epre[mt] = *(const float4*)(p.bias + n); }
+        if (EPI == EPI_RESID) epre[mt] = *(const float4*)(p.Y + (size_t)m * (NT * 16) + n);
+      }
+    }
+  }
   SMI_STAMP(1);
 
   // (2) prologue
@@ -181,11 +207,14 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
     __syncthreads();
   }
 
-  f32x4 acc[NTB][MT];
+  constexpr int NA = ACC3 ? 3 : 1;
+  f32x4 acc[NA][NTB][MT];
 #pragma unroll
-  for (int a = 0; a < NTB; ++a)
+  for (int c = 0; c < NA; ++c)
 #pragma unroll
-    for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < NTB; ++a)
+#pragma unroll
+      for (int b = 0; b < MT; ++b) acc[c][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   SMI_STAMP(2);
 
   for (int kc0 = 0; kc0 < KT; kc0 += p.KC) {
@@ -213,10 +242,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
     }
     __syncthreads();
     SMI_STAMP(3);
-    // ---- stream weight tiles; each wave owns k tiles wave, wave+NW, ...
+    // ---- stream weight tiles; wave w owns the k tiles with (kt mod NW) == w (KC is a multiple of NW)
     const int k8 = lane >> 4;
     for (int j0 = wave; j0 < kcn; j0 += NW * U) {
-      if (kc0 != 0 || j0 != wave) load_batch(kc0, kcn, j0);
+      if (!PF || kc0 != 0 || j0 != wave) load_batch(kc0, kcn, j0);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int j = j0 + u * NW;
@@ -235,18 +264,24 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
             const bf16x8 a = __builtin_bit_cast(bf16x8, w[u][nb]);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-              acc[nb][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[2][mt], acc[nb][mt], 0, 0, 0);
-              acc[nb][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[1][mt], acc[nb][mt], 0, 0, 0);
-              acc[nb][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[0][mt], acc[nb][mt], 0, 0, 0);
+              acc[ACC3 ? 2 : 0][nb][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[2][mt], acc[ACC3 ? 2 : 0][nb][mt], 0, 0, 0);
+              acc[ACC3 ? 1 : 0][nb][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[1][mt], acc[ACC3 ? 1 : 0][nb][mt], 0, 0, 0);
+              acc[0][nb][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[0][mt], acc[0][nb][mt], 0, 0, 0);
             }
           }
         }
       }
     }
   }
+  if (ACC3) {
+#pragma unroll
+    for (int a = 0; a < NTB; ++a)
+#pragma unroll
+      for (int b = 0; b < MT; ++b) acc[0][a][b] = (acc[2][a][b] + acc[1][a][b]) + acc[0][a][b];   // (lo + mid) + hi
+  }
 
   // ---- split-K reduction across the block's waves (fixed order => deterministic)
-  if (p.stamps) { asm volatile("" :: "v"(acc[0][0][0])); }
+  if (p.stamps) { asm volatile("" :: "v"(acc[0][0][0][0])); }
   SMI_STAMP(4);
   __syncthreads();
   float4* red = (float4*)smem;  // [NW][NTB][MT][64]
@@ -255,7 +290,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
       red[((wave * NTB + nb) * MT + mt) * 64 + lane] =
-          make_float4(acc[nb][mt][0], acc[nb][mt][1], acc[nb][mt][2], acc[nb][mt][3]);
+          make_float4(acc[0][nb][mt][0], acc[0][nb][mt][1], acc[0][nb][mt][2], acc[0][nb][mt][3]);
   if (EPI == EPI_LM) {
     for (int i = tid; i < NTB * 32; i += NW * 64) { bestv[i] = -INFINITY; besti[i] = 0x7fffffff; }
   }
@@ -279,10 +314,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
       const bool valid = m < M;
       if (EPI == EPI_RESID) {
         if (valid) {
-          float4* y = (float4*)(p.Y + (size_t)m * N + n);
-          float4 h = *y;
+          float4 h = epre[mt];   // fetched at kernel entry (only this lane ever writes it)
           h.x += s.x; h.y += s.y; h.z += s.z; h.w += s.w;
-          *y = h;
+          *(float4*)(p.Y + (size_t)m * N + n) = h;
         }
       } else if (EPI == EPI_SWIGLU) {
         if (valid) {
@@ -294,9 +328,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
         }
       } else if (EPI == EPI_QKV) {
         if (valid) {
-          const float4 b = *(const float4*)(p.bias + n);
+          const float4 b = epre[mt];
           s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
-          const RowDesc rd = p.rows[m];
+          const RowDesc rd = erd[mt];
           if (n < p.q_dim + p.kv_dim) {
             // rows inside a head are ordered (0,32,1,33,..): (s.x,s.y) and (s.z,s.w) are RoPE pairs
             const int i0 = (n & 63) >> 1;
@@ -380,23 +414,39 @@ struct AttnP {
   const void* vcache;
   const RowDesc* rows;
   float* out;          // [M][q_dim]
-  int q_dim, n_kv, group, max_pos;
+  int q_dim, n_kv, group, max_pos, n_heads;
+  int work_blocks;     // = n_heads * M; later blocks only prefetch [pf_ptr, pf_ptr + pf_bytes)
+  const void* pf_ptr;
+  size_t pf_bytes;
 };
 
 constexpr int kAttnWaves = 16;
 
+// 16 waves; a group of LPT lanes owns one token per pass (16-byte K and V pieces per lane, dot
+// product reduced on the DPP path), UNR passes of loads are in flight together.  Softmax is done
+// per chunk of TPB*UNR tokens against a block-wide running max, so every lane accumulates at the
+// same scale and the final merge is a plain sum through LDS (no per-stream rescale, no shuffles).
 template <int KVF32>
 __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
   constexpr int LPT = KVF32 ? 16 : 8;   // lanes per token row (each lane 16 bytes)
   constexpr int DPL = kHeadDim / LPT;   // dims per lane
   constexpr int TPW = 64 / LPT;         // tokens per wave per pass
-  constexpr int TPB = kAttnWaves * TPW; // tokens per block per pass
+  constexpr int NGRP = kAttnWaves * TPW;  // token streams per block = tokens per pass
   constexpr int UNR = 4;                // passes whose K/V loads are issued together
   constexpr float NEG = -1e30f;
-  __shared__ float wm[kAttnWaves], wl[kAttnWaves], wo[kAttnWaves][kHeadDim];
-  const int head = blockIdx.x, m = blockIdx.y;
+  __shared__ __attribute__((aligned(16))) float smax[NGRP];
+  __shared__ __attribute__((aligned(16))) float sl[NGRP];
+  __shared__ __attribute__((aligned(16))) float so[NGRP][kHeadDim];
+  __shared__ float so2[4][kHeadDim], sl2[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= p.work_blocks) {
+    smi_prefetch_range(p.pf_ptr, p.pf_bytes, ((int)blockIdx.x - p.work_blocks) * kAttnWaves * 64 + tid,
+                       ((int)gridDim.x - p.work_blocks) * kAttnWaves * 64);
+    return;
+  }
+  const int head = blockIdx.x % p.n_heads, m = blockIdx.x / p.n_heads;
   const int tl = lane / LPT, dl = lane % LPT;
+  const int grp = wave * TPW + tl;
   const RowDesc rd = p.rows[m];
   const int ctx = rd.pos + 1;
   const int kvh = head / p.group;
@@ -408,15 +458,15 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
 #pragma unroll
     for (int i = 0; i < DPL; ++i) qv[i] = qp[i] * 0.125f;  // head_dim^-0.5, exact
   }
-  float mrun = NEG, lrun = 0.f, o[DPL];
+  float m_run = NEG, lrun = 0.f, o[DPL];
 #pragma unroll
   for (int i = 0; i < DPL; ++i) o[i] = 0.f;
 
-  for (int t0 = wave * TPW + tl; t0 < ctx + tl; t0 += TPB * UNR) {   // wave-uniform trip count
+  for (int c0 = 0; c0 < ctx; c0 += NGRP * UNR) {   // block-uniform
     uint4 kr[UNR], vr[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      const int t = t0 + u * TPB;
+      const int t = c0 + u * NGRP + grp;
       const size_t off = (rowbase + (t < ctx ? t : ctx - 1)) * kHeadDim + dl * DPL;
       if (KVF32) {
         kr[u] = *(const uint4*)((const float*)p.kcache + off);
@@ -426,71 +476,77 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
         vr[u] = *(const uint4*)((const uint16_t*)p.vcache + off);
       }
     }
+    float sc[UNR];
+    float lmax = NEG;
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      const int t = t0 + u * TPB;
-      const bool valid = t < ctx;
-      float kf[DPL], vf[DPL];
-      const uint32_t ku[4] = {kr[u].x, kr[u].y, kr[u].z, kr[u].w}, vu[4] = {vr[u].x, vr[u].y, vr[u].z, vr[u].w};
+      const uint32_t ku[4] = {kr[u].x, kr[u].y, kr[u].z, kr[u].w};
+      float d = 0.f;
       if (KVF32) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { kf[i % DPL] = __uint_as_float(ku[i]); vf[i % DPL] = __uint_as_float(vu[i]); }
+        for (int i = 0; i < 4; ++i) d += qv[i % DPL] * __uint_as_float(ku[i]);
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          kf[(2 * i) % DPL] = __uint_as_float(ku[i] << 16);
-          kf[(2 * i + 1) % DPL] = __uint_as_float(ku[i] & 0xffff0000u);
-          vf[(2 * i) % DPL] = __uint_as_float(vu[i] << 16);
-          vf[(2 * i + 1) % DPL] = __uint_as_float(vu[i] & 0xffff0000u);
+          d += qv[(2 * i) % DPL] * __uint_as_float(ku[i] << 16);
+          d += qv[(2 * i + 1) % DPL] * __uint_as_float(ku[i] & 0xffff0000u);
         }
       }
-      float d = 0.f;
+      d = KVF32 ? smi_sum16(d) : smi_sum8(d);
+      sc[u] = (c0 + u * NGRP + grp < ctx) ? d : NEG;
+      lmax = fmaxf(lmax, sc[u]);
+    }
+    if (dl == 0) smax[grp] = lmax;
+    __syncthreads();
+    float bm = NEG;
 #pragma unroll
-      for (int i = 0; i < DPL; ++i) d += qv[i] * kf[i];
+    for (int i = 0; i < NGRP / 4; ++i) {
+      const float4 v = *(const float4*)&smax[4 * i];
+      bm = fmaxf(bm, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+    }
+    const float mn = fmaxf(m_run, bm);
+    const float a = expf(m_run - mn);
+    lrun *= a;
 #pragma unroll
-      for (int s = 1; s < LPT; s <<= 1) d += __shfl_xor(d, s, 64);
-      if (valid) {
-        const float mn = fmaxf(mrun, d);
-        const float a = expf(mrun - mn), e = expf(d - mn);
-        lrun = lrun * a + e;
+    for (int i = 0; i < DPL; ++i) o[i] *= a;
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) o[i] = o[i] * a + e * vf[i];
-        mrun = mn;
+    for (int u = 0; u < UNR; ++u) {
+      const float e = sc[u] > 0.5f * NEG ? expf(sc[u] - mn) : 0.f;
+      const uint32_t vu[4] = {vr[u].x, vr[u].y, vr[u].z, vr[u].w};
+      lrun += e;
+      if (KVF32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i % DPL] += e * __uint_as_float(vu[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o[(2 * i) % DPL] += e * __uint_as_float(vu[i] << 16);
+          o[(2 * i + 1) % DPL] += e * __uint_as_float(vu[i] & 0xffff0000u);
+        }
       }
     }
+    m_run = mn;
+    if (c0 + NGRP * UNR < ctx) __syncthreads();   // smax is rewritten by the next chunk
   }
-  // merge the token streams inside the wave
+  // every stream is at scale exp(-m_run): plain sums, fixed order
 #pragma unroll
-  for (int s = LPT; s < 64; s <<= 1) {
-    const float m2 = __shfl_xor(mrun, s, 64), l2 = __shfl_xor(lrun, s, 64);
-    const float mn = fmaxf(mrun, m2);
-    const float a1 = expf(mrun - mn), a2 = expf(m2 - mn);
-    lrun = lrun * a1 + l2 * a2;
-#pragma unroll
-    for (int i = 0; i < DPL; ++i) {
-      const float o2 = __shfl_xor(o[i], s, 64);
-      o[i] = o[i] * a1 + o2 * a2;
-    }
-    mrun = mn;
-  }
-  if (tl == 0) {
-    if (dl == 0) { wm[wave] = mrun; wl[wave] = lrun; }
-#pragma unroll
-    for (int i = 0; i < DPL; ++i) wo[wave][dl * DPL + i] = o[i];
+  for (int i = 0; i < DPL; i += 4)
+    *(float4*)&so[grp][dl * DPL + i] = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
+  if (dl == 0) sl[grp] = lrun;
+  __syncthreads();
+  if (tid < 256) {
+    const int d = tid & 63, qd = tid >> 6;
+    float O = 0.f, Ls = 0.f;
+#pragma unroll 8
+    for (int g = qd * (NGRP / 4); g < (qd + 1) * (NGRP / 4); ++g) { O += so[g][d]; Ls += sl[g]; }
+    so2[qd][d] = O;
+    if (d == 0) sl2[qd] = Ls;
   }
   __syncthreads();
   if (tid < kHeadDim) {
-    float mn = wm[0];
-#pragma unroll
-    for (int w = 1; w < kAttnWaves; ++w) mn = fmaxf(mn, wm[w]);
-    float L = 0.f, O = 0.f;
-#pragma unroll
-    for (int w = 0; w < kAttnWaves; ++w) {
-      const float a = expf(wm[w] - mn);
-      L += wl[w] * a;
-      O += wo[w][tid] * a;
-    }
-    p.out[(size_t)m * p.q_dim + head * kHeadDim + tid] = O / L;
+    const float O = (so2[0][tid] + so2[1][tid]) + (so2[2][tid] + so2[3][tid]);
+    const float Ls = (sl2[0] + sl2[1]) + (sl2[2] + sl2[3]);
+    p.out[(size_t)m * p.q_dim + head * kHeadDim + tid] = O / Ls;
   }
 }
 
@@ -654,10 +710,25 @@ __global__ __launch_bounds__(256) void k_finalize(FinP p) {
   for (int m = 0; m < p.M; ++m) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = tid; i < (p.tok ? 0 : p.nblk); i += 256) {
-      const float v = p.pval[(size_t)i * 32 + m];
-      const int ix = p.pidx[(size_t)i * 32 + m];
-      if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+    if (!p.tok) {
+      constexpr int NP = 16;   // all partial loads in flight together (one memory round trip)
+      float pv[NP];
+      int pi[NP];
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int i = tid + 256 * j;
+        const bool in = i < p.nblk;
+        pv[j] = in ? p.pval[(size_t)i * 32 + m] : -INFINITY;
+        pi[j] = in ? p.pidx[(size_t)i * 32 + m] : 0x7fffffff;
+      }
+#pragma unroll
+      for (int j = 0; j < NP; ++j)
+        if (pv[j] > bv || (pv[j] == bv && pi[j] < bi)) { bv = pv[j]; bi = pi[j]; }
+      for (int i = tid + 256 * NP; i < p.nblk; i += 256) {
+        const float v = p.pval[(size_t)i * 32 + m];
+        const int ix = p.pidx[(size_t)i * 32 + m];
+        if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -770,28 +841,41 @@ struct smi_llm {
 
 namespace {
 
-template <int MT, int NTB, int NW, int U, int PRO, int EPI>
-int launch_gemm_kv(const smi_llm* L, const GemmP& p, hipStream_t st) {
-  const int grid = (p.NT + NTB - 1) / NTB;
+template <int MT, int NTB, int NW, int U, int PRO, int EPI, bool PF, bool ACC3>
+int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
+  const int work = (p.NT + NTB - 1) / NTB;
+  p.work_blocks = work;
+  // helper blocks on the CUs this grid leaves idle pull a later kernel's weights into the Infinity Cache
+  const int helpers = (p.pf_ptr && p.pf_bytes && work < 224) ? 256 - work : 0;
   const int xs_bytes = p.KC * 192 * p.M;
   const int red_bytes = NW * NTB * MT * 1024;
   const size_t lds = (size_t)(xs_bytes > red_bytes ? xs_bytes : red_bytes) + 32 * 4 + NTB * 32 * 8;
-  if (L->cfg.kv_dtype)
-    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, PRO, EPI, 1>), dim3(grid), dim3(NW * 64), lds, st, p);
-  else
-    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, PRO, EPI, 0>), dim3(grid), dim3(NW * 64), lds, st, p);
+  SMI_REQUIRE(lds <= 150 * 1024, "k_gemm needs %zu bytes of LDS", lds);
+  if (L->cfg.kv_dtype) {
+    auto kfn = k_gemm<MT, NTB, NW, U, PRO, EPI, 1, PF, ACC3>;
+    static size_t cap = 64 * 1024;
+    if (lds > cap) { SMI_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); cap = 150 * 1024; }
+    hipLaunchKernelGGL(kfn, dim3(work + helpers), dim3(NW * 64), lds, st, p);
+  } else {
+    auto kfn = k_gemm<MT, NTB, NW, U, PRO, EPI, 0, PF, ACC3>;
+    static size_t cap = 64 * 1024;
+    if (lds > cap) { SMI_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); cap = 150 * 1024; }
+    hipLaunchKernelGGL(kfn, dim3(work + helpers), dim3(NW * 64), lds, st, p);
+  }
   SMI_LAUNCH_CHECK();
   return SMI_OK;
 }
 
-template <int NTB, int NW, int U, int PRO, int EPI>
+template <int NTB, int NW, int U, int PRO, int EPI, bool PF, bool ACC3>
 int launch_gemm(const smi_llm* L, GemmP p, hipStream_t st) {
-  // LDS chunking: activation splits cost 192 bytes per (row, k tile); keep them under 56 KiB
+  // LDS chunking: activation splits cost 192 bytes per (row, k tile).  The chunk is a multiple of
+  // NW so that k tile kt always belongs to wave kt mod NW (batch-invariant summation order).
   int kc = (56 * 1024) / (192 * p.M);
-  if (kc < 1) kc = 1;
+  kc = kc / NW * NW;
+  if (kc < NW) kc = NW;
   p.KC = kc < p.KT ? kc : p.KT;
-  if (p.M > 16) return launch_gemm_kv<2, NTB, NW, (U > 4 ? 4 : U), PRO, EPI>(L, p, st);
-  return launch_gemm_kv<1, NTB, NW, U, PRO, EPI>(L, p, st);
+  if (p.M > 16) return launch_gemm_kv<2, NTB, NW, (U > 4 ? 4 : U), PRO, EPI, PF, ACC3>(L, p, st);
+  return launch_gemm_kv<1, NTB, NW, U, PRO, EPI, PF, ACC3>(L, p, st);
 }
 
 const unsigned char* sec(const smi_llm* L, int s, int layer) {
@@ -820,35 +904,43 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       p.rope = (const float2*)sec(L, SMI_LLM_ROPE, 0);
       p.kcache = kv_layer(L, L->kcache, layer); p.vcache = kv_layer(L, L->vcache, layer);
       p.q_dim = L->Q; p.kv_dim = L->KV; p.n_kv = c.num_kv_heads; p.max_pos = c.max_positions;
-      return launch_gemm<1, 4, 8, PRO_NORM, EPI_QKV>(L, p, st);
+      p.pf_ptr = sec(L, SMI_LLM_WGU, layer); p.pf_bytes = L->lay.bytes[SMI_LLM_WGU];
+      return launch_gemm<1, 4, 8, PRO_NORM, EPI_QKV, true, true>(L, p, st);
     case KATTN: {
       AttnP a;
       a.q = L->qbuf; a.kcache = kv_layer(L, L->kcache, layer); a.vcache = kv_layer(L, L->vcache, layer);
       a.rows = rows; a.out = L->attn; a.q_dim = L->Q; a.n_kv = c.num_kv_heads;
-      a.group = c.num_heads / c.num_kv_heads; a.max_pos = c.max_positions;
-      if (c.kv_dtype) hipLaunchKernelGGL(k_attn<1>, dim3(c.num_heads, M), dim3(kAttnWaves * 64), 0, st, a);
-      else hipLaunchKernelGGL(k_attn<0>, dim3(c.num_heads, M), dim3(kAttnWaves * 64), 0, st, a);
+      a.group = c.num_heads / c.num_kv_heads; a.max_pos = c.max_positions; a.n_heads = c.num_heads;
+      a.work_blocks = c.num_heads * M;
+      a.pf_ptr = sec(L, SMI_LLM_WD, layer); a.pf_bytes = L->lay.bytes[SMI_LLM_WD];
+      const int helpers = a.work_blocks < 224 ? 256 - a.work_blocks : 0;
+      if (c.kv_dtype) hipLaunchKernelGGL(k_attn<1>, dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
+      else hipLaunchKernelGGL(k_attn<0>, dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
       SMI_LAUNCH_CHECK();
       return SMI_OK;
     }
     case KO:
       p.W = (const uint4*)sec(L, SMI_LLM_WO, layer); p.NT = L->NTh; p.KT = L->KTq;
       p.X = L->attn; p.Y = L->h;
-      return launch_gemm<1, 4, 8, PRO_PLAIN, EPI_RESID>(L, p, st);
+      if (layer + 1 < c.num_layers) {   // next layer's QKV .. O weights are contiguous in the arena
+        p.pf_ptr = sec(L, SMI_LLM_WQKV, layer + 1);
+        p.pf_bytes = (size_t)(sec(L, SMI_LLM_WO, layer + 1) - sec(L, SMI_LLM_WQKV, layer + 1)) + L->lay.bytes[SMI_LLM_WO];
+      }
+      return launch_gemm<1, 4, 8, PRO_PLAIN, EPI_RESID, true, true>(L, p, st);
     case KGU:
       p.W = (const uint4*)sec(L, SMI_LLM_WGU, layer); p.NT = L->NTgu; p.KT = L->KTh;
       p.X = L->h; p.gamma = (const float*)sec(L, SMI_LLM_LN2, layer); p.Y = L->act;
-      return launch_gemm<2, 4, 8, PRO_NORM, EPI_SWIGLU>(L, p, st);
+      return launch_gemm<2, 4, 8, PRO_NORM, EPI_SWIGLU, true, true>(L, p, st);
     case KD:
       p.W = (const uint4*)sec(L, SMI_LLM_WD, layer); p.NT = L->NTh; p.KT = L->KTi;
       p.X = L->act; p.Y = L->h;
-      return launch_gemm<1, 16, 5, PRO_PLAIN, EPI_RESID>(L, p, st);
+      return launch_gemm<1, 16, 5, PRO_PLAIN, EPI_RESID, true, true>(L, p, st);
     case KLM:
       p.W = (const uint4*)sec(L, SMI_LLM_LM_HEAD, 0); p.NT = L->NTlm; p.KT = L->KTh;
       p.X = L->h; p.gamma = (const float*)sec(L, SMI_LLM_FINAL_NORM, 0);
       p.Y = logits ? logits : (L->do_sample ? L->logits : nullptr);
       p.V = c.vocab_size; p.pval = L->pval; p.pidx = L->pidx;
-      return launch_gemm<4, 4, 4, PRO_NORM, EPI_LM>(L, p, st);
+      return launch_gemm<4, 4, 4, PRO_NORM, EPI_LM, false, false>(L, p, st);
     case KFIN: {
       FinP f;
       f.tok = nullptr;
