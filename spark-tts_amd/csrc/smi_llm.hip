@@ -98,6 +98,7 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
   const int nt0 = blockIdx.x * NTB;
 #define SMI_STAMP(i) do { if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   SMI_STAMP(0);
+  const unsigned long long c_entry = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
   // LDS map: [0, xs_bytes) activation splits (later aliased by the split-K reduction slab),
   // then rstd[32] floats, then argmax scratch.
   const int xs_bytes = p.KC * 192 * M;
@@ -113,8 +114,36 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
   constexpr int MAXO = 2;                 // octets per lane in the one-pass norm prologue => K <= 1024
   const bool onepass = single && (PRO == PRO_PLAIN || (K >> 3) <= 64 * MAXO);
 
-  // (1) The weights do not depend on the activations: put the first batch of tiles in flight
-  //     before touching anything else, so their latency overlaps the prologue.
+  // (1) Loads return in issue order, so the (short, critical-path) activation loads go first and
+  //     the first batch of weight tiles right behind them: the weights' HBM latency then overlaps
+  //     the prologue arithmetic instead of preceding it.
+  const int KO = K >> 3;
+  float xv[MAXO][8], xg[MAXO][8];          // PRO_NORM: this wave's first row (+ norm weight)
+  float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;   // PRO_PLAIN: this thread's first unit
+  const int octs_all = KT * 4;
+  if (onepass) {
+    if (PRO == PRO_NORM) {
+      if (wave < M) {
+#pragma unroll
+        for (int i = 0; i < MAXO; ++i) {
+          const int o = lane + 64 * i;
+          if (o < KO) {
+            const float4* src = (const float4*)(p.X + (size_t)wave * K + o * 8);
+            const float4* gp = (const float4*)(p.gamma + o * 8);
+            const float4 a = src[0], b = src[1], g0 = gp[0], g1 = gp[1];
+            xv[i][0] = a.x; xv[i][1] = a.y; xv[i][2] = a.z; xv[i][3] = a.w;
+            xv[i][4] = b.x; xv[i][5] = b.y; xv[i][6] = b.z; xv[i][7] = b.w;
+            xg[i][0] = g0.x; xg[i][1] = g0.y; xg[i][2] = g0.z; xg[i][3] = g0.w;
+            xg[i][4] = g1.x; xg[i][5] = g1.y; xg[i][6] = g1.z; xg[i][7] = g1.w;
+          }
+        }
+      }
+    } else if (tid < M * octs_all) {
+      const int m = tid / octs_all, o = tid - m * octs_all;
+      const float4* src = (const float4*)(p.X + (size_t)m * K + o * 8);
+      pa = src[0]; pb = src[1];
+    }
+  }
   uint4 w[U][NTB];
   const int kcn0 = KT < p.KC ? KT : p.KC;
   auto load_batch = [&](int kc0, int kcn, int j0) {
@@ -151,45 +180,48 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
   // (2) prologue
   if (onepass) {
     if (PRO == PRO_NORM) {
-      // one pass: wave w owns rows w, w+NW, ..: load the row once, reduce, scale, split, store
-      const int KO = K >> 3;
+      // wave w owns rows w, w+NW, ..: one pass per row -- reduce, scale, split, store
       for (int m = wave; m < M; m += NW) {
-        float v[MAXO][8], g[MAXO][8];
-        float ss = 0.f;
+        if (m != wave) {
 #pragma unroll
-        for (int i = 0; i < MAXO; ++i) {
-          const int o = lane + 64 * i;
-          if (o < KO) {
-            const float4* src = (const float4*)(p.X + (size_t)m * K + o * 8);
-            const float4* gp = (const float4*)(p.gamma + o * 8);
-            const float4 a = src[0], b = src[1], g0 = gp[0], g1 = gp[1];
-            v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w;
-            v[i][4] = b.x; v[i][5] = b.y; v[i][6] = b.z; v[i][7] = b.w;
-            g[i][0] = g0.x; g[i][1] = g0.y; g[i][2] = g0.z; g[i][3] = g0.w;
-            g[i][4] = g1.x; g[i][5] = g1.y; g[i][6] = g1.z; g[i][7] = g1.w;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
+          for (int i = 0; i < MAXO; ++i) {
+            const int o = lane + 64 * i;
+            if (o < KO) {
+              const float4* src = (const float4*)(p.X + (size_t)m * K + o * 8);
+              const float4 a = src[0], b = src[1];
+              xv[i][0] = a.x; xv[i][1] = a.y; xv[i][2] = a.z; xv[i][3] = a.w;
+              xv[i][4] = b.x; xv[i][5] = b.y; xv[i][6] = b.z; xv[i][7] = b.w;
+            }
           }
         }
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXO; ++i)
+          if (lane + 64 * i < KO) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += xv[i][e] * xv[i][e];
+          }
         ss = smi_wave_sum(ss);
         const float r = 1.0f / sqrtf(ss / (float)K + p.eps);
 #pragma unroll
         for (int i = 0; i < MAXO; ++i) {
           const int o = lane + 64 * i;
           if (o < KO) {
+            float t[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[i][e] = g[i][e] * (v[i][e] * r);  // weight * (x * rsqrt(var+eps)), MQ:251-252
-            split_store(v[i], xs + (((o >> 2) * 3) * 4 + (o & 3)) * mslot_bytes + m * 16, plane);
+            for (int e = 0; e < 8; ++e) t[e] = xg[i][e] * (xv[i][e] * r);  // weight * (x * rsqrt(var+eps)), MQ:251-252
+            split_store(t, xs + (((o >> 2) * 3) * 4 + (o & 3)) * mslot_bytes + m * 16, plane);
           }
         }
       }
     } else {
-      const int octs = KT * 4;
-      for (int u = tid; u < M * octs; u += NW * 64) {
-        const int m = u / octs, o = u - m * octs;
-        const float4* src = (const float4*)(p.X + (size_t)m * K + o * 8);
-        const float4 a = src[0], b = src[1];
-        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      for (int u = tid; u < M * octs_all; u += NW * 64) {
+        const int m = u / octs_all, o = u - m * octs_all;
+        if (u != tid) {
+          const float4* src = (const float4*)(p.X + (size_t)m * K + o * 8);
+          pa = src[0]; pb = src[1];
+        }
+        const float v[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
         split_store(v, xs + (((o >> 2) * 3) * 4 + (o & 3)) * mslot_bytes + m * 16, plane);
       }
     }
@@ -386,6 +418,7 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
     }
   }
   SMI_STAMP(6);
+  if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - c_entry;   // shader cycles in-kernel
   if (EPI == EPI_LM) {
     __syncthreads();
     if (tid < M) {
@@ -397,8 +430,8 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
         int oi = besti[nb * 32 + tid];
         if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
       }
-      p.pval[(size_t)blockIdx.x * 32 + tid] = bv;
-      p.pidx[(size_t)blockIdx.x * 32 + tid] = bi;
+      p.pval[(size_t)tid * p.work_blocks + blockIdx.x] = bv;   // [row][block]: finalize reads a row contiguously
+      p.pidx[(size_t)tid * p.work_blocks + blockIdx.x] = bi;
     }
   }
 }
@@ -718,15 +751,15 @@ __global__ __launch_bounds__(256) void k_finalize(FinP p) {
       for (int j = 0; j < NP; ++j) {
         const int i = tid + 256 * j;
         const bool in = i < p.nblk;
-        pv[j] = in ? p.pval[(size_t)i * 32 + m] : -INFINITY;
-        pi[j] = in ? p.pidx[(size_t)i * 32 + m] : 0x7fffffff;
+        pv[j] = in ? p.pval[(size_t)m * p.nblk + i] : -INFINITY;
+        pi[j] = in ? p.pidx[(size_t)m * p.nblk + i] : 0x7fffffff;
       }
 #pragma unroll
       for (int j = 0; j < NP; ++j)
         if (pv[j] > bv || (pv[j] == bv && pi[j] < bi)) { bv = pv[j]; bi = pi[j]; }
       for (int i = tid + 256 * NP; i < p.nblk; i += 256) {
-        const float v = p.pval[(size_t)i * 32 + m];
-        const int ix = p.pidx[(size_t)i * 32 + m];
+        const float v = p.pval[(size_t)m * p.nblk + i];
+        const int ix = p.pidx[(size_t)m * p.nblk + i];
         if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
       }
     }
@@ -755,10 +788,17 @@ __global__ __launch_bounds__(256) void k_finalize(FinP p) {
     }
     __syncthreads();
   }
-  const int K = p.KT * 32;
-  for (int i = tid; i < p.M * K; i += 256) {
-    const int m = i / K, k = i - m * K;
-    p.h[i] = lm_elem(p.Wlm, p.KT, tok_s[m], k);
+  // next step's embedding rows: one 16-byte piece (8 bf16) per thread-iteration
+  const int K = p.KT * 32, pieces = p.KT * 4;
+  for (int i = tid; i < p.M * pieces; i += 256) {
+    const int m = i / pieces, pc = i - m * pieces;       // pc = k / 8
+    const int n = tok_s[m];
+    const size_t tile = (size_t)(n >> 4) * p.KT + (pc >> 2);
+    const uint4 v = *(const uint4*)(p.Wlm + tile * 512 + ((pc & 3) * 16 + (n & 15)) * 8);
+    const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+    float* dst = p.h + (size_t)m * K + pc * 8;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dst[2 * e] = __uint_as_float(u[e] << 16); dst[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); }
   }
   if (tid == 0) *p.step = step + 1;
 }
@@ -832,6 +872,7 @@ struct smi_llm {
   int do_sample, top_k; float temperature, top_p; unsigned long long seed;
   float* logits; int* tok;
   unsigned long long* stamps; int stamps_on;
+  int prefetch;   // helper blocks warm the Infinity Cache for later kernels (measured: net loss; off unless SPARKMI_PREFETCH=1)
   int max_steps;
   hipGraphExec_t graph; int graph_B;
   hipEvent_t ev0, ev1;
@@ -846,7 +887,7 @@ int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
   const int work = (p.NT + NTB - 1) / NTB;
   p.work_blocks = work;
   // helper blocks on the CUs this grid leaves idle pull a later kernel's weights into the Infinity Cache
-  const int helpers = (p.pf_ptr && p.pf_bytes && work < 224) ? 256 - work : 0;
+  const int helpers = (L->prefetch && p.pf_ptr && p.pf_bytes && work < 224) ? 256 - work : 0;
   const int xs_bytes = p.KC * 192 * p.M;
   const int red_bytes = NW * NTB * MT * 1024;
   const size_t lds = (size_t)(xs_bytes > red_bytes ? xs_bytes : red_bytes) + 32 * 4 + NTB * 32 * 8;
@@ -913,7 +954,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       a.group = c.num_heads / c.num_kv_heads; a.max_pos = c.max_positions; a.n_heads = c.num_heads;
       a.work_blocks = c.num_heads * M;
       a.pf_ptr = sec(L, SMI_LLM_WD, layer); a.pf_bytes = L->lay.bytes[SMI_LLM_WD];
-      const int helpers = a.work_blocks < 224 ? 256 - a.work_blocks : 0;
+      const int helpers = (L->prefetch && a.work_blocks < 224) ? 256 - a.work_blocks : 0;
       if (c.kv_dtype) hipLaunchKernelGGL(k_attn<1>, dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
       else hipLaunchKernelGGL(k_attn<0>, dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
       SMI_LAUNCH_CHECK();
@@ -1047,6 +1088,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->lm_blocks = (L->NTlm + 3) / 4;
   L->max_steps = cfg->max_positions;
   L->do_sample = 0; L->top_k = 50; L->temperature = 0.8f; L->top_p = 0.95f; L->seed = 0; L->logits = nullptr; L->tok = nullptr; L->stamps = nullptr; L->stamps_on = 0;
+  { const char* e = getenv("SPARKMI_PREFETCH"); L->prefetch = e && e[0] == '1'; }
   L->graph = nullptr; L->graph_B = 0; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->eos = -1;
   const size_t esz = cfg->kv_dtype ? 4 : 2;
   L->kv_layer_elems = (size_t)cfg->max_slots * cfg->num_kv_heads * cfg->max_positions * kHeadDim;
@@ -1290,7 +1332,9 @@ int smi_llm_debug_stamps(smi_llm* L, int kernel, int layer, double* out) {
     for (int b = 0; b < nblk; ++b) s += (double)(h[(size_t)b * 8 + i] - t0);
     out[i] = s / nblk * 0.01;   // microseconds
   }
-  out[7] = nblk;
+  double cyc = 0, us = 0;   // shader clock during the kernel: cycles / (stamp6 - stamp0)
+  for (int b = 0; b < nblk; ++b) { cyc += (double)h[(size_t)b * 8 + 7]; us += (double)(h[(size_t)b * 8 + 6] - h[(size_t)b * 8]) * 0.01; }
+  out[7] = us > 0 ? cyc / us : 0;   // MHz
   return SMI_OK;
 }
 

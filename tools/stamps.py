@@ -21,7 +21,7 @@ for kname, kid in [("qkv", 0), ("o_proj", 2), ("gate_up", 3), ("down", 4), ("lm_
         assert f(llm._h, kid, layer, out) == 0, llm._lib.smi_last_error()
         acc += np.array(list(out))
     acc /= 8
-    print(f"{kname:8s} blocks {int(acc[7]):5d} | " + " | ".join(f"{n} {acc[i]:.2f}" for i, n in enumerate(names)))
+    print(f"{kname:8s} clock {acc[7]:6.0f} MHz | " + " | ".join(f"{n} {acc[i]:.2f}" for i, n in enumerate(names)))
     for name in ("qkv", "attn", "o_proj", "gate_up", "down", "lm_head"):
         pass
 for name in ("qkv", "attn", "o_proj", "gate_up", "down", "lm_head", "finalize", "step"):
