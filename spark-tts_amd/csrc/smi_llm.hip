@@ -113,6 +113,10 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
   const bool single = p.KC >= KT;         // the whole K fits in LDS at once (small M)
   constexpr int MAXO = 2;                 // octets per lane in the one-pass norm prologue => K <= 1024
   const bool onepass = single && (PRO == PRO_PLAIN || (K >> 3) <= 64 * MAXO);
+  // few rows: every wave builds the operand pieces of its OWN k tiles (kt mod NW == wave), so no
+  // block barrier separates the prologue from the MFMA loop
+  const bool wpriv = onepass && M <= 4;
+  const int row0 = wpriv ? 0 : wave, rstep = wpriv ? 1 : NW;
 
   // (1) Loads return in issue order, so the (short, critical-path) activation loads go first and
   //     the first batch of weight tiles right behind them: the weights' HBM latency then overlaps
@@ -123,12 +127,12 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
   const int octs_all = KT * 4;
   if (onepass) {
     if (PRO == PRO_NORM) {
-      if (wave < M) {
+      if (row0 < M) {
 #pragma unroll
         for (int i = 0; i < MAXO; ++i) {
           const int o = lane + 64 * i;
           if (o < KO) {
-            const float4* src = (const float4*)(p.X + (size_t)wave * K + o * 8);
+            const float4* src = (const float4*)(p.X + (size_t)row0 * K + o * 8);
             const float4* gp = (const float4*)(p.gamma + o * 8);
             const float4 a = src[0], b = src[1], g0 = gp[0], g1 = gp[1];
             xv[i][0] = a.x; xv[i][1] = a.y; xv[i][2] = a.z; xv[i][3] = a.w;
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
           }
         }
       }
-    } else if (tid < M * octs_all) {
+    } else if (!wpriv && tid < M * octs_all) {
       const int m = tid / octs_all, o = tid - m * octs_all;
       const float4* src = (const float4*)(p.X + (size_t)m * K + o * 8);
       pa = src[0]; pb = src[1];
@@ -181,8 +185,8 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
   if (onepass) {
     if (PRO == PRO_NORM) {
       // wave w owns rows w, w+NW, ..: one pass per row -- reduce, scale, split, store
-      for (int m = wave; m < M; m += NW) {
-        if (m != wave) {
+      for (int m = row0; m < M; m += rstep) {
+        if (m != row0) {
 #pragma unroll
           for (int i = 0; i < MAXO; ++i) {
             const int o = lane + 64 * i;
@@ -206,13 +210,24 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
 #pragma unroll
         for (int i = 0; i < MAXO; ++i) {
           const int o = lane + 64 * i;
-          if (o < KO) {
+          if (o < KO && (!wpriv || ((o >> 2) % NW) == wave)) {
             float t[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) t[e] = xg[i][e] * (xv[i][e] * r);  // weight * (x * rsqrt(var+eps)), MQ:251-252
             split_store(t, xs + (((o >> 2) * 3) * 4 + (o & 3)) * mslot_bytes + m * 16, plane);
           }
         }
+      }
+    } else if (wpriv) {
+      // this wave's k tiles are wave, wave+NW, ..: 4 octets each
+      const int mine = ((KT - wave + NW - 1) / NW) * 4;
+      for (int u = lane; u < M * mine; u += 64) {
+        const int m = u / mine, i = u - m * mine;
+        const int o = (wave + (i >> 2) * NW) * 4 + (i & 3);
+        const float4* src = (const float4*)(p.X + (size_t)m * K + o * 8);
+        const float4 a = src[0], b = src[1];
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        split_store(v, xs + (((o >> 2) * 3) * 4 + (o & 3)) * mslot_bytes + m * 16, plane);
       }
     } else {
       for (int u = tid; u < M * octs_all; u += NW * 64) {
@@ -272,7 +287,8 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
         split_store(v, xs + (((o >> 2) * 3) * 4 + (o & 3)) * mslot_bytes + m * 16, plane);
       }
     }
-    __syncthreads();
+    if (wpriv) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own LDS writes landed; no other wave's are read
+    else __syncthreads();
     SMI_STAMP(3);
     // ---- stream weight tiles; wave w owns the k tiles with (kt mod NW) == w (KC is a multiple of NW)
     const int k8 = lane >> 4;
