@@ -85,7 +85,7 @@ __device__ __forceinline__ void split_store(const float (&v)[8], unsigned char* 
 // accumulator chain per bf16 split term (3x shorter dependent MFMA chains), summed (lo+mid)+hi.
 // The k-tile -> wave map (kt mod NW), the chain structure and the reduction order do not depend on
 // M, so a row's result is bit-identical whatever else is in the batch.
-template <int MT, int NTB, int NW, int U, int PRO, int EPI, int KVF32, bool PF, bool ACC3>
+template <int MT, int NTB, int NW, int U, int PRO, int EPI, int KVF32, bool PF, bool ACC3, bool XFIRST, bool EPRE>
 __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k_gemm(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -113,10 +113,8 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
   const bool single = p.KC >= KT;         // the whole K fits in LDS at once (small M)
   constexpr int MAXO = 2;                 // octets per lane in the one-pass norm prologue => K <= 1024
   const bool onepass = single && (PRO == PRO_PLAIN || (K >> 3) <= 64 * MAXO);
-  // few rows: every wave builds the operand pieces of its OWN k tiles (kt mod NW == wave), so no
-  // block barrier separates the prologue from the MFMA loop
-  const bool wpriv = onepass && M <= 4;
-  const int row0 = wpriv ? 0 : wave, rstep = wpriv ? 1 : NW;
+  constexpr bool wpriv = false;   // wave-private staging (every wave re-reading the row) measured slower: kept off
+  const int row0 = wave, rstep = NW;
 
   // (1) Loads return in issue order, so the (short, critical-path) activation loads go first and
   //     the first batch of weight tiles right behind them: the weights' HBM latency then overlaps
@@ -125,7 +123,7 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
   float xv[MAXO][8], xg[MAXO][8];          // PRO_NORM: this wave's first row (+ norm weight)
   float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;   // PRO_PLAIN: this thread's first unit
   const int octs_all = KT * 4;
-  if (onepass) {
+  if (onepass && XFIRST) {
     if (PRO == PRO_NORM) {
       if (row0 < M) {
 #pragma unroll
@@ -168,7 +166,7 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
   const int em = lane & 15;                 // this lane's row inside an m-tile
   RowDesc erd[MT];
   float4 epre[MT];
-  if (wave < NTB && nt0 + wave < NT) {
+  if (EPRE && wave < NTB && nt0 + wave < NT) {
     const int n = (nt0 + wave) * 16 + 4 * (lane >> 4);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -186,7 +184,7 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
     if (PRO == PRO_NORM) {
       // wave w owns rows w, w+NW, ..: one pass per row -- reduce, scale, split, store
       for (int m = row0; m < M; m += rstep) {
-        if (m != row0) {
+        if (!XFIRST || m != row0) {
 #pragma unroll
           for (int i = 0; i < MAXO; ++i) {
             const int o = lane + 64 * i;
@@ -195,6 +193,12 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
               const float4 a = src[0], b = src[1];
               xv[i][0] = a.x; xv[i][1] = a.y; xv[i][2] = a.z; xv[i][3] = a.w;
               xv[i][4] = b.x; xv[i][5] = b.y; xv[i][6] = b.z; xv[i][7] = b.w;
+              if (!XFIRST && m == row0) {
+                const float4* gp = (const float4*)(p.gamma + o * 8);
+                const float4 g0 = gp[0], g1 = gp[1];
+                xg[i][0] = g0.x; xg[i][1] = g0.y; xg[i][2] = g0.z; xg[i][3] = g0.w;
+                xg[i][4] = g1.x; xg[i][5] = g1.y; xg[i][6] = g1.z; xg[i][7] = g1.w;
+              }
             }
           }
         }
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
     } else {
       for (int u = tid; u < M * octs_all; u += NW * 64) {
         const int m = u / octs_all, o = u - m * octs_all;
-        if (u != tid) {
+        if (!XFIRST || u != tid) {
           const float4* src = (const float4*)(p.X + (size_t)m * K + o * 8);
           pa = src[0]; pb = src[1];
         }
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
       const bool valid = m < M;
       if (EPI == EPI_RESID) {
         if (valid) {
-          float4 h = epre[mt];   // fetched at kernel entry (only this lane ever writes it)
+          float4 h = EPRE ? epre[mt] : *(const float4*)(p.Y + (size_t)m * N + n);   // EPRE: fetched at kernel entry
           h.x += s.x; h.y += s.y; h.z += s.z; h.w += s.w;
           *(float4*)(p.Y + (size_t)m * N + n) = h;
         }
@@ -376,9 +380,9 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
         }
       } else if (EPI == EPI_QKV) {
         if (valid) {
-          const float4 b = epre[mt];
+          const float4 b = EPRE ? epre[mt] : *(const float4*)(p.bias + n);
           s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
-          const RowDesc rd = erd[mt];
+          const RowDesc rd = EPRE ? erd[mt] : p.rows[m];
           if (n < p.q_dim + p.kv_dim) {
             // rows inside a head are ordered (0,32,1,33,..): (s.x,s.y) and (s.z,s.w) are RoPE pairs
             const int i0 = (n & 63) >> 1;
@@ -888,6 +892,7 @@ struct smi_llm {
   int do_sample, top_k; float temperature, top_p; unsigned long long seed;
   float* logits; int* tok;
   unsigned long long* stamps; int stamps_on;
+  int variant;    // diagnostics (SPARKMI_VARIANT)
   int prefetch;   // helper blocks warm the Infinity Cache for later kernels (measured: net loss; off unless SPARKMI_PREFETCH=1)
   int max_steps;
   hipGraphExec_t graph; int graph_B;
@@ -898,7 +903,7 @@ struct smi_llm {
 
 namespace {
 
-template <int MT, int NTB, int NW, int U, int PRO, int EPI, bool PF, bool ACC3>
+template <int MT, int NTB, int NW, int U, int PRO, int EPI, bool PF, bool ACC3, bool XFIRST, bool EPRE>
 int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
   const int work = (p.NT + NTB - 1) / NTB;
   p.work_blocks = work;
@@ -909,12 +914,12 @@ int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
   const size_t lds = (size_t)(xs_bytes > red_bytes ? xs_bytes : red_bytes) + 32 * 4 + NTB * 32 * 8;
   SMI_REQUIRE(lds <= 150 * 1024, "k_gemm needs %zu bytes of LDS", lds);
   if (L->cfg.kv_dtype) {
-    auto kfn = k_gemm<MT, NTB, NW, U, PRO, EPI, 1, PF, ACC3>;
+    auto kfn = k_gemm<MT, NTB, NW, U, PRO, EPI, 1, PF, ACC3, XFIRST, EPRE>;
     static size_t cap = 64 * 1024;
     if (lds > cap) { SMI_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); cap = 150 * 1024; }
     hipLaunchKernelGGL(kfn, dim3(work + helpers), dim3(NW * 64), lds, st, p);
   } else {
-    auto kfn = k_gemm<MT, NTB, NW, U, PRO, EPI, 0, PF, ACC3>;
+    auto kfn = k_gemm<MT, NTB, NW, U, PRO, EPI, 0, PF, ACC3, XFIRST, EPRE>;
     static size_t cap = 64 * 1024;
     if (lds > cap) { SMI_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); cap = 150 * 1024; }
     hipLaunchKernelGGL(kfn, dim3(work + helpers), dim3(NW * 64), lds, st, p);
@@ -923,6 +928,7 @@ int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
   return SMI_OK;
 }
 
+// PF / ACC3 must not depend on M (bit-identical rows across batch sizes); XFIRST / EPRE only move loads.
 template <int NTB, int NW, int U, int PRO, int EPI, bool PF, bool ACC3>
 int launch_gemm(const smi_llm* L, GemmP p, hipStream_t st) {
   // LDS chunking: activation splits cost 192 bytes per (row, k tile).  The chunk is a multiple of
@@ -931,8 +937,13 @@ int launch_gemm(const smi_llm* L, GemmP p, hipStream_t st) {
   kc = kc / NW * NW;
   if (kc < NW) kc = NW;
   p.KC = kc < p.KT ? kc : p.KT;
-  if (p.M > 16) return launch_gemm_kv<2, NTB, NW, (U > 4 ? 4 : U), PRO, EPI, PF, ACC3>(L, p, st);
-  return launch_gemm_kv<1, NTB, NW, U, PRO, EPI, PF, ACC3>(L, p, st);
+  if (p.M > 16) return launch_gemm_kv<2, NTB, NW, (U > 4 ? 4 : U), PRO, EPI, PF, ACC3, false, false>(L, p, st);
+  switch (L->variant & 3) {   // diagnostics: SPARKMI_VARIANT bit0 = activation loads first, bit1 = early epilogue operands
+    case 1: return launch_gemm_kv<1, NTB, NW, U, PRO, EPI, PF, ACC3, true, false>(L, p, st);
+    case 2: return launch_gemm_kv<1, NTB, NW, U, PRO, EPI, PF, ACC3, false, true>(L, p, st);
+    case 3: return launch_gemm_kv<1, NTB, NW, U, PRO, EPI, PF, ACC3, true, true>(L, p, st);
+    default: return launch_gemm_kv<1, NTB, NW, U, PRO, EPI, PF, ACC3, false, false>(L, p, st);
+  }
 }
 
 const unsigned char* sec(const smi_llm* L, int s, int layer) {
@@ -962,6 +973,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       p.kcache = kv_layer(L, L->kcache, layer); p.vcache = kv_layer(L, L->vcache, layer);
       p.q_dim = L->Q; p.kv_dim = L->KV; p.n_kv = c.num_kv_heads; p.max_pos = c.max_positions;
       p.pf_ptr = sec(L, SMI_LLM_WGU, layer); p.pf_bytes = L->lay.bytes[SMI_LLM_WGU];
+      if (L->variant & 4) return launch_gemm<1, 4, 8, PRO_NORM, EPI_QKV, true, false>(L, p, st);
       return launch_gemm<1, 4, 8, PRO_NORM, EPI_QKV, true, true>(L, p, st);
     case KATTN: {
       AttnP a;
@@ -983,14 +995,17 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
         p.pf_ptr = sec(L, SMI_LLM_WQKV, layer + 1);
         p.pf_bytes = (size_t)(sec(L, SMI_LLM_WO, layer + 1) - sec(L, SMI_LLM_WQKV, layer + 1)) + L->lay.bytes[SMI_LLM_WO];
       }
+      if (L->variant & 4) return launch_gemm<1, 4, 8, PRO_PLAIN, EPI_RESID, true, false>(L, p, st);
       return launch_gemm<1, 4, 8, PRO_PLAIN, EPI_RESID, true, true>(L, p, st);
     case KGU:
       p.W = (const uint4*)sec(L, SMI_LLM_WGU, layer); p.NT = L->NTgu; p.KT = L->KTh;
       p.X = L->h; p.gamma = (const float*)sec(L, SMI_LLM_LN2, layer); p.Y = L->act;
+      if (L->variant & 4) return launch_gemm<2, 4, 8, PRO_NORM, EPI_SWIGLU, true, false>(L, p, st);
       return launch_gemm<2, 4, 8, PRO_NORM, EPI_SWIGLU, true, true>(L, p, st);
     case KD:
       p.W = (const uint4*)sec(L, SMI_LLM_WD, layer); p.NT = L->NTh; p.KT = L->KTi;
       p.X = L->act; p.Y = L->h;
+      if (L->variant & 4) return launch_gemm<1, 16, 5, PRO_PLAIN, EPI_RESID, true, false>(L, p, st);
       return launch_gemm<1, 16, 5, PRO_PLAIN, EPI_RESID, true, true>(L, p, st);
     case KLM:
       p.W = (const uint4*)sec(L, SMI_LLM_LM_HEAD, 0); p.NT = L->NTlm; p.KT = L->KTh;
@@ -1105,6 +1120,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->max_steps = cfg->max_positions;
   L->do_sample = 0; L->top_k = 50; L->temperature = 0.8f; L->top_p = 0.95f; L->seed = 0; L->logits = nullptr; L->tok = nullptr; L->stamps = nullptr; L->stamps_on = 0;
   { const char* e = getenv("SPARKMI_PREFETCH"); L->prefetch = e && e[0] == '1'; }
+  { const char* e = getenv("SPARKMI_VARIANT"); L->variant = e ? atoi(e) : 0; }
   L->graph = nullptr; L->graph_B = 0; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->eos = -1;
   const size_t esz = cfg->kv_dtype ? 4 : 2;
   L->kv_layer_elems = (size_t)cfg->max_slots * cfg->num_kv_heads * cfg->max_positions * kHeadDim;

@@ -10,7 +10,7 @@ import os
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libsparkmi.so"
+LIB_PATH = Path(os.environ["SPARKMI_LIB"]) if os.environ.get("SPARKMI_LIB") else _HERE / "libsparkmi.so"
 
 SMI_MAX_ROWS = 32
 
@@ -88,6 +88,8 @@ def lib() -> C.CDLL:
         import torch  # noqa: F401
         l = C.CDLL(str(LIB_PATH))
         for name, (res, args) in SYMBOLS.items():
+            if os.environ.get("SPARKMI_LIB") and not hasattr(l, name):
+                continue            # A/B runs against an older build (diagnostics only)
             fn = getattr(l, name)   # AttributeError here = header/library mismatch
             fn.restype, fn.argtypes = res, args
         if l.smi_version() != 1:
