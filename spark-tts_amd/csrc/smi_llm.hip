@@ -40,134 +40,97 @@ enum { PRO_PLAIN = 0, PRO_NORM = 1 };
 enum { EPI_RESID = 0, EPI_SWIGLU = 1, EPI_QKV = 2, EPI_LM = 3 };
 
 struct GemmP {
-  const uint4* W;   // [NT][KT][64] 16-byte lane pieces
-  int NT, KT, M, KC;  // n tiles, k tiles, rows, k tiles per LDS chunk
+  const uint4* W;        // [NT][KT][64] 16-byte lane pieces (bf16 tiles in MFMA A-operand order)
+  int NT, KT, M;         // n tiles, k tiles, rows
   const RowDesc* rows;
-  const float* X;      // [M][K] f32
-  const float* gamma;  // [K] RMSNorm weight (PRO_NORM)
+  const unsigned char* XS;   // operand: exact bf16 triples [KT][3][4][M][16 B] in MFMA B-operand order
+  const float* sspart;   // PRO_NORM: [32][npart] partial sums of squares of the operand's fp32 source row
+  int npart;
   float eps;
-  float* Y;            // RESID: h [M][N]; SWIGLU: act [M][N/2]; QKV: q [M][q_dim]; LM: logits [M][V] or null
-  const float* bias;   // QKV bias [N] (arena order)
-  const float2* rope;  // [max_pos][32] (cos, sin)
-  void* kcache;        // this layer's K cache: [slot][kvh][max_pos][64]
+  float* Y;              // RESID: h [M][N]; QKV: q [M][q_dim]; LM: logits [M][V] or null
+  const float* bias;     // QKV bias [N] (arena order)
+  const float2* rope;    // [max_pos][32] (cos, sin)
+  void* kcache;          // this layer's K cache: [slot][kvh][max_pos][64]
   void* vcache;
   int q_dim, kv_dim, n_kv, max_pos;
-  int V;               // LM: true vocab size
-  float* pval;         // LM: [gridDim.x][32] per-block best logit
-  int* pidx;           // LM: [gridDim.x][32] per-block best index
-  unsigned long long* stamps;  // diagnostics: [gridDim.x][8] s_memrealtime stamps (100 MHz) or null
-  int work_blocks;             // blocks >= work_blocks only prefetch [pf_ptr, pf_ptr + pf_bytes) into the Infinity Cache
-  const void* pf_ptr;
-  size_t pf_bytes;
+  int V;                 // LM: true vocab size
+  float* pval;           // LM: [32][work_blocks] per-block best logit
+  int* pidx;
+  // producer side: the next consumer's operand, written by the epilogue
+  unsigned char* XSout;  // RESID: triples of gamma_next * h_new, [N/32][3][4][M][16]; SWIGLU: triples of act
+  const float* gamma_next;  // RESID: [N] RMSNorm weight of the NEXT norm
+  float* ssout;          // RESID: [32][NT] partial sum of squares of h_new (this block writes column nt)
+  unsigned long long* stamps;
+  int work_blocks;
 };
 
-// ------------------------------------------------------------------------------------------
-// GEMM: Y[m][n] = sum_k W[n][k] * X'[m][k]
-// ------------------------------------------------------------------------------------------
-// exact 3-way bf16 split of 8 fp32 values, written as three 16-byte B-operand pieces
-__device__ __forceinline__ void split_store(const float (&v)[8], unsigned char* dst, int plane_bytes) {
-  uint32_t hi[8], mi[8], lo[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    hi[i] = smi_f32_to_bf16(v[i]);
-    const float r1 = v[i] - smi_bf16_to_f32(hi[i]);
-    mi[i] = smi_f32_to_bf16(r1);
-    const float r2 = r1 - smi_bf16_to_f32(mi[i]);
-    lo[i] = smi_f32_to_bf16(r2);
-  }
-  *(uint4*)(dst) = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
-  *(uint4*)(dst + plane_bytes) = make_uint4(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16), mi[4] | (mi[5] << 16), mi[6] | (mi[7] << 16));
-  *(uint4*)(dst + 2 * plane_bytes) = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+// exact 3-way bf16 split: x == hi + mid + lo (8 + 8 + 8 mantissa bits)
+__device__ __forceinline__ void split3(float x, uint32_t& hi, uint32_t& mi, uint32_t& lo) {
+  hi = smi_f32_to_bf16(x);
+  const float r1 = x - smi_bf16_to_f32(hi);
+  mi = smi_f32_to_bf16(r1);
+  const float r2 = r1 - smi_bf16_to_f32(mi);
+  lo = smi_f32_to_bf16(r2);
+}
+// byte offset of the 16-byte piece (k tile kt, split s, octet k8, row m) in a triples buffer
+__device__ __forceinline__ size_t xs_off(int kt, int s, int k8, int m, int M) {
+  return ((size_t)((kt * 3 + s) * 4 + k8) * M + m) * 16;
 }
 
-// MT m-tiles of 16 rows, NTB 16-row weight tiles per block, NW waves (split K), U weight tiles per
-// wave kept in flight per batch.  PF: issue the first weight batch before the prologue.  ACC3: one
-// accumulator chain per bf16 split term (3x shorter dependent MFMA chains), summed (lo+mid)+hi.
-// The k-tile -> wave map (kt mod NW), the chain structure and the reduction order do not depend on
-// M, so a row's result is bit-identical whatever else is in the batch.
-template <int MT, int NTB, int NW, int U, int PRO, int EPI, int KVF32, bool PF, bool ACC3, bool XFIRST, bool EPRE>
-__global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k_gemm(GemmP p) {
+// ------------------------------------------------------------------------------------------
+// GEMM: Y[m][n] = sum_k W[n][k] * X[m][k], X given as exact bf16 triples in global memory.
+// MT m-tiles of 16 rows, NTB 16-row weight tiles per block, NW waves split K (k tile kt belongs to
+// wave kt mod NW), U tiles per wave in flight per batch.  One accumulator chain per split term,
+// summed (lo + mid) + hi; cross-wave reduction in fixed order.  Nothing depends on M, so a row's
+// result is bit-identical whatever else is in the batch.  PRO_NORM: the operand is gamma * x and the
+// RMSNorm factor rsqrt(mean(x^2) + eps) -- a per-row scalar -- is applied to the accumulator.
+// ------------------------------------------------------------------------------------------
+template <int MT, int NTB, int NW, int U, int PRO, int EPI, int KVF32>
+__global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if ((int)blockIdx.x >= p.work_blocks) {   // helper blocks: warm the cache for a later kernel
-    smi_prefetch_range(p.pf_ptr, p.pf_bytes, ((int)blockIdx.x - p.work_blocks) * NW * 64 + tid,
-                       ((int)gridDim.x - p.work_blocks) * NW * 64);
-    return;
-  }
-  const int KT = p.KT, K = KT * 32, M = p.M, NT = p.NT;
+  const int KT = p.KT, M = p.M, NT = p.NT;
   const int nt0 = blockIdx.x * NTB;
 #define SMI_STAMP(i) do { if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   SMI_STAMP(0);
-  const unsigned long long c_entry = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-  // LDS map: [0, xs_bytes) activation splits (later aliased by the split-K reduction slab),
-  // then rstd[32] floats, then argmax scratch.
-  const int xs_bytes = p.KC * 192 * M;
-  const int red_bytes = NW * NTB * MT * 1024;
-  const int main_bytes = xs_bytes > red_bytes ? xs_bytes : red_bytes;
-  unsigned char* xs = smem;
-  float* rstd = (float*)(smem + main_bytes);
-  float* bestv = rstd + 32;               // [NTB][32]
-  int* besti = (int*)(bestv + NTB * 32);  // [NTB][32]
-  const int mslot_bytes = M * 16;
-  const int plane = 4 * mslot_bytes;      // bytes between the hi / mid / lo planes of one k tile
-  const bool single = p.KC >= KT;         // the whole K fits in LDS at once (small M)
-  constexpr int MAXO = 2;                 // octets per lane in the one-pass norm prologue => K <= 1024
-  const bool onepass = single && (PRO == PRO_PLAIN || (K >> 3) <= 64 * MAXO);
-  constexpr bool wpriv = false;   // wave-private staging (every wave re-reading the row) measured slower: kept off
-  const int row0 = wave, rstep = NW;
+  float4* red = (float4*)smem;                                   // [NW][NTB][MT][64]
+  float* rarr = (float*)(smem + (size_t)NW * NTB * MT * 1024);  // [32] per-row RMSNorm factor
+  float* bestv = rarr + 32;                                      // LM: [NTB][32]
+  int* besti = (int*)(bestv + NTB * 32);
 
-  // (1) Loads return in issue order, so the (short, critical-path) activation loads go first and
-  //     the first batch of weight tiles right behind them: the weights' HBM latency then overlaps
-  //     the prologue arithmetic instead of preceding it.
-  const int KO = K >> 3;
-  float xv[MAXO][8], xg[MAXO][8];          // PRO_NORM: this wave's first row (+ norm weight)
-  float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;   // PRO_PLAIN: this thread's first unit
-  const int octs_all = KT * 4;
-  if (onepass && XFIRST) {
-    if (PRO == PRO_NORM) {
-      if (row0 < M) {
-#pragma unroll
-        for (int i = 0; i < MAXO; ++i) {
-          const int o = lane + 64 * i;
-          if (o < KO) {
-            const float4* src = (const float4*)(p.X + (size_t)row0 * K + o * 8);
-            const float4* gp = (const float4*)(p.gamma + o * 8);
-            const float4 a = src[0], b = src[1], g0 = gp[0], g1 = gp[1];
-            xv[i][0] = a.x; xv[i][1] = a.y; xv[i][2] = a.z; xv[i][3] = a.w;
-            xv[i][4] = b.x; xv[i][5] = b.y; xv[i][6] = b.z; xv[i][7] = b.w;
-            xg[i][0] = g0.x; xg[i][1] = g0.y; xg[i][2] = g0.z; xg[i][3] = g0.w;
-            xg[i][4] = g1.x; xg[i][5] = g1.y; xg[i][6] = g1.z; xg[i][7] = g1.w;
-          }
-        }
-      }
-    } else if (!wpriv && tid < M * octs_all) {
-      const int m = tid / octs_all, o = tid - m * octs_all;
-      const float4* src = (const float4*)(p.X + (size_t)m * K + o * 8);
-      pa = src[0]; pb = src[1];
-    }
-  }
+  // ---- operands in flight: weight tiles + the matching activation triples
   uint4 w[U][NTB];
-  const int kcn0 = KT < p.KC ? KT : p.KC;
-  auto load_batch = [&](int kc0, int kcn, int j0) {
+  bf16x8 bf[U][3][MT];
+  const int k8 = lane >> 4;
+  int mrow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) { const int m = mt * 16 + (lane & 15); mrow[mt] = m < M ? m : M - 1; }
+  auto load_batch = [&](int j0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       int j = j0 + u * NW;
-      j = j < kcn ? j : kcn - 1;
+      j = j < KT ? j : KT - 1;
 #pragma unroll
       for (int nb = 0; nb < NTB; ++nb) {
         int nt = nt0 + nb;
         nt = nt < NT ? nt : NT - 1;
-        w[u][nb] = p.W[((size_t)nt * KT + kc0 + j) * 64 + lane];
+        w[u][nb] = p.W[((size_t)nt * KT + j) * 64 + lane];
       }
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) bf[u][s][mt] = *(const bf16x8*)(p.XS + xs_off(j, s, k8, mrow[mt], M));
     }
   };
-  if (PF && wave < kcn0) load_batch(0, kcn0, wave);
-  // epilogue operands that do not depend on the GEMM: fetch them now as well
-  const int em = lane & 15;                 // this lane's row inside an m-tile
+  if (wave < KT) load_batch(wave);
+
+  // ---- epilogue operands that do not depend on the GEMM
+  const int em = lane & 15;
   RowDesc erd[MT];
-  float4 epre[MT];
-  if (EPRE && wave < NTB && nt0 + wave < NT) {
+  float4 epre[MT], egam = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (wave < NTB && nt0 + wave < NT) {
     const int n = (nt0 + wave) * 16 + 4 * (lane >> 4);
+    if (EPI == EPI_RESID) egam = *(const float4*)(p.gamma_next + n);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int m = mt * 16 + em;
@@ -177,172 +140,52 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
       }
     }
   }
+  // ---- RMSNorm factor per row from the producer's partial sums (fixed order: DPP tree over partials)
+  if (PRO == PRO_NORM) {
+    for (int m = wave; m < M; m += NW) {
+      float v = 0.f;
+      for (int i = lane; i < p.npart; i += 64) v += p.sspart[(size_t)m * p.npart + i];
+      v = smi_wave_sum(v);
+      if (lane == 0) rarr[m] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
+    }
+  }
   SMI_STAMP(1);
 
-  // (2) prologue
-  if (onepass) {
-    if (PRO == PRO_NORM) {
-      // wave w owns rows w, w+NW, ..: one pass per row -- reduce, scale, split, store
-      for (int m = row0; m < M; m += rstep) {
-        if (!XFIRST || m != row0) {
+  f32x4 acc[3][NTB][MT];
 #pragma unroll
-          for (int i = 0; i < MAXO; ++i) {
-            const int o = lane + 64 * i;
-            if (o < KO) {
-              const float4* src = (const float4*)(p.X + (size_t)m * K + o * 8);
-              const float4 a = src[0], b = src[1];
-              xv[i][0] = a.x; xv[i][1] = a.y; xv[i][2] = a.z; xv[i][3] = a.w;
-              xv[i][4] = b.x; xv[i][5] = b.y; xv[i][6] = b.z; xv[i][7] = b.w;
-              if (!XFIRST && m == row0) {
-                const float4* gp = (const float4*)(p.gamma + o * 8);
-                const float4 g0 = gp[0], g1 = gp[1];
-                xg[i][0] = g0.x; xg[i][1] = g0.y; xg[i][2] = g0.z; xg[i][3] = g0.w;
-                xg[i][4] = g1.x; xg[i][5] = g1.y; xg[i][6] = g1.z; xg[i][7] = g1.w;
-              }
-            }
-          }
-        }
-        float ss = 0.f;
-#pragma unroll
-        for (int i = 0; i < MAXO; ++i)
-          if (lane + 64 * i < KO) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ss += xv[i][e] * xv[i][e];
-          }
-        ss = smi_wave_sum(ss);
-        const float r = 1.0f / sqrtf(ss / (float)K + p.eps);
-#pragma unroll
-        for (int i = 0; i < MAXO; ++i) {
-          const int o = lane + 64 * i;
-          if (o < KO && (!wpriv || ((o >> 2) % NW) == wave)) {
-            float t[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = xg[i][e] * (xv[i][e] * r);  // weight * (x * rsqrt(var+eps)), MQ:251-252
-            split_store(t, xs + (((o >> 2) * 3) * 4 + (o & 3)) * mslot_bytes + m * 16, plane);
-          }
-        }
-      }
-    } else if (wpriv) {
-      // this wave's k tiles are wave, wave+NW, ..: 4 octets each
-      const int mine = ((KT - wave + NW - 1) / NW) * 4;
-      for (int u = lane; u < M * mine; u += 64) {
-        const int m = u / mine, i = u - m * mine;
-        const int o = (wave + (i >> 2) * NW) * 4 + (i & 3);
-        const float4* src = (const float4*)(p.X + (size_t)m * K + o * 8);
-        const float4 a = src[0], b = src[1];
-        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        split_store(v, xs + (((o >> 2) * 3) * 4 + (o & 3)) * mslot_bytes + m * 16, plane);
-      }
-    } else {
-      for (int u = tid; u < M * octs_all; u += NW * 64) {
-        const int m = u / octs_all, o = u - m * octs_all;
-        if (!XFIRST || u != tid) {
-          const float4* src = (const float4*)(p.X + (size_t)m * K + o * 8);
-          pa = src[0]; pb = src[1];
-        }
-        const float v[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
-        split_store(v, xs + (((o >> 2) * 3) * 4 + (o & 3)) * mslot_bytes + m * 16, plane);
-      }
-    }
-  } else if (PRO == PRO_NORM) {
-    for (int m = wave; m < M; m += NW) {
-      const float4* xr = (const float4*)(p.X + (size_t)m * K);
-      float s = 0.f;
-      for (int i = lane; i < K / 4; i += 64) {
-        float4 v = xr[i];
-        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-      }
-      s = smi_wave_sum(s);
-      if (lane == 0) rstd[m] = 1.0f / sqrtf(s / (float)K + p.eps);
-    }
-    __syncthreads();
-  }
-
-  constexpr int NA = ACC3 ? 3 : 1;
-  f32x4 acc[NA][NTB][MT];
-#pragma unroll
-  for (int c = 0; c < NA; ++c)
+  for (int c = 0; c < 3; ++c)
 #pragma unroll
     for (int a = 0; a < NTB; ++a)
 #pragma unroll
       for (int b = 0; b < MT; ++b) acc[c][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  SMI_STAMP(2);
 
-  for (int kc0 = 0; kc0 < KT; kc0 += p.KC) {
-    const int kcn = (KT - kc0) < p.KC ? (KT - kc0) : p.KC;
-    if (!onepass) {
-      if (kc0) __syncthreads();
-      // stage this chunk's activations as exact bf16 triples in MFMA B-operand order
-      const int octs = kcn * 4;
-      for (int u = tid; u < M * octs; u += NW * 64) {
-        const int m = u / octs, o = u - m * octs;
-        const int k = (kc0 * 4 + o) * 8;
-        const float4* src = (const float4*)(p.X + (size_t)m * K + k);
-        float4 a = src[0], b = src[1];
-        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        if (PRO == PRO_NORM) {
-          const float r = rstd[m];
-          const float4* gp = (const float4*)(p.gamma + k);
-          float4 g0 = gp[0], g1 = gp[1];
-          float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+  for (int j0 = wave; j0 < KT; j0 += NW * U) {
+    if (j0 != wave) load_batch(j0);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = g[i] * (v[i] * r);
-        }
-        split_store(v, xs + (((o >> 2) * 3) * 4 + (o & 3)) * mslot_bytes + m * 16, plane);
-      }
-    }
-    if (wpriv) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own LDS writes landed; no other wave's are read
-    else __syncthreads();
-    SMI_STAMP(3);
-    // ---- stream weight tiles; wave w owns the k tiles with (kt mod NW) == w (KC is a multiple of NW)
-    const int k8 = lane >> 4;
-    for (int j0 = wave; j0 < kcn; j0 += NW * U) {
-      if (!PF || kc0 != 0 || j0 != wave) load_batch(kc0, kcn, j0);
+    for (int u = 0; u < U; ++u) {
+      if (j0 + u * NW < KT) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int j = j0 + u * NW;
-        if (j < kcn) {
-          bf16x8 bf[3][MT];
+        for (int nb = 0; nb < NTB; ++nb) {
+          const bf16x8 a = __builtin_bit_cast(bf16x8, w[u][nb]);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            int m = mt * 16 + (lane & 15);
-            m = m < M ? m : M - 1;
-            const unsigned char* bp = xs + ((j * 3) * 4 + k8) * mslot_bytes + m * 16;
-#pragma unroll
-            for (int s = 0; s < 3; ++s) bf[s][mt] = *(const bf16x8*)(bp + s * plane);
-          }
-#pragma unroll
-          for (int nb = 0; nb < NTB; ++nb) {
-            const bf16x8 a = __builtin_bit_cast(bf16x8, w[u][nb]);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              acc[ACC3 ? 2 : 0][nb][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[2][mt], acc[ACC3 ? 2 : 0][nb][mt], 0, 0, 0);
-              acc[ACC3 ? 1 : 0][nb][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[1][mt], acc[ACC3 ? 1 : 0][nb][mt], 0, 0, 0);
-              acc[0][nb][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[0][mt], acc[0][nb][mt], 0, 0, 0);
-            }
+            acc[2][nb][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[u][2][mt], acc[2][nb][mt], 0, 0, 0);
+            acc[1][nb][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[u][1][mt], acc[1][nb][mt], 0, 0, 0);
+            acc[0][nb][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[u][0][mt], acc[0][nb][mt], 0, 0, 0);
           }
         }
       }
     }
   }
-  if (ACC3) {
-#pragma unroll
-    for (int a = 0; a < NTB; ++a)
-#pragma unroll
-      for (int b = 0; b < MT; ++b) acc[0][a][b] = (acc[2][a][b] + acc[1][a][b]) + acc[0][a][b];   // (lo + mid) + hi
-  }
-
-  // ---- split-K reduction across the block's waves (fixed order => deterministic)
-  if (p.stamps) { asm volatile("" :: "v"(acc[0][0][0][0])); }
   SMI_STAMP(4);
-  __syncthreads();
-  float4* red = (float4*)smem;  // [NW][NTB][MT][64]
+  // ---- split-K reduction across the block's waves (fixed order => deterministic)
 #pragma unroll
   for (int nb = 0; nb < NTB; ++nb)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-      red[((wave * NTB + nb) * MT + mt) * 64 + lane] =
-          make_float4(acc[0][nb][mt][0], acc[0][nb][mt][1], acc[0][nb][mt][2], acc[0][nb][mt][3]);
+    for (int mt = 0; mt < MT; ++mt) {
+      const f32x4 t = (acc[2][nb][mt] + acc[1][nb][mt]) + acc[0][nb][mt];   // (lo + mid) + hi
+      red[((wave * NTB + nb) * MT + mt) * 64 + lane] = make_float4(t[0], t[1], t[2], t[3]);
+    }
   if (EPI == EPI_LM) {
     for (int i = tid; i < NTB * 32; i += NW * 64) { bestv[i] = -INFINITY; besti[i] = 0x7fffffff; }
   }
@@ -357,32 +200,59 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
     for (int mt = 0; mt < MT; ++mt) {
       float4 s = red[((0 * NTB + nb) * MT + mt) * 64 + lane];
 #pragma unroll
-      for (int w = 1; w < NW; ++w) {
-        float4 t = red[((w * NTB + nb) * MT + mt) * 64 + lane];
+      for (int wv = 1; wv < NW; ++wv) {
+        const float4 t = red[((wv * NTB + nb) * MT + mt) * 64 + lane];
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
       }
-      const int m = mt * 16 + (lane & 15);
+      const int m = mt * 16 + em;
       const int n = nt * 16 + 4 * (lane >> 4);
       const bool valid = m < M;
+      if (PRO == PRO_NORM) {
+        const float r = rarr[valid ? m : 0];
+        s.x *= r; s.y *= r; s.z *= r; s.w *= r;
+      }
       if (EPI == EPI_RESID) {
+        float ssq = 0.f;
         if (valid) {
-          float4 h = EPRE ? epre[mt] : *(const float4*)(p.Y + (size_t)m * N + n);   // EPRE: fetched at kernel entry
+          float4 h = epre[mt];   // fetched at kernel entry (only this lane ever writes it)
           h.x += s.x; h.y += s.y; h.z += s.z; h.w += s.w;
           *(float4*)(p.Y + (size_t)m * N + n) = h;
+          ssq = (h.x * h.x + h.y * h.y) + (h.z * h.z + h.w * h.w);
+          // next consumer's operand: exact triples of gamma_next * h_new (4 of the 8 values of an octet)
+          const float t[4] = {egam.x * h.x, egam.y * h.y, egam.z * h.z, egam.w * h.w};
+          uint32_t hi[4], mi[4], lo[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split3(t[e], hi[e], mi[e], lo[e]);
+          const size_t o = xs_off(n >> 5, 0, (n >> 3) & 3, m, M) + ((n >> 2) & 1) * 8;
+          const size_t pl = (size_t)4 * M * 16;
+          *(uint2*)(p.XSout + o) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+          *(uint2*)(p.XSout + o + pl) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
+          *(uint2*)(p.XSout + o + 2 * pl) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
         }
+        // this tile's 16 columns of row m sit in lanes em, em+16, em+32, em+48
+        ssq += __shfl_xor(ssq, 16, 64);
+        ssq += __shfl_xor(ssq, 32, 64);
+        if (lane < 16 && valid) p.ssout[(size_t)m * NT + nt] = ssq;
       } else if (EPI == EPI_SWIGLU) {
         if (valid) {
           // rows are (gate, up, gate, up): silu(g) * u, MQ:46-48
-          float2 o;
-          o.x = (s.x / (1.0f + expf(-s.x))) * s.y;
-          o.y = (s.z / (1.0f + expf(-s.z))) * s.w;
-          *(float2*)(p.Y + (size_t)m * (N / 2) + n / 2) = o;
+          const float a0 = (s.x / (1.0f + expf(-s.x))) * s.y;
+          const float a1 = (s.z / (1.0f + expf(-s.z))) * s.w;
+          uint32_t h0, m0, l0, h1, m1, l1;
+          split3(a0, h0, m0, l0);
+          split3(a1, h1, m1, l1);
+          const int k = n >> 1;   // activation index of a0
+          const size_t o = xs_off(k >> 5, 0, (k >> 3) & 3, m, M) + ((k >> 1) & 3) * 4;
+          const size_t pl = (size_t)4 * M * 16;
+          *(uint32_t*)(p.XSout + o) = h0 | (h1 << 16);
+          *(uint32_t*)(p.XSout + o + pl) = m0 | (m1 << 16);
+          *(uint32_t*)(p.XSout + o + 2 * pl) = l0 | (l1 << 16);
         }
       } else if (EPI == EPI_QKV) {
         if (valid) {
-          const float4 b = EPRE ? epre[mt] : *(const float4*)(p.bias + n);
+          const float4 b = epre[mt];
           s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
-          const RowDesc rd = EPRE ? erd[mt] : p.rows[m];
+          const RowDesc rd = erd[mt];
           if (n < p.q_dim + p.kv_dim) {
             // rows inside a head are ordered (0,32,1,33,..): (s.x,s.y) and (s.z,s.w) are RoPE pairs
             const int i0 = (n & 63) >> 1;
@@ -438,7 +308,6 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
     }
   }
   SMI_STAMP(6);
-  if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - c_entry;   // shader cycles in-kernel
   if (EPI == EPI_LM) {
     __syncthreads();
     if (tid < M) {
@@ -456,17 +325,13 @@ __global__ __launch_bounds__(NW * 64, (EPI == EPI_LM && MT == 1) ? 4 : 1) void k
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// Attention: one block per (query head, row).  softmax(q.K^T / 8) V over positions 0..pos.
-// q is pre-rotated fp32 in the arena's (0,32,1,33,..) order, K cached in the same order, so the
-// dot product is unchanged; V is cached in natural order.
-// ------------------------------------------------------------------------------------------
 struct AttnP {
   const float* q;      // [M][q_dim]
   const void* kcache;  // layer base
   const void* vcache;
   const RowDesc* rows;
-  float* out;          // [M][q_dim]
+  unsigned char* xs_out;  // o_proj operand: exact bf16 triples [q_dim/32][3][4][M][16 B]
+  int M;
   int q_dim, n_kv, group, max_pos, n_heads;
   int work_blocks;     // = n_heads * M; later blocks only prefetch [pf_ptr, pf_ptr + pf_bytes)
   const void* pf_ptr;
@@ -599,25 +464,56 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
   if (tid < kHeadDim) {
     const float O = (so2[0][tid] + so2[1][tid]) + (so2[2][tid] + so2[3][tid]);
     const float Ls = (sl2[0] + sl2[1]) + (sl2[2] + sl2[3]);
-    p.out[(size_t)m * p.q_dim + head * kHeadDim + tid] = O / Ls;
+    uint32_t hi, mi, lo;
+    split3(O / Ls, hi, mi, lo);
+    const int k = head * kHeadDim + tid;
+    const size_t o = xs_off(k >> 5, 0, (k >> 3) & 3, m, p.M) + (k & 7) * 2;
+    const size_t pl = (size_t)4 * p.M * 16;
+    *(uint16_t*)(p.xs_out + o) = (uint16_t)hi;
+    *(uint16_t*)(p.xs_out + o + pl) = (uint16_t)mi;
+    *(uint16_t*)(p.xs_out + o + 2 * pl) = (uint16_t)lo;
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// Embedding gather from the tiled lm_head (tied embeddings): h[m][:] = E[token_m][:]
+// Token -> residual row.  One wave per row: gathers the embedding row from the tiled lm_head (tied
+// weights), writes h (fp32), the first norm's operand (exact triples of gamma * h) and the row's
+// sum of squares (partial slot 0; the other slots are zeroed so consumers sum a fixed count).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float lm_elem(const uint16_t* W, int KT, int n, int k) {
-  const size_t tile = (size_t)(n >> 4) * KT + (k >> 5);
-  const int in = (((k >> 3) & 3) * 16 + (n & 15)) * 8 + (k & 7);
-  return smi_bf16_to_f32(W[tile * 512 + in]);
+__device__ __forceinline__ void embed_row(const uint16_t* Wlm, int KT, int token, int m, int M, const float* gamma,
+                                          float* h, unsigned char* xs, float* sspart, int npart, int lane) {
+  const int K = KT * 32, pieces = KT * 4;
+  float ss = 0.f;
+  for (int pc = lane; pc < pieces; pc += 64) {      // pc = k / 8
+    const size_t tile = (size_t)(token >> 4) * KT + (pc >> 2);
+    const uint4 v = *(const uint4*)(Wlm + tile * 512 + ((pc & 3) * 16 + (token & 15)) * 8);
+    const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(u[e] << 16); x[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); }
+    float* dst = h + (size_t)m * K + pc * 8;
+    *(float4*)dst = make_float4(x[0], x[1], x[2], x[3]);
+    *(float4*)(dst + 4) = make_float4(x[4], x[5], x[6], x[7]);
+    const float4 g0 = *(const float4*)(gamma + pc * 8), g1 = *(const float4*)(gamma + pc * 8 + 4);
+    const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    uint32_t hi[8], mi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ss += x[e] * x[e]; split3(g[e] * x[e], hi[e], mi[e], lo[e]); }
+    const size_t o = xs_off(pc >> 2, 0, pc & 3, m, M);
+    const size_t pl = (size_t)4 * M * 16;
+    *(uint4*)(xs + o) = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+    *(uint4*)(xs + o + pl) = make_uint4(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16), mi[4] | (mi[5] << 16), mi[6] | (mi[7] << 16));
+    *(uint4*)(xs + o + 2 * pl) = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+  }
+  ss = smi_wave_sum(ss);
+  for (int i = lane; i < npart; i += 64) sspart[(size_t)m * npart + i] = i == 0 ? ss : 0.f;
 }
 
-__global__ void k_embed(const uint16_t* W, int KT, const RowDesc* rows, int M, float* h) {
-  const int K = KT * 32;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M * K; i += gridDim.x * blockDim.x) {
-    const int m = i / K, k = i - m * K;
-    h[i] = lm_elem(W, KT, rows[m].token, k);
-  }
+__global__ __launch_bounds__(256) void k_embed(const uint16_t* Wlm, int KT, const RowDesc* rows, int M, const float* gamma,
+                                               float* h, unsigned char* xs, float* sspart, int npart) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4)
+    embed_row(Wlm, KT, rows[m].token, m, M, gamma, h, xs, sspart, npart, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -752,6 +648,9 @@ struct FinP {
   const uint16_t* Wlm;
   float* h;
   int max_steps;
+  const float* gamma0;   // first layer's input norm weight
+  unsigned char* xs;     // first layer's operand
+  float* sspart; int npart;
 };
 
 __global__ __launch_bounds__(256) void k_finalize(FinP p) {
@@ -808,18 +707,9 @@ __global__ __launch_bounds__(256) void k_finalize(FinP p) {
     }
     __syncthreads();
   }
-  // next step's embedding rows: one 16-byte piece (8 bf16) per thread-iteration
-  const int K = p.KT * 32, pieces = p.KT * 4;
-  for (int i = tid; i < p.M * pieces; i += 256) {
-    const int m = i / pieces, pc = i - m * pieces;       // pc = k / 8
-    const int n = tok_s[m];
-    const size_t tile = (size_t)(n >> 4) * p.KT + (pc >> 2);
-    const uint4 v = *(const uint4*)(p.Wlm + tile * 512 + ((pc & 3) * 16 + (n & 15)) * 8);
-    const uint32_t u[4] = {v.x, v.y, v.z, v.w};
-    float* dst = p.h + (size_t)m * K + pc * 8;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { dst[2 * e] = __uint_as_float(u[e] << 16); dst[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); }
-  }
+  // next step's residual rows, first-norm operands and sums of squares: one wave per row
+  for (int m = wave; m < p.M; m += 4)
+    embed_row(p.Wlm, p.KT, tok_s[m], m, p.M, p.gamma0, p.h, p.xs, p.sspart, p.npart, lane);
   if (tid == 0) *p.step = step + 1;
 }
 
@@ -879,7 +769,9 @@ struct smi_llm {
   const unsigned char* arena;
   int H, Q, KV, I, KTh, KTq, KTi, NTqkv, NTh, NTgu, NTlm;
   // device scratch
-  float *h, *qbuf, *attn, *act;
+  float *h, *qbuf;
+  unsigned char *xs_h, *xs_attn, *xs_act;   // GEMM operands as exact bf16 triples ([K/32][3][4][M][16 B])
+  float* sspart;       // [32][NTh] partial sums of squares of h (RMSNorm)
   RowDesc* rows;       // live decode rows [32]
   RowDesc* plan;       // prefill plan
   size_t plan_cap;     // rows
@@ -892,8 +784,6 @@ struct smi_llm {
   int do_sample, top_k; float temperature, top_p; unsigned long long seed;
   float* logits; int* tok;
   unsigned long long* stamps; int stamps_on;
-  int variant;    // diagnostics (SPARKMI_VARIANT)
-  int prefetch;   // helper blocks warm the Infinity Cache for later kernels (measured: net loss; off unless SPARKMI_PREFETCH=1)
   int max_steps;
   hipGraphExec_t graph; int graph_B;
   hipEvent_t ev0, ev1;
@@ -903,47 +793,26 @@ struct smi_llm {
 
 namespace {
 
-template <int MT, int NTB, int NW, int U, int PRO, int EPI, bool PF, bool ACC3, bool XFIRST, bool EPRE>
+template <int MT, int NTB, int NW, int U, int PRO, int EPI>
 int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
   const int work = (p.NT + NTB - 1) / NTB;
   p.work_blocks = work;
-  // helper blocks on the CUs this grid leaves idle pull a later kernel's weights into the Infinity Cache
-  const int helpers = (L->prefetch && p.pf_ptr && p.pf_bytes && work < 224) ? 256 - work : 0;
-  const int xs_bytes = p.KC * 192 * p.M;
-  const int red_bytes = NW * NTB * MT * 1024;
-  const size_t lds = (size_t)(xs_bytes > red_bytes ? xs_bytes : red_bytes) + 32 * 4 + NTB * 32 * 8;
-  SMI_REQUIRE(lds <= 150 * 1024, "k_gemm needs %zu bytes of LDS", lds);
-  if (L->cfg.kv_dtype) {
-    auto kfn = k_gemm<MT, NTB, NW, U, PRO, EPI, 1, PF, ACC3, XFIRST, EPRE>;
-    static size_t cap = 64 * 1024;
-    if (lds > cap) { SMI_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); cap = 150 * 1024; }
-    hipLaunchKernelGGL(kfn, dim3(work + helpers), dim3(NW * 64), lds, st, p);
-  } else {
-    auto kfn = k_gemm<MT, NTB, NW, U, PRO, EPI, 0, PF, ACC3, XFIRST, EPRE>;
-    static size_t cap = 64 * 1024;
-    if (lds > cap) { SMI_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); cap = 150 * 1024; }
-    hipLaunchKernelGGL(kfn, dim3(work + helpers), dim3(NW * 64), lds, st, p);
-  }
+  p.stamps = L->stamps_on ? L->stamps : nullptr;
+  const size_t lds = (size_t)NW * NTB * MT * 1024 + 32 * 4 + NTB * 32 * 8;
+  if (L->cfg.kv_dtype)
+    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, PRO, EPI, 1>), dim3(work), dim3(NW * 64), lds, st, p);
+  else
+    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, PRO, EPI, 0>), dim3(work), dim3(NW * 64), lds, st, p);
   SMI_LAUNCH_CHECK();
   return SMI_OK;
 }
 
-// PF / ACC3 must not depend on M (bit-identical rows across batch sizes); XFIRST / EPRE only move loads.
-template <int NTB, int NW, int U, int PRO, int EPI, bool PF, bool ACC3>
-int launch_gemm(const smi_llm* L, GemmP p, hipStream_t st) {
-  // LDS chunking: activation splits cost 192 bytes per (row, k tile).  The chunk is a multiple of
-  // NW so that k tile kt always belongs to wave kt mod NW (batch-invariant summation order).
-  int kc = (56 * 1024) / (192 * p.M);
-  kc = kc / NW * NW;
-  if (kc < NW) kc = NW;
-  p.KC = kc < p.KT ? kc : p.KT;
-  if (p.M > 16) return launch_gemm_kv<2, NTB, NW, (U > 4 ? 4 : U), PRO, EPI, PF, ACC3, false, false>(L, p, st);
-  switch (L->variant & 3) {   // diagnostics: SPARKMI_VARIANT bit0 = activation loads first, bit1 = early epilogue operands
-    case 1: return launch_gemm_kv<1, NTB, NW, U, PRO, EPI, PF, ACC3, true, false>(L, p, st);
-    case 2: return launch_gemm_kv<1, NTB, NW, U, PRO, EPI, PF, ACC3, false, true>(L, p, st);
-    case 3: return launch_gemm_kv<1, NTB, NW, U, PRO, EPI, PF, ACC3, true, true>(L, p, st);
-    default: return launch_gemm_kv<1, NTB, NW, U, PRO, EPI, PF, ACC3, false, false>(L, p, st);
-  }
+// NW (the k-tile -> wave map) is fixed per kernel type for every M; only the batch depth U shrinks
+// for two m-tiles (register budget), which does not change any summation order.
+template <int NTB, int NW, int U, int PRO, int EPI>
+int launch_gemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
+  if (p.M > 16) return launch_gemm_kv<2, NTB, NW, (NW >= 16 || NTB >= 4 ? 2 : (U > 4 ? 4 : U)), PRO, EPI>(L, p, st);
+  return launch_gemm_kv<1, NTB, NW, U, PRO, EPI>(L, p, st);
 }
 
 const unsigned char* sec(const smi_llm* L, int s, int layer) {
@@ -962,57 +831,50 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
   const smi_llm_cfg& c = L->cfg;
   GemmP p;
   memset(&p, 0, sizeof(p));
-  p.M = M; p.rows = rows; p.eps = c.rms_eps;
-  p.stamps = L->stamps_on ? L->stamps : nullptr;
+  p.M = M; p.rows = rows; p.eps = c.rms_eps; p.sspart = L->sspart; p.npart = L->NTh;
   switch (which) {
     case KQKV:
       p.W = (const uint4*)sec(L, SMI_LLM_WQKV, layer); p.NT = L->NTqkv; p.KT = L->KTh;
-      p.X = L->h; p.gamma = (const float*)sec(L, SMI_LLM_LN1, layer);
+      p.XS = L->xs_h;
       p.Y = L->qbuf; p.bias = (const float*)sec(L, SMI_LLM_BQKV, layer);
       p.rope = (const float2*)sec(L, SMI_LLM_ROPE, 0);
       p.kcache = kv_layer(L, L->kcache, layer); p.vcache = kv_layer(L, L->vcache, layer);
       p.q_dim = L->Q; p.kv_dim = L->KV; p.n_kv = c.num_kv_heads; p.max_pos = c.max_positions;
-      p.pf_ptr = sec(L, SMI_LLM_WGU, layer); p.pf_bytes = L->lay.bytes[SMI_LLM_WGU];
-      if (L->variant & 4) return launch_gemm<1, 4, 8, PRO_NORM, EPI_QKV, true, false>(L, p, st);
-      return launch_gemm<1, 4, 8, PRO_NORM, EPI_QKV, true, true>(L, p, st);
+      return launch_gemm<1, 4, 8, PRO_NORM, EPI_QKV>(L, p, st);
     case KATTN: {
       AttnP a;
+      memset(&a, 0, sizeof(a));
       a.q = L->qbuf; a.kcache = kv_layer(L, L->kcache, layer); a.vcache = kv_layer(L, L->vcache, layer);
-      a.rows = rows; a.out = L->attn; a.q_dim = L->Q; a.n_kv = c.num_kv_heads;
+      a.rows = rows; a.xs_out = L->xs_attn; a.M = M; a.q_dim = L->Q; a.n_kv = c.num_kv_heads;
       a.group = c.num_heads / c.num_kv_heads; a.max_pos = c.max_positions; a.n_heads = c.num_heads;
       a.work_blocks = c.num_heads * M;
-      a.pf_ptr = sec(L, SMI_LLM_WD, layer); a.pf_bytes = L->lay.bytes[SMI_LLM_WD];
-      const int helpers = (L->prefetch && a.work_blocks < 224) ? 256 - a.work_blocks : 0;
-      if (c.kv_dtype) hipLaunchKernelGGL(k_attn<1>, dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
-      else hipLaunchKernelGGL(k_attn<0>, dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
+      if (c.kv_dtype) hipLaunchKernelGGL(k_attn<1>, dim3(a.work_blocks), dim3(kAttnWaves * 64), 0, st, a);
+      else hipLaunchKernelGGL(k_attn<0>, dim3(a.work_blocks), dim3(kAttnWaves * 64), 0, st, a);
       SMI_LAUNCH_CHECK();
       return SMI_OK;
     }
-    case KO:
+    case KO:   // h += Wo attn; emits the post-attention norm's operand
       p.W = (const uint4*)sec(L, SMI_LLM_WO, layer); p.NT = L->NTh; p.KT = L->KTq;
-      p.X = L->attn; p.Y = L->h;
-      if (layer + 1 < c.num_layers) {   // next layer's QKV .. O weights are contiguous in the arena
-        p.pf_ptr = sec(L, SMI_LLM_WQKV, layer + 1);
-        p.pf_bytes = (size_t)(sec(L, SMI_LLM_WO, layer + 1) - sec(L, SMI_LLM_WQKV, layer + 1)) + L->lay.bytes[SMI_LLM_WO];
-      }
-      if (L->variant & 4) return launch_gemm<1, 4, 8, PRO_PLAIN, EPI_RESID, true, false>(L, p, st);
-      return launch_gemm<1, 4, 8, PRO_PLAIN, EPI_RESID, true, true>(L, p, st);
+      p.XS = L->xs_attn; p.Y = L->h;
+      p.XSout = L->xs_h; p.gamma_next = (const float*)sec(L, SMI_LLM_LN2, layer); p.ssout = L->sspart;
+      return launch_gemm<1, 4, 8, PRO_PLAIN, EPI_RESID>(L, p, st);
     case KGU:
       p.W = (const uint4*)sec(L, SMI_LLM_WGU, layer); p.NT = L->NTgu; p.KT = L->KTh;
-      p.X = L->h; p.gamma = (const float*)sec(L, SMI_LLM_LN2, layer); p.Y = L->act;
-      if (L->variant & 4) return launch_gemm<2, 4, 8, PRO_NORM, EPI_SWIGLU, true, false>(L, p, st);
-      return launch_gemm<2, 4, 8, PRO_NORM, EPI_SWIGLU, true, true>(L, p, st);
-    case KD:
+      p.XS = L->xs_h; p.XSout = L->xs_act;
+      return launch_gemm<2, 4, 8, PRO_NORM, EPI_SWIGLU>(L, p, st);
+    case KD:   // h += Wd act; emits the next layer's input-norm operand (or the final norm's)
       p.W = (const uint4*)sec(L, SMI_LLM_WD, layer); p.NT = L->NTh; p.KT = L->KTi;
-      p.X = L->act; p.Y = L->h;
-      if (L->variant & 4) return launch_gemm<1, 16, 5, PRO_PLAIN, EPI_RESID, true, false>(L, p, st);
-      return launch_gemm<1, 16, 5, PRO_PLAIN, EPI_RESID, true, true>(L, p, st);
+      p.XS = L->xs_act; p.Y = L->h;
+      p.XSout = L->xs_h; p.ssout = L->sspart;
+      p.gamma_next = layer + 1 < c.num_layers ? (const float*)sec(L, SMI_LLM_LN1, layer + 1)
+                                              : (const float*)sec(L, SMI_LLM_FINAL_NORM, 0);
+      return launch_gemm<1, 16, 5, PRO_PLAIN, EPI_RESID>(L, p, st);
     case KLM:
       p.W = (const uint4*)sec(L, SMI_LLM_LM_HEAD, 0); p.NT = L->NTlm; p.KT = L->KTh;
-      p.X = L->h; p.gamma = (const float*)sec(L, SMI_LLM_FINAL_NORM, 0);
+      p.XS = L->xs_h;
       p.Y = logits ? logits : (L->do_sample ? L->logits : nullptr);
       p.V = c.vocab_size; p.pval = L->pval; p.pidx = L->pidx;
-      return launch_gemm<4, 4, 4, PRO_NORM, EPI_LM, false, false>(L, p, st);
+      return launch_gemm<4, 4, 2, PRO_NORM, EPI_LM>(L, p, st);
     case KFIN: {
       FinP f;
       f.tok = nullptr;
@@ -1027,6 +889,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       f.pval = L->pval; f.pidx = L->pidx; f.nblk = L->lm_blocks; f.M = M; f.KT = L->KTh;
       f.rows = L->rows; f.hist = L->hist; f.count = L->count; f.finished = L->finished; f.step = L->step;
       f.eos = L->eos; f.Wlm = (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0); f.h = L->h; f.max_steps = L->max_steps;
+      f.gamma0 = (const float*)sec(L, SMI_LLM_LN1, 0); f.xs = L->xs_h; f.sspart = L->sspart; f.npart = L->NTh;
       hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, st, f);
       SMI_LAUNCH_CHECK();
       return SMI_OK;
@@ -1037,9 +900,8 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
 }
 
 int launch_embed(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
-  const int n = M * L->H;
-  hipLaunchKernelGGL(k_embed, dim3((n + 255) / 256), dim3(256), 0, st,
-                     (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0), L->KTh, rows, M, L->h);
+  hipLaunchKernelGGL(k_embed, dim3((M + 3) / 4), dim3(256), 0, st, (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0), L->KTh, rows, M,
+                     (const float*)sec(L, SMI_LLM_LN1, 0), L->h, L->xs_h, L->sspart, L->NTh);
   SMI_LAUNCH_CHECK();
   return SMI_OK;
 }
@@ -1119,8 +981,6 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->lm_blocks = (L->NTlm + 3) / 4;
   L->max_steps = cfg->max_positions;
   L->do_sample = 0; L->top_k = 50; L->temperature = 0.8f; L->top_p = 0.95f; L->seed = 0; L->logits = nullptr; L->tok = nullptr; L->stamps = nullptr; L->stamps_on = 0;
-  { const char* e = getenv("SPARKMI_PREFETCH"); L->prefetch = e && e[0] == '1'; }
-  { const char* e = getenv("SPARKMI_VARIANT"); L->variant = e ? atoi(e) : 0; }
   L->graph = nullptr; L->graph_B = 0; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->eos = -1;
   const size_t esz = cfg->kv_dtype ? 4 : 2;
   L->kv_layer_elems = (size_t)cfg->max_slots * cfg->num_kv_heads * cfg->max_positions * kHeadDim;
@@ -1133,8 +993,10 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   }
   SMI_ALLOC(L->h, (size_t)kMaxRows * L->H * 4);
   SMI_ALLOC(L->qbuf, (size_t)kMaxRows * L->Q * 4);
-  SMI_ALLOC(L->attn, (size_t)kMaxRows * L->Q * 4);
-  SMI_ALLOC(L->act, (size_t)kMaxRows * L->I * 4);
+  SMI_ALLOC(L->xs_h, (size_t)kMaxRows * L->H * 6);
+  SMI_ALLOC(L->xs_attn, (size_t)kMaxRows * L->Q * 6);
+  SMI_ALLOC(L->xs_act, (size_t)kMaxRows * L->I * 6);
+  SMI_ALLOC(L->sspart, (size_t)kMaxRows * L->NTh * 4);
   SMI_ALLOC(L->rows, kMaxRows * sizeof(RowDesc));
   SMI_ALLOC(L->pval, (size_t)L->lm_blocks * 32 * 4);
   SMI_ALLOC(L->pidx, (size_t)L->lm_blocks * 32 * 4);
@@ -1150,8 +1012,10 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
 #undef SMI_ALLOC
   if (hipMemset(L->kcache, 0, kvbytes) != hipSuccess || hipMemset(L->vcache, 0, kvbytes) != hipSuccess ||
       hipMemset(L->h, 0, (size_t)kMaxRows * L->H * 4) != hipSuccess ||
-      hipMemset(L->act, 0, (size_t)kMaxRows * L->I * 4) != hipSuccess ||
-      hipMemset(L->attn, 0, (size_t)kMaxRows * L->Q * 4) != hipSuccess ||
+      hipMemset(L->xs_h, 0, (size_t)kMaxRows * L->H * 6) != hipSuccess ||
+      hipMemset(L->xs_attn, 0, (size_t)kMaxRows * L->Q * 6) != hipSuccess ||
+      hipMemset(L->xs_act, 0, (size_t)kMaxRows * L->I * 6) != hipSuccess ||
+      hipMemset(L->sspart, 0, (size_t)kMaxRows * L->NTh * 4) != hipSuccess ||
       hipMemset(L->qbuf, 0, (size_t)kMaxRows * L->Q * 4) != hipSuccess ||
       hipMemset(L->rows, 0, kMaxRows * sizeof(RowDesc)) != hipSuccess ||
       hipMemset(L->count, 0, 128) != hipSuccess || hipMemset(L->finished, 0, 128) != hipSuccess ||
@@ -1172,7 +1036,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
 int smi_llm_destroy(smi_llm* L) {
   if (!L) return SMI_OK;
   if (L->graph) (void)hipGraphExecDestroy(L->graph);
-  void* ptrs[] = {L->h, L->qbuf, L->attn, L->act, L->rows, L->plan, L->pval, L->pidx, L->hist,
+  void* ptrs[] = {L->h, L->qbuf, L->xs_h, L->xs_attn, L->xs_act, L->sspart, L->rows, L->plan, L->pval, L->pidx, L->hist,
                   L->count, L->finished, L->step, L->kcache, L->vcache, L->logits, L->tok, L->stamps};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
