@@ -85,7 +85,7 @@ __device__ __forceinline__ size_t xs_off(int kt, int s, int k8, int m, int M) {
 // result is bit-identical whatever else is in the batch.  PRO_NORM: the operand is gamma * x and the
 // RMSNorm factor rsqrt(mean(x^2) + eps) -- a per-row scalar -- is applied to the accumulator.
 // ------------------------------------------------------------------------------------------
-template <int MT, int NTB, int NW, int U, int PRO, int EPI, int KVF32>
+template <int MT, int NTB, int NW, int U, int WB, int PRO, int EPI, int KVF32>
 __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -98,14 +98,15 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
   float* bestv = rarr + 32;                                      // LM: [NTB][32]
   int* besti = (int*)(bestv + NTB * 32);
 
-  // ---- operands in flight: weight tiles + the matching activation triples
-  uint4 w[U][NTB];
+  // ---- operands in flight: the (cold, HBM) weight tiles of the first WB batches are requested up
+  //      front; the activation triples (small, L2) are fetched per batch
+  uint4 w[WB][U][NTB];
   bf16x8 bf[U][3][MT];
   const int k8 = lane >> 4;
   int mrow[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) { const int m = mt * 16 + (lane & 15); mrow[mt] = m < M ? m : M - 1; }
-  auto load_batch = [&](int j0) {
+  auto load_w = [&](uint4 (&dst)[U][NTB], int j0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       int j = j0 + u * NW;
@@ -114,15 +115,25 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
       for (int nb = 0; nb < NTB; ++nb) {
         int nt = nt0 + nb;
         nt = nt < NT ? nt : NT - 1;
-        w[u][nb] = p.W[((size_t)nt * KT + j) * 64 + lane];
+        dst[u][nb] = p.W[((size_t)nt * KT + j) * 64 + lane];
       }
+    }
+  };
+  auto load_bf = [&](int j0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int j = j0 + u * NW;
+      j = j < KT ? j : KT - 1;
 #pragma unroll
       for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) bf[u][s][mt] = *(const bf16x8*)(p.XS + xs_off(j, s, k8, mrow[mt], M));
     }
   };
-  if (wave < KT) load_batch(wave);
+#pragma unroll
+  for (int b = 0; b < WB; ++b)
+    if (wave + b * NW * U < KT) load_w(w[b], wave + b * NW * U);
+  if (wave < KT) load_bf(wave);
 
   // ---- epilogue operands that do not depend on the GEMM
   const int em = lane & 15;
@@ -159,14 +170,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
 #pragma unroll
       for (int b = 0; b < MT; ++b) acc[c][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int j0 = wave; j0 < KT; j0 += NW * U) {
-    if (j0 != wave) load_batch(j0);
+  auto compute = [&](const uint4 (&wt)[U][NTB], int j0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (j0 + u * NW < KT) {
 #pragma unroll
         for (int nb = 0; nb < NTB; ++nb) {
-          const bf16x8 a = __builtin_bit_cast(bf16x8, w[u][nb]);
+          const bf16x8 a = __builtin_bit_cast(bf16x8, wt[u][nb]);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             acc[2][nb][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[u][2][mt], acc[2][nb][mt], 0, 0, 0);
@@ -176,6 +186,19 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
         }
       }
     }
+  };
+#pragma unroll
+  for (int b = 0; b < WB; ++b) {
+    const int j0 = wave + b * NW * U;
+    if (j0 < KT) {
+      if (b > 0) load_bf(j0);
+      compute(w[b], j0);
+    }
+  }
+  for (int j0 = wave + WB * NW * U; j0 < KT; j0 += NW * U) {   // only for K beyond NW*U*WB tiles
+    load_w(w[0], j0);
+    load_bf(j0);
+    compute(w[0], j0);
   }
   SMI_STAMP(4);
   // ---- split-K reduction across the block's waves (fixed order => deterministic)
@@ -322,6 +345,138 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
       p.pval[(size_t)tid * p.work_blocks + blockIdx.x] = bv;   // [row][block]: finalize reads a row contiguously
       p.pidx[(size_t)tid * p.work_blocks + blockIdx.x] = bi;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// lm_head for up to 16 rows: persistent blocks.  The activation triples of the wave's k tiles are
+// loaded once and stay in registers; the block then streams groups of two 16-row vocabulary tiles
+// (next group's weights requested as soon as the MFMAs have consumed the current ones) and keeps
+// a running arg-max per row.  Same k-tile -> wave map, accumulator chains and reduction order as
+// k_gemm<EPI_LM>, so the logits are bit-identical to the two-m-tile path.
+// ------------------------------------------------------------------------------------------
+template <int KVF32_UNUSED>
+__global__ __launch_bounds__(256) void k_lm(GemmP p, int ngroups) {
+  constexpr int NTB = 2, NW = 4, U = 8, MT = 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int KT = p.KT, M = p.M, NT = p.NT;
+  float4* red = (float4*)smem;                                   // [NW][NTB][64]
+  float* rarr = (float*)(smem + (size_t)NW * NTB * MT * 1024);
+  float* bestv = rarr + 32;                                      // [NTB][32] running best of this block
+  int* besti = (int*)(bestv + NTB * 32);
+  const int k8 = lane >> 4, em = lane & 15;
+  const int mrow = em < M ? em : M - 1;
+  bf16x8 bf[U][3];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    int j = wave + u * NW;
+    j = j < KT ? j : KT - 1;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) bf[u][s] = *(const bf16x8*)(p.XS + xs_off(j, s, k8, mrow, M));
+  }
+  uint4 w[U][NTB];
+  auto load_w = [&](int g) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int j = wave + u * NW;
+      j = j < KT ? j : KT - 1;
+#pragma unroll
+      for (int nb = 0; nb < NTB; ++nb) {
+        int nt = g * NTB + nb;
+        nt = nt < NT ? nt : NT - 1;
+        w[u][nb] = p.W[((size_t)nt * KT + j) * 64 + lane];
+      }
+    }
+  };
+  int g = blockIdx.x;
+  if (g < ngroups) load_w(g);
+  for (int m = wave; m < M; m += NW) {
+    float v = 0.f;
+    for (int i = lane; i < p.npart; i += 64) v += p.sspart[(size_t)m * p.npart + i];
+    v = smi_wave_sum(v);
+    if (lane == 0) rarr[m] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
+  }
+  for (int i = tid; i < NTB * 32; i += 256) { bestv[i] = -INFINITY; besti[i] = 0x7fffffff; }
+  __syncthreads();
+  const float rn = rarr[mrow];
+  for (; g < ngroups; g += gridDim.x) {
+    f32x4 acc[3][NTB];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int a = 0; a < NTB; ++a) acc[c][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (wave + u * NW < KT) {
+#pragma unroll
+        for (int nb = 0; nb < NTB; ++nb) {
+          const bf16x8 a = __builtin_bit_cast(bf16x8, w[u][nb]);
+          acc[2][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[u][2], acc[2][nb], 0, 0, 0);
+          acc[1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[u][1], acc[1][nb], 0, 0, 0);
+          acc[0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[u][0], acc[0][nb], 0, 0, 0);
+        }
+      }
+    }
+    const int gn = g + gridDim.x;
+    if (gn < ngroups) load_w(gn);          // overlaps the reduction and the epilogue below
+#pragma unroll
+    for (int nb = 0; nb < NTB; ++nb) {
+      const f32x4 t = (acc[2][nb] + acc[1][nb]) + acc[0][nb];
+      red[(wave * NTB + nb) * 64 + lane] = make_float4(t[0], t[1], t[2], t[3]);
+    }
+    __syncthreads();
+    if (wave < NTB) {
+      const int nb = wave, nt = g * NTB + nb;
+      if (nt < NT) {
+        float4 s = red[(0 * NTB + nb) * 64 + lane];
+#pragma unroll
+        for (int wv = 1; wv < NW; ++wv) {
+          const float4 t = red[(wv * NTB + nb) * 64 + lane];
+          s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        s.x *= rn; s.y *= rn; s.z *= rn; s.w *= rn;
+        const int n = nt * 16 + 4 * (lane >> 4);
+        const bool valid = em < M;
+        if (valid && p.Y) {
+          float* y = p.Y + (size_t)em * p.V + n;
+          if (n + 0 < p.V) y[0] = s.x;
+          if (n + 1 < p.V) y[1] = s.y;
+          if (n + 2 < p.V) y[2] = s.z;
+          if (n + 3 < p.V) y[3] = s.w;
+        }
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.V && sv[r] > bv) { bv = sv[r]; bi = n + r; }
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+          const float ov = __shfl_xor(bv, o, 64);
+          const int oi = __shfl_xor(bi, o, 64);
+          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane < 16 && valid) {
+          const float cv = bestv[nb * 32 + em];
+          const int ci = besti[nb * 32 + em];
+          if (bv > cv || (bv == cv && bi < ci)) { bestv[nb * 32 + em] = bv; besti[nb * 32 + em] = bi; }
+        }
+      }
+    }
+    __syncthreads();   // red is rewritten by the next group
+  }
+  if (tid < M) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int nb = 0; nb < NTB; ++nb) {
+      const float ov = bestv[nb * 32 + tid];
+      const int oi = besti[nb * 32 + tid];
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    p.pval[(size_t)tid * gridDim.x + blockIdx.x] = bv;
+    p.pidx[(size_t)tid * gridDim.x + blockIdx.x] = bi;
   }
 }
 
@@ -775,7 +930,7 @@ struct smi_llm {
   RowDesc* rows;       // live decode rows [32]
   RowDesc* plan;       // prefill plan
   size_t plan_cap;     // rows
-  float* pval; int* pidx; int lm_blocks;
+  float* pval; int* pidx; int lm_blocks, lm_cap;
   int64_t* hist; int32_t *count, *finished, *step;
   void *kcache, *vcache; size_t kv_layer_elems;
   int B; int64_t eos; int started;
@@ -793,26 +948,26 @@ struct smi_llm {
 
 namespace {
 
-template <int MT, int NTB, int NW, int U, int PRO, int EPI>
+template <int MT, int NTB, int NW, int U, int WB, int PRO, int EPI>
 int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
   const int work = (p.NT + NTB - 1) / NTB;
   p.work_blocks = work;
   p.stamps = L->stamps_on ? L->stamps : nullptr;
   const size_t lds = (size_t)NW * NTB * MT * 1024 + 32 * 4 + NTB * 32 * 8;
   if (L->cfg.kv_dtype)
-    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, PRO, EPI, 1>), dim3(work), dim3(NW * 64), lds, st, p);
+    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 1>), dim3(work), dim3(NW * 64), lds, st, p);
   else
-    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, PRO, EPI, 0>), dim3(work), dim3(NW * 64), lds, st, p);
+    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 0>), dim3(work), dim3(NW * 64), lds, st, p);
   SMI_LAUNCH_CHECK();
   return SMI_OK;
 }
 
 // NW (the k-tile -> wave map) is fixed per kernel type for every M; only the batch depth U shrinks
 // for two m-tiles (register budget), which does not change any summation order.
-template <int NTB, int NW, int U, int PRO, int EPI>
+template <int NTB, int NW, int U, int WB, int PRO, int EPI>
 int launch_gemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
-  if (p.M > 16) return launch_gemm_kv<2, NTB, NW, (NW >= 16 || NTB >= 4 ? 2 : (U > 4 ? 4 : U)), PRO, EPI>(L, p, st);
-  return launch_gemm_kv<1, NTB, NW, U, PRO, EPI>(L, p, st);
+  if (p.M > 16) return launch_gemm_kv<2, NTB, NW, (NW >= 16 || NTB >= 4 ? 2 : (U > 4 ? 4 : U)), 1, PRO, EPI>(L, p, st);
+  return launch_gemm_kv<1, NTB, NW, U, WB, PRO, EPI>(L, p, st);
 }
 
 const unsigned char* sec(const smi_llm* L, int s, int layer) {
@@ -840,7 +995,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       p.rope = (const float2*)sec(L, SMI_LLM_ROPE, 0);
       p.kcache = kv_layer(L, L->kcache, layer); p.vcache = kv_layer(L, L->vcache, layer);
       p.q_dim = L->Q; p.kv_dim = L->KV; p.n_kv = c.num_kv_heads; p.max_pos = c.max_positions;
-      return launch_gemm<1, 4, 8, PRO_NORM, EPI_QKV>(L, p, st);
+      return launch_gemm<1, 4, 8, 1, PRO_NORM, EPI_QKV>(L, p, st);
     case KATTN: {
       AttnP a;
       memset(&a, 0, sizeof(a));
@@ -857,24 +1012,32 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       p.W = (const uint4*)sec(L, SMI_LLM_WO, layer); p.NT = L->NTh; p.KT = L->KTq;
       p.XS = L->xs_attn; p.Y = L->h;
       p.XSout = L->xs_h; p.gamma_next = (const float*)sec(L, SMI_LLM_LN2, layer); p.ssout = L->sspart;
-      return launch_gemm<1, 4, 8, PRO_PLAIN, EPI_RESID>(L, p, st);
+      return launch_gemm<1, 4, 8, 1, PRO_PLAIN, EPI_RESID>(L, p, st);
     case KGU:
       p.W = (const uint4*)sec(L, SMI_LLM_WGU, layer); p.NT = L->NTgu; p.KT = L->KTh;
       p.XS = L->xs_h; p.XSout = L->xs_act;
-      return launch_gemm<2, 4, 8, PRO_NORM, EPI_SWIGLU>(L, p, st);
+      return launch_gemm<2, 4, 8, 1, PRO_NORM, EPI_SWIGLU>(L, p, st);
     case KD:   // h += Wd act; emits the next layer's input-norm operand (or the final norm's)
       p.W = (const uint4*)sec(L, SMI_LLM_WD, layer); p.NT = L->NTh; p.KT = L->KTi;
       p.XS = L->xs_act; p.Y = L->h;
       p.XSout = L->xs_h; p.ssout = L->sspart;
       p.gamma_next = layer + 1 < c.num_layers ? (const float*)sec(L, SMI_LLM_LN1, layer + 1)
                                               : (const float*)sec(L, SMI_LLM_FINAL_NORM, 0);
-      return launch_gemm<1, 16, 5, PRO_PLAIN, EPI_RESID>(L, p, st);
+      return launch_gemm<1, 8, 10, 2, PRO_PLAIN, EPI_RESID>(L, p, st);
     case KLM:
       p.W = (const uint4*)sec(L, SMI_LLM_LM_HEAD, 0); p.NT = L->NTlm; p.KT = L->KTh;
       p.XS = L->xs_h;
       p.Y = logits ? logits : (L->do_sample ? L->logits : nullptr);
       p.V = c.vocab_size; p.pval = L->pval; p.pidx = L->pidx;
-      return launch_gemm<4, 4, 2, PRO_NORM, EPI_LM>(L, p, st);
+      if (M <= 16 && L->KTh <= 32) {   // persistent path (operand resident in registers)
+        const int ngroups = (L->NTlm + 1) / 2;
+        const size_t lds = (size_t)4 * 2 * 1024 + 32 * 4 + 2 * 32 * 8;
+        hipLaunchKernelGGL(k_lm<0>, dim3(L->lm_blocks), dim3(256), lds, st, p, ngroups);
+        SMI_LAUNCH_CHECK();
+        return SMI_OK;
+      }
+      SMI_REQUIRE((L->NTlm + 3) / 4 <= L->lm_cap, "lm_head partial buffer too small");
+      return launch_gemm<4, 4, 2, 1, PRO_NORM, EPI_LM>(L, p, st);
     case KFIN: {
       FinP f;
       f.tok = nullptr;
@@ -886,7 +1049,8 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
         SMI_LAUNCH_CHECK();
         f.tok = L->tok;
       }
-      f.pval = L->pval; f.pidx = L->pidx; f.nblk = L->lm_blocks; f.M = M; f.KT = L->KTh;
+      f.pval = L->pval; f.pidx = L->pidx; f.M = M; f.KT = L->KTh;
+      f.nblk = (M <= 16 && L->KTh <= 32) ? L->lm_blocks : L->lm_cap;
       f.rows = L->rows; f.hist = L->hist; f.count = L->count; f.finished = L->finished; f.step = L->step;
       f.eos = L->eos; f.Wlm = (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0); f.h = L->h; f.max_steps = L->max_steps;
       f.gamma0 = (const float*)sec(L, SMI_LLM_LN1, 0); f.xs = L->xs_h; f.sspart = L->sspart; f.npart = L->NTh;
@@ -978,7 +1142,8 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->I = cfg->intermediate_size;
   L->KTh = L->H / 32; L->KTq = L->Q / 32; L->KTi = L->I / 32;
   L->NTqkv = (L->Q + 2 * L->KV) / 16; L->NTh = L->H / 16; L->NTgu = 2 * L->I / 16; L->NTlm = lay.vpad / 16;
-  L->lm_blocks = (L->NTlm + 3) / 4;
+  L->lm_cap = (L->NTlm + 3) / 4;                       // partial-argmax slots (two-m-tile path: one per block)
+  L->lm_blocks = L->lm_cap < 512 ? L->lm_cap : 512;    // persistent path: 2 resident blocks per CU
   L->max_steps = cfg->max_positions;
   L->do_sample = 0; L->top_k = 50; L->temperature = 0.8f; L->top_p = 0.95f; L->seed = 0; L->logits = nullptr; L->tok = nullptr; L->stamps = nullptr; L->stamps_on = 0;
   L->graph = nullptr; L->graph_B = 0; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->eos = -1;
@@ -998,8 +1163,8 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   SMI_ALLOC(L->xs_act, (size_t)kMaxRows * L->I * 6);
   SMI_ALLOC(L->sspart, (size_t)kMaxRows * L->NTh * 4);
   SMI_ALLOC(L->rows, kMaxRows * sizeof(RowDesc));
-  SMI_ALLOC(L->pval, (size_t)L->lm_blocks * 32 * 4);
-  SMI_ALLOC(L->pidx, (size_t)L->lm_blocks * 32 * 4);
+  SMI_ALLOC(L->pval, (size_t)L->lm_cap * 32 * 4);
+  SMI_ALLOC(L->pidx, (size_t)L->lm_cap * 32 * 4);
   SMI_ALLOC(L->hist, (size_t)L->max_steps * 32 * 8);
   SMI_ALLOC(L->count, 32 * 4);
   SMI_ALLOC(L->finished, 32 * 4);
@@ -1211,7 +1376,8 @@ int smi_llm_debug_stamps(smi_llm* L, int kernel, int layer, double* out) {
   SMI_REQUIRE(L && out && L->started, "smi_llm_debug_stamps: needs a started generation");
   SMI_REQUIRE(kernel == KQKV || kernel == KO || kernel == KGU || kernel == KD || kernel == KLM, "smi_llm_debug_stamps: GEMM kernels only");
   const int grids[] = {L->NTqkv, 0, L->NTh, (L->NTgu + 1) / 2, L->NTh, 0};
-  const int nblk = kernel == KLM ? L->lm_blocks : grids[kernel];
+  const int nblk = kernel == KLM ? ((L->B <= 16 && L->KTh <= 32) ? 0 : L->lm_cap) : grids[kernel];
+  SMI_REQUIRE(nblk > 0, "smi_llm_debug_stamps: the persistent lm_head has no stamps");
   SMI_REQUIRE(nblk <= 4096, "smi_llm_debug_stamps: grid too large");
   SMI_HIP(hipMemset(L->stamps, 0, (size_t)4096 * 64));
   L->stamps_on = 1;

@@ -14,7 +14,7 @@ llm.prefill([prompt]); llm.decode(40); torch.cuda.synchronize()
 f = llm._lib.smi_llm_debug_stamps
 f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
 names = ["entry", "w issued", "prologue done", "barrier1", "mfma done", "reduce barrier", "epilogue done"]
-for kname, kid in [("qkv", 0), ("o_proj", 2), ("gate_up", 3), ("down", 4), ("lm_head", 5)]:
+for kname, kid in [("qkv", 0), ("o_proj", 2), ("gate_up", 3), ("down", 4)]:
     acc = np.zeros(8)
     for layer in range(4, 12):
         out = (C.c_double * 8)()
