@@ -62,6 +62,8 @@ struct GemmP {
   float* ssout;          // RESID: [32][NT] partial sum of squares of h_new (this block writes column nt)
   unsigned long long* stamps;
   int work_blocks;
+  int ldsb;              // few rows: bytes of wave-private LDS for the activation triples (0 = read them from global per tile)
+  int lt_shift;          // log2(lanes that fetch one k tile's 12*M pieces)
 };
 
 // exact 3-way bf16 split: x == hi + mid + lo (8 + 8 + 8 mantissa bits)
@@ -133,7 +135,24 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
 #pragma unroll
   for (int b = 0; b < WB; ++b)
     if (wave + b * NW * U < KT) load_w(w[b], wave + b * NW * U);
-  if (wave < KT) load_bf(wave);
+  // few rows (MT == 1, ldsb > 0): a k tile's 12*M operand pieces are contiguous in XS, so the wave pulls
+  // them with full-width loads into its own LDS slice (no block barrier) instead of 3 narrow loads per tile
+  const bool vlds = MT == 1 && p.ldsb > 0;
+  unsigned char* bw = smem + (size_t)NW * NTB * MT * 1024 + 32 * 4 + NTB * 32 * 8 + (size_t)wave * p.ldsb;
+  if (vlds) {
+    const int tw = (KT - wave + NW - 1) / NW;          // this wave's k tiles
+    const int per = 64 >> p.lt_shift, pm = 12 * M;
+    const int r = lane & ((1 << p.lt_shift) - 1);
+    for (int t0 = 0; t0 < tw; t0 += per) {
+      const int tl = t0 + (lane >> p.lt_shift);
+      if (tl < tw && r < pm) {
+        const uint4 v = *(const uint4*)(p.XS + xs_off(wave + tl * NW, 0, 0, 0, M) + r * 16);
+        *(uint4*)(bw + ((size_t)tl * pm + r) * 16) = v;
+      }
+    }
+  } else if (wave < KT) {
+    load_bf(wave);
+  }
 
   // ---- epilogue operands that do not depend on the GEMM
   const int em = lane & 15;
@@ -170,10 +189,16 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
 #pragma unroll
       for (int b = 0; b < MT; ++b) acc[c][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  if (vlds) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own staging writes have landed (same wave reads them)
   auto compute = [&](const uint4 (&wt)[U][NTB], int j0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (j0 + u * NW < KT) {
+        if (vlds) {
+          const unsigned char* bp = bw + ((size_t)((j0 - wave) / NW + u) * 12 * M + k8 * M + mrow[0]) * 16;
+#pragma unroll
+          for (int s = 0; s < 3; ++s) bf[u][s][0] = *(const bf16x8*)(bp + (size_t)s * 4 * M * 16);
+        }
 #pragma unroll
         for (int nb = 0; nb < NTB; ++nb) {
           const bf16x8 a = __builtin_bit_cast(bf16x8, wt[u][nb]);
@@ -191,13 +216,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
   for (int b = 0; b < WB; ++b) {
     const int j0 = wave + b * NW * U;
     if (j0 < KT) {
-      if (b > 0) load_bf(j0);
+      if (b > 0 && !vlds) load_bf(j0);
       compute(w[b], j0);
     }
   }
   for (int j0 = wave + WB * NW * U; j0 < KT; j0 += NW * U) {   // only for K beyond NW*U*WB tiles
     load_w(w[0], j0);
-    load_bf(j0);
+    if (!vlds) load_bf(j0);
     compute(w[0], j0);
   }
   SMI_STAMP(4);
@@ -953,7 +978,19 @@ int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
   const int work = (p.NT + NTB - 1) / NTB;
   p.work_blocks = work;
   p.stamps = L->stamps_on ? L->stamps : nullptr;
-  const size_t lds = (size_t)NW * NTB * MT * 1024 + 32 * 4 + NTB * 32 * 8;
+  size_t lds = (size_t)NW * NTB * MT * 1024 + 32 * 4 + NTB * 32 * 8;
+  p.ldsb = 0; p.lt_shift = 0;
+  if (MT == 1 && p.M <= 5) {
+    const int tw = (p.KT + NW - 1) / NW;               // k tiles per wave
+    const size_t per_wave = (size_t)tw * 12 * p.M * 16;
+    if (per_wave * NW <= 40 * 1024) {
+      p.ldsb = (int)per_wave;
+      int sh = 4;                                       // 16 lanes fetch 12 pieces (M = 1)
+      while ((1 << sh) < 12 * p.M) ++sh;
+      p.lt_shift = sh;
+      lds += per_wave * NW;
+    }
+  }
   if (L->cfg.kv_dtype)
     hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 1>), dim3(work), dim3(NW * 64), lds, st, p);
   else
