@@ -513,6 +513,7 @@ struct AttnP {
   unsigned char* xs_out;  // o_proj operand: exact bf16 triples [q_dim/32][3][4][M][16 B]
   int M;
   int q_dim, n_kv, group, max_pos, n_heads;
+  int slot_is_row;     // every row m lives in KV slot m (decode): addresses need no descriptor
   int work_blocks;     // = n_heads * M; later blocks only prefetch [pf_ptr, pf_ptr + pf_bytes)
   const void* pf_ptr;
   size_t pf_bytes;
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
   constexpr int DPL = kHeadDim / LPT;   // dims per lane
   constexpr int TPW = 64 / LPT;         // tokens per wave per pass
   constexpr int NGRP = kAttnWaves * TPW;  // token streams per block = tokens per pass
-  constexpr int UNR = 4;                // passes whose K/V loads are issued together
+  constexpr int UNR = 2;                // passes whose K/V loads are issued together (256 tokens per chunk)
   constexpr float NEG = -1e30f;
   __shared__ __attribute__((aligned(16))) float smax[NGRP];
   __shared__ __attribute__((aligned(16))) float sl[NGRP];
@@ -546,9 +547,12 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
   const int tl = lane / LPT, dl = lane % LPT;
   const int grp = wave * TPW + tl;
   const RowDesc rd = p.rows[m];
-  const int ctx = rd.pos + 1;
   const int kvh = head / p.group;
-  const size_t rowbase = ((size_t)rd.slot * p.n_kv + kvh) * p.max_pos;
+  // decode rows use slot == row, so the K/V addresses do not depend on the descriptor and the first
+  // chunk's loads leave together with it (positions beyond ctx are valid cache memory, masked later)
+  const int slot = p.slot_is_row ? m : rd.slot;
+  const size_t rowbase = ((size_t)slot * p.n_kv + kvh) * p.max_pos;
+  const int ctx = rd.pos + 1;
 
   float qv[DPL];
   {
@@ -560,12 +564,14 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
 #pragma unroll
   for (int i = 0; i < DPL; ++i) o[i] = 0.f;
 
-  for (int c0 = 0; c0 < ctx; c0 += NGRP * UNR) {   // block-uniform
+  int c0 = 0;
+  do {   // block-uniform trip count; the first chunk never waits for ctx before its loads
     uint4 kr[UNR], vr[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int t = c0 + u * NGRP + grp;
-      const size_t off = (rowbase + (t < ctx ? t : ctx - 1)) * kHeadDim + dl * DPL;
+      const int tc = p.slot_is_row ? (t < p.max_pos ? t : p.max_pos - 1) : (t < ctx ? t : ctx - 1);
+      const size_t off = (rowbase + tc) * kHeadDim + dl * DPL;
       if (KVF32) {
         kr[u] = *(const uint4*)((const float*)p.kcache + off);
         vr[u] = *(const uint4*)((const float*)p.vcache + off);
@@ -625,7 +631,8 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
     }
     m_run = mn;
     if (c0 + NGRP * UNR < ctx) __syncthreads();   // smax is rewritten by the next chunk
-  }
+    c0 += NGRP * UNR;
+  } while (c0 < ctx);
   // every stream is at scale exp(-m_run): plain sums, fixed order
 #pragma unroll
   for (int i = 0; i < DPL; i += 4)
@@ -1040,6 +1047,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       a.rows = rows; a.xs_out = L->xs_attn; a.M = M; a.q_dim = L->Q; a.n_kv = c.num_kv_heads;
       a.group = c.num_heads / c.num_kv_heads; a.max_pos = c.max_positions; a.n_heads = c.num_heads;
       a.work_blocks = c.num_heads * M;
+      a.slot_is_row = rows == L->rows;   // the live decode rows are (slot b, ...) in order
       if (c.kv_dtype) hipLaunchKernelGGL(k_attn<1>, dim3(a.work_blocks), dim3(kAttnWaves * 64), 0, st, a);
       else hipLaunchKernelGGL(k_attn<0>, dim3(a.work_blocks), dim3(kAttnWaves * 64), 0, st, a);
       SMI_LAUNCH_CHECK();
