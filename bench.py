@@ -125,11 +125,19 @@ def main():
     from sparkmi.bicodec import BiCodecVocoder
     from sparkmi import dist as SD
 
+    # rehearsal on a one-GPU box: SPARKMI_ONE_GPU=1 maps every rank to cuda:0 and uses gloo (RCCL refuses
+    # two ranks on one device); the driver's real multi-GPU runs use one GPU per rank over RCCL/xGMI
+    one_gpu = os.environ.get("SPARKMI_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     arch = _lib.require_gfx950()
     torch.set_num_threads(host_cores())
     if rank == 0:
@@ -204,7 +212,7 @@ def main():
         dist.barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        t = torch.tensor([el], device="cpu" if one_gpu else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 

@@ -35,8 +35,16 @@ def broadcast_arenas(llm_arena: Optional[torch.Tensor], voc_arena: Optional[torc
         torch.cuda.synchronize(device)
     dist.barrier()
     t0 = time.perf_counter()
-    dist.broadcast(llm_arena, src=0)
-    dist.broadcast(voc_arena, src=0)
+    if dist.get_backend() == "gloo" and device.type == "cuda":
+        # gloo rehearsal path: stage through host memory
+        for a in (llm_arena, voc_arena):
+            h = a.cpu()
+            dist.broadcast(h, src=0)
+            if rank != 0:
+                a.copy_(h)
+    else:
+        dist.broadcast(llm_arena, src=0)
+        dist.broadcast(voc_arena, src=0)
     if device.type == "cuda":
         torch.cuda.synchronize(device)
     dist.barrier()
