@@ -85,16 +85,37 @@ __global__ __launch_bounds__(256) void k_conv(ConvP p) {
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   const int xw = p.xw;
-  for (int c0 = 0; c0 < p.CinP; c0 += kChunk) {
-    if (c0) __syncthreads();
-    for (int i = tid; i < kChunk * xw; i += 256) {
-      const int row = i / xw, col = i - row * xw;
-      const int ci = c0 + row, t = q0 - p.halo_l + col;
-      float v = 0.f;
-      if (ci < p.Cin && t >= 0 && t < len) v = Xb[(long long)ci * p.xstride + t];
-      lds[i] = v;
+  // Staging: wave w owns rows 8w..8w+7 of the 32-channel chunk, lanes run along time (coalesced rows).
+  // The next chunk's rows are requested before the MFMAs of the current one and written to LDS after
+  // them, so global latency hides behind the matrix pipe.  With KS each wave multiplies exactly the
+  // rows it staged, so only the wave itself has to see its LDS writes (no block barrier).
+  float sreg[8][2];
+  auto stage_load = [&](int c0) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int ci = c0 + wave * 8 + r;
+      const float* xr = Xb + (long long)ci * p.xstride;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int col = lane + 64 * k, t = q0 - p.halo_l + col;
+        sreg[r][k] = (ci < p.Cin && col < xw && t >= 0 && t < len) ? xr[t] : 0.f;
+      }
     }
-    __syncthreads();
+  };
+  auto stage_store = [&]() {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      float* lr = lds + (wave * 8 + r) * xw;
+      lr[lane] = sreg[r][0];
+      if (lane + 64 < xw) lr[lane + 64] = sreg[r][1];
+    }
+  };
+  stage_load(0);
+  for (int c0 = 0; c0 < p.CinP; c0 += kChunk) {
+    if (c0) { if (KS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads(); }   // chunk c0-32 fully read
+    stage_store();
+    if (KS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads();
+    if (c0 + kChunk < p.CinP) stage_load(c0 + kChunk);
     if (live) {
       const int g0 = KS ? wave : 0, g1 = KS ? wave + 1 : 4;
       for (int tap = 0; tap < ntap; ++tap) {
@@ -815,6 +836,7 @@ int smi_voc_forward(smi_voc* h, const int64_t* sem_dev, const int32_t* lens_host
     if (L.kind == 0) {
       SMI_REQUIRE(L.cp.W, "smi_voc_forward: arena entry for %s not found", L.name.c_str());
       SMI_REQUIRE(L.lds <= 64 * 1024, "smi_voc_forward: %s needs %zu bytes of LDS", L.name.c_str(), L.lds);
+      SMI_REQUIRE(L.cp.xw <= 128, "smi_voc_forward: %s stages %d columns (> 128)", L.name.c_str(), L.cp.xw);
     }
     int rc = run_launch(L, st);
     if (rc) return rc;
