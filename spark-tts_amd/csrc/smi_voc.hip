@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvP p) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       float* lr = lds + (wave * 8 + r) * xw;
-      lr[lane] = sreg[r][0];
+      if (lane < xw) lr[lane] = sreg[r][0];
       if (lane + 64 < xw) lr[lane + 64] = sreg[r][1];
     }
   };
