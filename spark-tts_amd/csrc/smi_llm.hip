@@ -19,9 +19,11 @@
 //
 // The GEMM core: weights are bf16 in 16x32 tiles stored in MFMA A-operand order (one 1 KiB tile =
 // one coalesced 16-B-per-lane wave load = one v_mfma_f32_16x16x32_bf16 operand).  Activations stay
-// fp32: each is split exactly into three bf16 terms (hi+mid+lo, 8+8+8 mantissa bits) staged in LDS
-// in B-operand order, so every product is exact and only the fp32 summation order differs from the
-// CPU oracle.  MFMA columns are the rows m of the step.
+// fp32-exact: every GEMM operand is kept in HBM/L2 as three bf16 terms (hi+mid+lo, 8+8+8 mantissa
+// bits) in B-operand order, written by the epilogue of the kernel that produced the value (with the
+// next RMSNorm's weight folded in and the row's partial sums of squares beside it), so consumers
+// only stream.  Every product is exact and only the fp32 summation order differs from the CPU
+// oracle.  MFMA columns are the rows m of the step.
 #include "smi_common.h"
 #include <stdio.h>
 #include <string.h>
