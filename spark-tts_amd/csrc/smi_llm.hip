@@ -842,64 +842,65 @@ struct FinP {
   float* sspart; int npart;
 };
 
+// One block per row: arg-max over the lm_head blocks' partials (or the sampled token), per-row
+// bookkeeping, and the next step's residual row / first-norm operand.  The per-row step index lives
+// in the row descriptor (flags), so blocks never race on a shared counter; block 0 publishes it.
 __global__ __launch_bounds__(256) void k_finalize(FinP p) {
   __shared__ float sv[4];
   __shared__ int si[4];
-  __shared__ int tok_s[kMaxRows];
+  __shared__ int tok_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int step = *p.step;
-  for (int m = 0; m < p.M; ++m) {
-    float bv = -INFINITY;
-    int bi = 0x7fffffff;
-    if (!p.tok) {
-      constexpr int NP = 16;   // all partial loads in flight together (one memory round trip)
-      float pv[NP];
-      int pi[NP];
+  const int m = blockIdx.x;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  if (!p.tok) {
+    constexpr int NP = 16;   // all partial loads in flight together (one memory round trip)
+    float pv[NP];
+    int pi[NP];
 #pragma unroll
-      for (int j = 0; j < NP; ++j) {
-        const int i = tid + 256 * j;
-        const bool in = i < p.nblk;
-        pv[j] = in ? p.pval[(size_t)m * p.nblk + i] : -INFINITY;
-        pi[j] = in ? p.pidx[(size_t)m * p.nblk + i] : 0x7fffffff;
-      }
-#pragma unroll
-      for (int j = 0; j < NP; ++j)
-        if (pv[j] > bv || (pv[j] == bv && pi[j] < bi)) { bv = pv[j]; bi = pi[j]; }
-      for (int i = tid + 256 * NP; i < p.nblk; i += 256) {
-        const float v = p.pval[(size_t)m * p.nblk + i];
-        const int ix = p.pidx[(size_t)m * p.nblk + i];
-        if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
-      }
+    for (int j = 0; j < NP; ++j) {
+      const int i = tid + 256 * j;
+      const bool in = i < p.nblk;
+      pv[j] = in ? p.pval[(size_t)m * p.nblk + i] : -INFINITY;
+      pi[j] = in ? p.pidx[(size_t)m * p.nblk + i] : 0x7fffffff;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    for (int j = 0; j < NP; ++j)
+      if (pv[j] > bv || (pv[j] == bv && pi[j] < bi)) { bv = pv[j]; bi = pi[j]; }
+    for (int i = tid + 256 * NP; i < p.nblk; i += 256) {
+      const float v = p.pval[(size_t)m * p.nblk + i];
+      const int ix = p.pidx[(size_t)m * p.nblk + i];
+      if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
     }
-    if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
-    __syncthreads();
-    if (tid == 0) {
-      for (int w = 1; w < 4; ++w)
-        if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
-      if (p.tok) bi = p.tok[m];
-      tok_s[m] = bi;
-      if (step < p.max_steps) p.hist[(size_t)step * 32 + m] = bi;
-      if (!p.finished[m]) {
-        p.count[m] = step + 1;
-        if ((int64_t)bi == p.eos) p.finished[m] = 1;
-      }
-      RowDesc rd = p.rows[m];
-      rd.token = bi;
-      rd.pos += 1;
-      p.rows[m] = rd;
-    }
-    __syncthreads();
   }
-  // next step's residual rows, first-norm operands and sums of squares: one wave per row
-  for (int m = wave; m < p.M; m += 4)
-    embed_row(p.Wlm, p.KT, tok_s[m], m, p.M, p.gamma0, p.h, p.xs, p.sspart, p.npart, lane);
-  if (tid == 0) *p.step = step + 1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+    if (p.tok) bi = p.tok[m];
+    tok_s = bi;
+    RowDesc rd = p.rows[m];
+    const int step = rd.flags;                 // tokens this row has emitted so far
+    if (step < p.max_steps) p.hist[(size_t)step * 32 + m] = bi;
+    if (!p.finished[m]) {
+      p.count[m] = step + 1;
+      if ((int64_t)bi == p.eos) p.finished[m] = 1;
+    }
+    rd.token = bi;
+    rd.pos += 1;
+    rd.flags = step + 1;
+    p.rows[m] = rd;
+    if (m == 0) *p.step = step + 1;
+  }
+  __syncthreads();
+  if (wave == 0) embed_row(p.Wlm, p.KT, tok_s, m, p.M, p.gamma0, p.h, p.xs, p.sspart, p.npart, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1101,7 +1102,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       f.rows = L->rows; f.hist = L->hist; f.count = L->count; f.finished = L->finished; f.step = L->step;
       f.eos = L->eos; f.Wlm = (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0); f.h = L->h; f.max_steps = L->max_steps;
       f.gamma0 = (const float*)sec(L, SMI_LLM_LN1, 0); f.xs = L->xs_h; f.sspart = L->sspart; f.npart = L->NTh;
-      hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, st, f);
+      hipLaunchKernelGGL(k_finalize, dim3(M), dim3(256), 0, st, f);
       SMI_LAUNCH_CHECK();
       return SMI_OK;
     }
@@ -1296,7 +1297,7 @@ int smi_llm_prefill(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, 
   for (int b = 0; b < B; ++b)
     for (int t = 0; t + 1 < lens[b]; ++t) L->host_rows[r++] = RowDesc{b, t, (int32_t)ids[(size_t)b * P_max + t], 0};
   for (int b = 0; b < B; ++b)
-    L->host_rows[nchunks * kMaxRows + b] = RowDesc{b, lens[b] - 1, (int32_t)ids[(size_t)b * P_max + lens[b] - 1], 1};
+    L->host_rows[nchunks * kMaxRows + b] = RowDesc{b, lens[b] - 1, (int32_t)ids[(size_t)b * P_max + lens[b] - 1], 0};   // flags = tokens emitted
   SMI_HIP(hipMemcpyAsync(L->plan, L->host_rows.data(), L->host_rows.size() * sizeof(RowDesc), hipMemcpyHostToDevice, st));
   SMI_HIP(hipMemsetAsync(L->count, 0, 128, st));
   SMI_HIP(hipMemsetAsync(L->finished, 0, 128, st));
