@@ -521,30 +521,28 @@ struct AttnP {
   size_t pf_bytes;
 };
 
-constexpr int kAttnWaves = 16;
+constexpr int kAttnWaves = 8;
 
-// 16 waves; a group of LPT lanes owns one token per pass (16-byte K and V pieces per lane, dot
-// product reduced on the DPP path), UNR passes of loads are in flight together.  Softmax is done
-// per chunk of TPB*UNR tokens against a block-wide running max, so every lane accumulates at the
-// same scale and the final merge is a plain sum through LDS (no per-stream rescale, no shuffles).
+// 8 waves; a group of LPT lanes owns one token per pass (16-byte K and V pieces per lane, dot product
+// reduced on the DPP path), UNR passes of loads in flight together (256 tokens per chunk with bf16
+// KV).  Softmax runs per chunk against a block-wide running max (one LDS word per wave, one barrier),
+// so every lane accumulates at the same scale; the final merge is a plain sum: inside the wave through
+// its private LDS slice, across waves through one more barrier.  Little redundant work per thread:
+// with one block per head the kernel is bound by instruction issue of its own waves.
 template <int KVF32>
 __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
   constexpr int LPT = KVF32 ? 16 : 8;   // lanes per token row (each lane 16 bytes)
   constexpr int DPL = kHeadDim / LPT;   // dims per lane
   constexpr int TPW = 64 / LPT;         // tokens per wave per pass
-  constexpr int NGRP = kAttnWaves * TPW;  // token streams per block = tokens per pass
-  constexpr int UNR = 2;                // passes whose K/V loads are issued together (256 tokens per chunk)
+  constexpr int NGRP = kAttnWaves * TPW;  // tokens per block per pass
+  constexpr int UNR = 4;                // passes whose K/V loads are issued together
   constexpr float NEG = -1e30f;
-  __shared__ __attribute__((aligned(16))) float smax[NGRP];
-  __shared__ __attribute__((aligned(16))) float sl[NGRP];
-  __shared__ __attribute__((aligned(16))) float so[NGRP][kHeadDim];
-  __shared__ float so2[4][kHeadDim], sl2[4];
+  constexpr float LOG2E = 1.4426950408889634f;
+  __shared__ float wmax[kAttnWaves];
+  __shared__ __attribute__((aligned(16))) float so[kAttnWaves][TPW][kHeadDim];   // wave-private merge slices
+  __shared__ float sl[kAttnWaves][TPW];
+  __shared__ float pw[kAttnWaves][kHeadDim], pl[kAttnWaves];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if ((int)blockIdx.x >= p.work_blocks) {
-    smi_prefetch_range(p.pf_ptr, p.pf_bytes, ((int)blockIdx.x - p.work_blocks) * kAttnWaves * 64 + tid,
-                       ((int)gridDim.x - p.work_blocks) * kAttnWaves * 64);
-    return;
-  }
   const int head = blockIdx.x % p.n_heads, m = blockIdx.x / p.n_heads;
   const int tl = lane / LPT, dl = lane % LPT;
   const int grp = wave * TPW + tl;
@@ -602,22 +600,22 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
       sc[u] = (c0 + u * NGRP + grp < ctx) ? d : NEG;
       lmax = fmaxf(lmax, sc[u]);
     }
-    if (dl == 0) smax[grp] = lmax;
+    // wave max: inside a 16-lane row on the DPP path, across the four rows by readlane
+    lmax = fmaxf(lmax, smi_dpp<0x128>(lmax));   // row_ror:8
+    const float wm = fmaxf(fmaxf(smi_readlane(lmax, 0), smi_readlane(lmax, 16)), fmaxf(smi_readlane(lmax, 32), smi_readlane(lmax, 48)));
+    if (lane == 0) wmax[wave] = wm;
     __syncthreads();
-    float bm = NEG;
+    float bm = wmax[0];
 #pragma unroll
-    for (int i = 0; i < NGRP / 4; ++i) {
-      const float4 v = *(const float4*)&smax[4 * i];
-      bm = fmaxf(bm, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
-    }
+    for (int w = 1; w < kAttnWaves; ++w) bm = fmaxf(bm, wmax[w]);
     const float mn = fmaxf(m_run, bm);
-    const float a = expf(m_run - mn);
+    const float a = exp2f((m_run - mn) * LOG2E);
     lrun *= a;
 #pragma unroll
     for (int i = 0; i < DPL; ++i) o[i] *= a;
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      const float e = sc[u] > 0.5f * NEG ? expf(sc[u] - mn) : 0.f;
+      const float e = sc[u] > 0.5f * NEG ? exp2f((sc[u] - mn) * LOG2E) : 0.f;
       const uint32_t vu[4] = {vr[u].x, vr[u].y, vr[u].z, vr[u].w};
       lrun += e;
       if (KVF32) {
@@ -632,35 +630,35 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
       }
     }
     m_run = mn;
-    if (c0 + NGRP * UNR < ctx) __syncthreads();   // smax is rewritten by the next chunk
+    if (c0 + NGRP * UNR < ctx) __syncthreads();   // wmax is rewritten by the next chunk
     c0 += NGRP * UNR;
   } while (c0 < ctx);
-  // every stream is at scale exp(-m_run): plain sums, fixed order
+  // every stream is at scale exp(-m_run): plain sums in fixed order.  Step 1, inside the wave.
 #pragma unroll
   for (int i = 0; i < DPL; i += 4)
-    *(float4*)&so[grp][dl * DPL + i] = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
-  if (dl == 0) sl[grp] = lrun;
-  __syncthreads();
-  if (tid < 256) {
-    const int d = tid & 63, qd = tid >> 6;
+    *(float4*)&so[wave][tl][dl * DPL + i] = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
+  if (dl == 0) sl[wave][tl] = lrun;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes have landed
+  {
     float O = 0.f, Ls = 0.f;
-#pragma unroll 8
-    for (int g = qd * (NGRP / 4); g < (qd + 1) * (NGRP / 4); ++g) { O += so[g][d]; Ls += sl[g]; }
-    so2[qd][d] = O;
-    if (d == 0) sl2[qd] = Ls;
+#pragma unroll
+    for (int g = 0; g < TPW; ++g) { O += so[wave][g][lane]; Ls += sl[wave][g]; }
+    pw[wave][lane] = O;
+    if (lane == 0) pl[wave] = Ls;
   }
   __syncthreads();
-  if (tid < kHeadDim) {
-    const float O = (so2[0][tid] + so2[1][tid]) + (so2[2][tid] + so2[3][tid]);
-    const float Ls = (sl2[0] + sl2[1]) + (sl2[2] + sl2[3]);
+  if (tid < kHeadDim) {   // step 2, across the waves
+    float O = 0.f, Ls = 0.f;
+#pragma unroll
+    for (int w = 0; w < kAttnWaves; ++w) { O += pw[w][tid]; Ls += pl[w]; }
     uint32_t hi, mi, lo;
     split3(O / Ls, hi, mi, lo);
     const int k = head * kHeadDim + tid;
-    const size_t o = xs_off(k >> 5, 0, (k >> 3) & 3, m, p.M) + (k & 7) * 2;
-    const size_t pl = (size_t)4 * p.M * 16;
-    *(uint16_t*)(p.xs_out + o) = (uint16_t)hi;
-    *(uint16_t*)(p.xs_out + o + pl) = (uint16_t)mi;
-    *(uint16_t*)(p.xs_out + o + 2 * pl) = (uint16_t)lo;
+    const size_t ob = xs_off(k >> 5, 0, (k >> 3) & 3, m, p.M) + (k & 7) * 2;
+    const size_t pl2 = (size_t)4 * p.M * 16;
+    *(uint16_t*)(p.xs_out + ob) = (uint16_t)hi;
+    *(uint16_t*)(p.xs_out + ob + pl2) = (uint16_t)mi;
+    *(uint16_t*)(p.xs_out + ob + 2 * pl2) = (uint16_t)lo;
   }
 }
 
@@ -975,6 +973,7 @@ struct smi_llm {
   float* logits; int* tok;
   unsigned long long* stamps; int stamps_on;
   int max_steps;
+  int tune[4];   // SPARKMI_TUNE block-shape selectors (diagnostics)
   hipGraphExec_t graph; int graph_B;
   hipEvent_t ev0, ev1;
   // host staging
@@ -1042,7 +1041,11 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       p.rope = (const float2*)sec(L, SMI_LLM_ROPE, 0);
       p.kcache = kv_layer(L, L->kcache, layer); p.vcache = kv_layer(L, L->vcache, layer);
       p.q_dim = L->Q; p.kv_dim = L->KV; p.n_kv = c.num_kv_heads; p.max_pos = c.max_positions;
-      return launch_gemm<1, 4, 8, 1, PRO_NORM, EPI_QKV>(L, p, st);
+      switch (L->tune[0]) {   // SPARKMI_TUNE=q,o,g,d: block-shape sweeps (diagnostics; NW changes the summation order)
+        case 1: return launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_QKV>(L, p, st);
+        case 3: return launch_gemm<1, 4, 8, 1, PRO_NORM, EPI_QKV>(L, p, st);
+        default: return launch_gemm<1, 16, 2, 1, PRO_NORM, EPI_QKV>(L, p, st);   // measured best (profiles/README.md)
+      }
     case KATTN: {
       AttnP a;
       memset(&a, 0, sizeof(a));
@@ -1060,18 +1063,30 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       p.W = (const uint4*)sec(L, SMI_LLM_WO, layer); p.NT = L->NTh; p.KT = L->KTq;
       p.XS = L->xs_attn; p.Y = L->h;
       p.XSout = L->xs_h; p.gamma_next = (const float*)sec(L, SMI_LLM_LN2, layer); p.ssout = L->sspart;
-      return launch_gemm<1, 4, 8, 1, PRO_PLAIN, EPI_RESID>(L, p, st);
+      switch (L->tune[1]) {
+        case 2: return launch_gemm<1, 16, 2, 1, PRO_PLAIN, EPI_RESID>(L, p, st);
+        case 3: return launch_gemm<1, 4, 8, 1, PRO_PLAIN, EPI_RESID>(L, p, st);
+        default: return launch_gemm<1, 8, 4, 1, PRO_PLAIN, EPI_RESID>(L, p, st);
+      }
     case KGU:
       p.W = (const uint4*)sec(L, SMI_LLM_WGU, layer); p.NT = L->NTgu; p.KT = L->KTh;
       p.XS = L->xs_h; p.XSout = L->xs_act;
-      return launch_gemm<2, 4, 8, 1, PRO_NORM, EPI_SWIGLU>(L, p, st);
+      switch (L->tune[2]) {
+        case 2: return launch_gemm<1, 16, 2, 1, PRO_NORM, EPI_SWIGLU>(L, p, st);
+        case 5: return launch_gemm<2, 4, 8, 1, PRO_NORM, EPI_SWIGLU>(L, p, st);
+        default: return launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_SWIGLU>(L, p, st);
+      }
     case KD:   // h += Wd act; emits the next layer's input-norm operand (or the final norm's)
       p.W = (const uint4*)sec(L, SMI_LLM_WD, layer); p.NT = L->NTh; p.KT = L->KTi;
       p.XS = L->xs_act; p.Y = L->h;
       p.XSout = L->xs_h; p.ssout = L->sspart;
       p.gamma_next = layer + 1 < c.num_layers ? (const float*)sec(L, SMI_LLM_LN1, layer + 1)
                                               : (const float*)sec(L, SMI_LLM_FINAL_NORM, 0);
-      return launch_gemm<1, 8, 10, 2, PRO_PLAIN, EPI_RESID>(L, p, st);
+      switch (L->tune[3]) {
+        case 2: return launch_gemm<1, 16, 3, 4, PRO_PLAIN, EPI_RESID>(L, p, st);
+        case 4: return launch_gemm<1, 8, 10, 2, PRO_PLAIN, EPI_RESID>(L, p, st);
+        default: return launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID>(L, p, st);
+      }
     case KLM:
       p.W = (const uint4*)sec(L, SMI_LLM_LM_HEAD, 0); p.NT = L->NTlm; p.KT = L->KTh;
       p.XS = L->xs_h;
@@ -1194,6 +1209,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->lm_blocks = L->lm_cap < 512 ? L->lm_cap : 512;    // persistent path: 2 resident blocks per CU
   L->max_steps = cfg->max_positions;
   L->do_sample = 0; L->top_k = 50; L->temperature = 0.8f; L->top_p = 0.95f; L->seed = 0; L->logits = nullptr; L->tok = nullptr; L->stamps = nullptr; L->stamps_on = 0;
+  { L->tune[0] = L->tune[1] = L->tune[2] = L->tune[3] = 0; const char* e = getenv("SPARKMI_TUNE"); if (e) sscanf(e, "%d,%d,%d,%d", &L->tune[0], &L->tune[1], &L->tune[2], &L->tune[3]); }
   L->graph = nullptr; L->graph_B = 0; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->eos = -1;
   const size_t esz = cfg->kv_dtype ? 4 : 2;
   L->kv_layer_elems = (size_t)cfg->max_slots * cfg->num_kv_heads * cfg->max_positions * kHeadDim;

@@ -21,6 +21,8 @@ print("variant", os.environ.get("SPARKMI_VARIANT", "0"), out, "graph step", step
 ''' % ROOT
 for v in sys.argv[1:] or ["0", "1", "2", "3", "4", "5", "6", "7"]:
     env = dict(os.environ, SPARKMI_VARIANT=v)
+    if v.startswith("tune:"):
+        env = dict(os.environ, SPARKMI_TUNE=v[5:], SPARKMI_VARIANT=v)
     if v.startswith("lib:"):
         env = dict(os.environ, SPARKMI_LIB=os.path.join(ROOT, v[4:]), SPARKMI_VARIANT="lib")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
