@@ -376,6 +376,173 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Prefill GEMM: many rows (a whole batch of prompts) against one weight matrix, no split-K.
+// Block = 4 waves = 8 weight tiles (128 output columns) x 128 rows; each wave owns 2 weight tiles
+// (A operands straight from HBM, used for all 8 m-tiles) and the block shares the rows' operand
+// triples through a double-buffered LDS image (24 KB per k tile), so a weight tile is read once per
+// 128 rows and an operand piece once per 128 output columns.  One accumulator per (tile, m-tile),
+// terms in the order lo, mid, hi per k tile: a row's result does not depend on M or on the batch.
+// ------------------------------------------------------------------------------------------
+template <int PRO, int EPI, int KVF32>
+__global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
+  constexpr int NTW = 2, MTB = 8, ROWS = MTB * 16, PIECES = 3 * 4 * ROWS;   // 1536 16-byte pieces per k tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* Bs = (uint4*)smem;                              // [2][PIECES]
+  float* rarr = (float*)(smem + (size_t)2 * PIECES * 16);  // [ROWS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int KT = p.KT, M = p.M, NT = p.NT;
+  const int m0 = blockIdx.y * ROWS;
+  const int k8 = lane >> 4, em = lane & 15;
+  int nts[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) { const int nt = ((int)blockIdx.x * 4 + wave) * NTW + i; nts[i] = nt < NT ? nt : NT - 1; }
+
+  uint4 sreg[PIECES / 256];
+  auto stage_load = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < PIECES / 256; ++i) {
+      const int q = tid + 256 * i;                       // [s][k8][row]
+      int row = m0 + (q & (ROWS - 1));
+      row = row < M ? row : M - 1;
+      sreg[i] = *(const uint4*)(p.XS + xs_off(kt, q / (4 * ROWS), (q / ROWS) & 3, row, M));
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PIECES / 256; ++i) Bs[buf * PIECES + tid + 256 * i] = sreg[i];
+  };
+  stage_load(0);
+  if (PRO == PRO_NORM) {
+    for (int r = wave; r < ROWS; r += 4) {
+      int m = m0 + r;
+      m = m < M ? m : M - 1;
+      float v = 0.f;
+      for (int i = lane; i < p.npart; i += 64) v += p.sspart[(size_t)m * p.npart + i];
+      v = smi_wave_sum(v);
+      if (lane == 0) rarr[r] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
+    }
+  }
+  f32x4 acc[NTW][MTB];
+#pragma unroll
+  for (int a = 0; a < NTW; ++a)
+#pragma unroll
+    for (int b = 0; b < MTB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  stage_store(0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    uint4 wA[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) wA[i] = p.W[((size_t)nts[i] * KT + kt) * 64 + lane];
+    if (kt + 1 < KT) stage_load(kt + 1);                 // in flight during this tile's MFMAs
+    const uint4* Bb = Bs + buf * PIECES;
+#pragma unroll
+    for (int mt = 0; mt < MTB; ++mt) {
+      bf16x8 b[3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) b[s] = __builtin_bit_cast(bf16x8, Bb[(s * 4 + k8) * ROWS + mt * 16 + em]);
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        const bf16x8 a = __builtin_bit_cast(bf16x8, wA[i]);
+        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[2], acc[i][mt], 0, 0, 0);
+        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[1], acc[i][mt], 0, 0, 0);
+        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[0], acc[i][mt], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < KT) {
+      stage_store(buf ^ 1);                              // the other buffer was last read two barriers ago
+      __syncthreads();
+    }
+  }
+  // ---- epilogue (same arithmetic as k_gemm's)
+  const int N = NT * 16;
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    const int nt = ((int)blockIdx.x * 4 + wave) * NTW + i;
+    if (nt >= NT) continue;   // wave-uniform
+    const int n = nt * 16 + 4 * (lane >> 4);
+#pragma unroll
+    for (int mt = 0; mt < MTB; ++mt) {
+      const int m = m0 + mt * 16 + em;
+      const bool valid = m < M;
+      float4 s = make_float4(acc[i][mt][0], acc[i][mt][1], acc[i][mt][2], acc[i][mt][3]);
+      if (PRO == PRO_NORM) {
+        const float r = rarr[mt * 16 + em];
+        s.x *= r; s.y *= r; s.z *= r; s.w *= r;
+      }
+      if (EPI == EPI_RESID) {
+        float ssq = 0.f;
+        if (valid) {
+          float4 h = *(const float4*)(p.Y + (size_t)m * N + n);
+          h.x += s.x; h.y += s.y; h.z += s.z; h.w += s.w;
+          *(float4*)(p.Y + (size_t)m * N + n) = h;
+          ssq = (h.x * h.x + h.y * h.y) + (h.z * h.z + h.w * h.w);
+          const float4 g = *(const float4*)(p.gamma_next + n);
+          const float t[4] = {g.x * h.x, g.y * h.y, g.z * h.z, g.w * h.w};
+          uint32_t hi[4], mi[4], lo[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split3(t[e], hi[e], mi[e], lo[e]);
+          const size_t o = xs_off(n >> 5, 0, (n >> 3) & 3, m, M) + ((n >> 2) & 1) * 8;
+          const size_t pl = (size_t)4 * M * 16;
+          *(uint2*)(p.XSout + o) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+          *(uint2*)(p.XSout + o + pl) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
+          *(uint2*)(p.XSout + o + 2 * pl) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+        }
+        ssq += __shfl_xor(ssq, 16, 64);
+        ssq += __shfl_xor(ssq, 32, 64);
+        if (lane < 16 && valid) p.ssout[(size_t)m * NT + nt] = ssq;
+      } else if (EPI == EPI_SWIGLU) {
+        if (valid) {
+          const float a0 = (s.x / (1.0f + expf(-s.x))) * s.y;
+          const float a1 = (s.z / (1.0f + expf(-s.z))) * s.w;
+          uint32_t h0, q0, l0, h1, q1, l1;
+          split3(a0, h0, q0, l0);
+          split3(a1, h1, q1, l1);
+          const int k = n >> 1;
+          const size_t o = xs_off(k >> 5, 0, (k >> 3) & 3, m, M) + ((k >> 1) & 3) * 4;
+          const size_t pl = (size_t)4 * M * 16;
+          *(uint32_t*)(p.XSout + o) = h0 | (h1 << 16);
+          *(uint32_t*)(p.XSout + o + pl) = q0 | (q1 << 16);
+          *(uint32_t*)(p.XSout + o + 2 * pl) = l0 | (l1 << 16);
+        }
+      } else if (EPI == EPI_QKV) {
+        if (valid) {
+          const float4 b = *(const float4*)(p.bias + n);
+          s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+          const RowDesc rd = p.rows[m];
+          if (n < p.q_dim + p.kv_dim) {
+            const int i0 = (n & 63) >> 1;
+            const float2 c0 = p.rope[(size_t)rd.pos * 32 + i0], c1 = p.rope[(size_t)rd.pos * 32 + i0 + 1];
+            float4 r;
+            r.x = __fadd_rn(__fmul_rn(s.x, c0.x), __fmul_rn(-s.y, c0.y));
+            r.y = __fadd_rn(__fmul_rn(s.y, c0.x), __fmul_rn(s.x, c0.y));
+            r.z = __fadd_rn(__fmul_rn(s.z, c1.x), __fmul_rn(-s.w, c1.y));
+            r.w = __fadd_rn(__fmul_rn(s.w, c1.x), __fmul_rn(s.z, c1.y));
+            s = r;
+          }
+          if (n < p.q_dim) {
+            *(float4*)(p.Y + (size_t)m * p.q_dim + n) = s;
+          } else {
+            const bool isk = n < p.q_dim + p.kv_dim;
+            const int c = n - p.q_dim - (isk ? 0 : p.kv_dim);
+            const size_t off = (((size_t)rd.slot * p.n_kv + (c >> 6)) * p.max_pos + rd.pos) * 64 + (c & 63);
+            void* base = isk ? p.kcache : p.vcache;
+            if (KVF32) {
+              *(float4*)((float*)base + off) = s;
+            } else {
+              uint2 pk;
+              pk.x = smi_f32_to_bf16(s.x) | (smi_f32_to_bf16(s.y) << 16);
+              pk.y = smi_f32_to_bf16(s.z) | (smi_f32_to_bf16(s.w) << 16);
+              *(uint2*)((uint16_t*)base + off) = pk;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // lm_head for up to 16 rows: persistent blocks.  The activation triples of the wave's k tiles are
 // loaded once and stay in registers; the block then streams groups of two 16-row vocabulary tiles
 // (next group's weights requested as soon as the MFMAs have consumed the current ones) and keeps
@@ -960,6 +1127,8 @@ struct smi_llm {
   float *h, *qbuf;
   unsigned char *xs_h, *xs_attn, *xs_act;   // GEMM operands as exact bf16 triples ([K/32][3][4][M][16 B])
   float* sspart;       // [32][NTh] partial sums of squares of h (RMSNorm)
+  // prefill workspace for up to big_rows rows at once (allocated at the first multi-chunk prefill)
+  float *bh, *bq; unsigned char *bxs_h, *bxs_attn, *bxs_act; float* bss; int big_rows;
   RowDesc* rows;       // live decode rows [32]
   RowDesc* plan;       // prefill plan
   size_t plan_cap;     // rows
@@ -1126,6 +1295,83 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
   return SMI_EINVAL;
 }
 
+// One prefill GEMM over M rows (any M) with k_pgemm; `which` as in launch_one (GEMM kernels only).
+template <int PRO, int EPI>
+int launch_pgemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
+  const dim3 grid((p.NT + 7) / 8, (p.M + 127) / 128);
+  const size_t lds = (size_t)2 * 1536 * 16 + 128 * 4;
+  if (L->cfg.kv_dtype) hipLaunchKernelGGL((k_pgemm<PRO, EPI, 1>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((k_pgemm<PRO, EPI, 0>), grid, dim3(256), lds, st, p);
+  SMI_LAUNCH_CHECK();
+  return SMI_OK;
+}
+
+// All layers for M (> 32) prompt rows living in the big workspace: K/V of every row appended, hidden
+// states of the last layer never needed (no prompt row except each sequence's last feeds lm_head).
+int launch_layers_big(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
+  const smi_llm_cfg& c = L->cfg;
+  int rc;
+  for (int l = 0; l < c.num_layers; ++l) {
+    GemmP p;
+    memset(&p, 0, sizeof(p));
+    p.M = M; p.rows = rows; p.eps = c.rms_eps; p.sspart = L->bss; p.npart = L->NTh;
+    // QKV
+    p.W = (const uint4*)sec(L, SMI_LLM_WQKV, l); p.NT = L->NTqkv; p.KT = L->KTh; p.XS = L->bxs_h;
+    p.Y = L->bq; p.bias = (const float*)sec(L, SMI_LLM_BQKV, l); p.rope = (const float2*)sec(L, SMI_LLM_ROPE, 0);
+    p.kcache = kv_layer(L, L->kcache, l); p.vcache = kv_layer(L, L->vcache, l);
+    p.q_dim = L->Q; p.kv_dim = L->KV; p.n_kv = c.num_kv_heads; p.max_pos = c.max_positions;
+    if ((rc = launch_pgemm<PRO_NORM, EPI_QKV>(L, p, st))) return rc;
+    if (l == c.num_layers - 1) break;
+    // attention
+    AttnP a;
+    memset(&a, 0, sizeof(a));
+    a.q = L->bq; a.kcache = p.kcache; a.vcache = p.vcache; a.rows = rows; a.xs_out = L->bxs_attn; a.M = M;
+    a.q_dim = L->Q; a.n_kv = c.num_kv_heads; a.group = c.num_heads / c.num_kv_heads; a.max_pos = c.max_positions;
+    a.n_heads = c.num_heads; a.work_blocks = c.num_heads * M; a.slot_is_row = 0;
+    if (c.kv_dtype) hipLaunchKernelGGL(k_attn<1>, dim3(a.work_blocks), dim3(kAttnWaves * 64), 0, st, a);
+    else hipLaunchKernelGGL(k_attn<0>, dim3(a.work_blocks), dim3(kAttnWaves * 64), 0, st, a);
+    SMI_LAUNCH_CHECK();
+    // o_proj
+    GemmP o;
+    memset(&o, 0, sizeof(o));
+    o.M = M; o.rows = rows; o.eps = c.rms_eps; o.sspart = L->bss; o.npart = L->NTh;
+    o.W = (const uint4*)sec(L, SMI_LLM_WO, l); o.NT = L->NTh; o.KT = L->KTq; o.XS = L->bxs_attn; o.Y = L->bh;
+    o.XSout = L->bxs_h; o.gamma_next = (const float*)sec(L, SMI_LLM_LN2, l); o.ssout = L->bss;
+    if ((rc = launch_pgemm<PRO_PLAIN, EPI_RESID>(L, o, st))) return rc;
+    // gate_up
+    GemmP g;
+    memset(&g, 0, sizeof(g));
+    g.M = M; g.rows = rows; g.eps = c.rms_eps; g.sspart = L->bss; g.npart = L->NTh;
+    g.W = (const uint4*)sec(L, SMI_LLM_WGU, l); g.NT = L->NTgu; g.KT = L->KTh; g.XS = L->bxs_h; g.XSout = L->bxs_act;
+    if ((rc = launch_pgemm<PRO_NORM, EPI_SWIGLU>(L, g, st))) return rc;
+    // down
+    GemmP d;
+    memset(&d, 0, sizeof(d));
+    d.M = M; d.rows = rows; d.eps = c.rms_eps; d.sspart = L->bss; d.npart = L->NTh;
+    d.W = (const uint4*)sec(L, SMI_LLM_WD, l); d.NT = L->NTh; d.KT = L->KTi; d.XS = L->bxs_act; d.Y = L->bh;
+    d.XSout = L->bxs_h; d.ssout = L->bss; d.gamma_next = (const float*)sec(L, SMI_LLM_LN1, l + 1);
+    if ((rc = launch_pgemm<PRO_PLAIN, EPI_RESID>(L, d, st))) return rc;
+  }
+  return SMI_OK;
+}
+
+int ensure_big(smi_llm* L, int rows) {
+  if (rows <= L->big_rows) return SMI_OK;
+  void* old[] = {L->bh, L->bq, L->bxs_h, L->bxs_attn, L->bxs_act, L->bss};
+  for (void* q : old)
+    if (q) (void)hipFree(q);
+  L->bh = L->bq = nullptr; L->bxs_h = L->bxs_attn = L->bxs_act = nullptr; L->bss = nullptr; L->big_rows = 0;
+  const size_t R = (size_t)rows;
+  if (hipMalloc((void**)&L->bh, R * L->H * 4) != hipSuccess || hipMalloc((void**)&L->bq, R * L->Q * 4) != hipSuccess ||
+      hipMalloc((void**)&L->bxs_h, R * L->H * 6) != hipSuccess || hipMalloc((void**)&L->bxs_attn, R * L->Q * 6) != hipSuccess ||
+      hipMalloc((void**)&L->bxs_act, R * L->I * 6) != hipSuccess || hipMalloc((void**)&L->bss, R * L->NTh * 4) != hipSuccess) {
+    smi_set_error("hipMalloc(prefill workspace for %d rows) failed", rows);
+    return SMI_ENOMEM;
+  }
+  L->big_rows = rows;
+  return SMI_OK;
+}
+
 int launch_embed(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
   hipLaunchKernelGGL(k_embed, dim3((M + 3) / 4), dim3(256), 0, st, (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0), L->KTh, rows, M,
                      (const float*)sec(L, SMI_LLM_LN1, 0), L->h, L->xs_h, L->sspart, L->NTh);
@@ -1210,6 +1456,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->max_steps = cfg->max_positions;
   L->do_sample = 0; L->top_k = 50; L->temperature = 0.8f; L->top_p = 0.95f; L->seed = 0; L->logits = nullptr; L->tok = nullptr; L->stamps = nullptr; L->stamps_on = 0;
   { L->tune[0] = L->tune[1] = L->tune[2] = L->tune[3] = 0; const char* e = getenv("SPARKMI_TUNE"); if (e) sscanf(e, "%d,%d,%d,%d", &L->tune[0], &L->tune[1], &L->tune[2], &L->tune[3]); }
+  L->bh = L->bq = nullptr; L->bxs_h = L->bxs_attn = L->bxs_act = nullptr; L->bss = nullptr; L->big_rows = 0;
   L->graph = nullptr; L->graph_B = 0; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->eos = -1;
   const size_t esz = cfg->kv_dtype ? 4 : 2;
   L->kv_layer_elems = (size_t)cfg->max_slots * cfg->num_kv_heads * cfg->max_positions * kHeadDim;
@@ -1266,7 +1513,7 @@ int smi_llm_destroy(smi_llm* L) {
   if (!L) return SMI_OK;
   if (L->graph) (void)hipGraphExecDestroy(L->graph);
   void* ptrs[] = {L->h, L->qbuf, L->xs_h, L->xs_attn, L->xs_act, L->sspart, L->rows, L->plan, L->pval, L->pidx, L->hist,
-                  L->count, L->finished, L->step, L->kcache, L->vcache, L->logits, L->tok, L->stamps};
+                  L->count, L->finished, L->step, L->kcache, L->vcache, L->logits, L->tok, L->stamps, L->bh, L->bq, L->bxs_h, L->bxs_attn, L->bxs_act, L->bss};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (L->ev0) (void)hipEventDestroy(L->ev0);
@@ -1323,11 +1570,25 @@ int smi_llm_prefill(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, 
   for (int b = 0; b < B; ++b) L->max_len = lens[b] > L->max_len ? lens[b] : L->max_len;
   L->steps_launched = 1;
   if (L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }  // eos / B are baked into the graph
-  for (size_t c = 0; c < nchunks; ++c) {
-    const int M = (int)((total - c * kMaxRows) < (size_t)kMaxRows ? (total - c * kMaxRows) : kMaxRows);
-    const RowDesc* rows = L->plan + c * kMaxRows;
-    if ((rc = launch_embed(L, rows, M, st))) return rc;
-    if ((rc = launch_layers(L, rows, M, true, st))) return rc;
+  if (total > (size_t)kMaxRows && !getenv("SPARKMI_PREFILL_CHUNKS")) {
+    // many prompt rows: whole groups of up to kBigRows rows through the prefill GEMM (k_pgemm)
+    constexpr size_t kBigRows = 4096;
+    if ((rc = ensure_big(L, (int)(total < kBigRows ? total : kBigRows)))) return rc;
+    for (size_t r0 = 0; r0 < total; r0 += kBigRows) {
+      const int M = (int)((total - r0) < kBigRows ? (total - r0) : kBigRows);
+      const RowDesc* rows = L->plan + r0;
+      hipLaunchKernelGGL(k_embed, dim3((M + 3) / 4), dim3(256), 0, st, (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0), L->KTh, rows, M,
+                         (const float*)sec(L, SMI_LLM_LN1, 0), L->bh, L->bxs_h, L->bss, L->NTh);
+      SMI_LAUNCH_CHECK();
+      if ((rc = launch_layers_big(L, rows, M, st))) return rc;
+    }
+  } else {
+    for (size_t c = 0; c < nchunks; ++c) {
+      const int M = (int)((total - c * kMaxRows) < (size_t)kMaxRows ? (total - c * kMaxRows) : kMaxRows);
+      const RowDesc* rows = L->plan + c * kMaxRows;
+      if ((rc = launch_embed(L, rows, M, st))) return rc;
+      if ((rc = launch_layers(L, rows, M, true, st))) return rc;
+    }
   }
   SMI_HIP(hipMemcpyAsync(L->rows, L->plan + nchunks * kMaxRows, kMaxRows * sizeof(RowDesc), hipMemcpyDeviceToDevice, st));
   if ((rc = launch_embed(L, L->rows, B, st))) return rc;
