@@ -1570,7 +1570,8 @@ int smi_llm_prefill(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, 
   for (int b = 0; b < B; ++b) L->max_len = lens[b] > L->max_len ? lens[b] : L->max_len;
   L->steps_launched = 1;
   if (L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }  // eos / B are baked into the graph
-  if (total > (size_t)kMaxRows && !getenv("SPARKMI_PREFILL_CHUNKS")) {
+  // measured crossover (profiles/README.md): 32-row chunks cost ~1.4 ms each, the prefill GEMM ~16 ms + 5 us/row
+  if (total >= 384 && !getenv("SPARKMI_PREFILL_CHUNKS")) {
     // many prompt rows: whole groups of up to kBigRows rows through the prefill GEMM (k_pgemm)
     constexpr size_t kBigRows = 4096;
     if ((rc = ensure_big(L, (int)(total < kBigRows ? total : kBigRows)))) return rc;

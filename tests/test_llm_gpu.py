@@ -202,3 +202,19 @@ def test_full_size_batch_is_bit_identical_to_single_runs():
     one.prefill([ids.tolist()])          # last row runs as an M=1 step with sampling off; compare via argmax + top logits
     step_tok = one.tokens(1)[0][0]
     assert int(chunked.argmax()) == step_tok
+
+
+def test_prefill_gemm_path_matches_chunked_prefill(tiny, monkeypatch):
+    """>= 384 prompt rows go through the prefill GEMM (k_pgemm); the generated tokens must equal the
+    32-row-chunk path's and the oracle's."""
+    cfg, syn = tiny
+    rng = np.random.Generator(np.random.PCG64(314))
+    B = 12
+    prompts = [rng.integers(0, cfg.vocab_size, size=int(rng.integers(30, 60))).tolist() for _ in range(B)]
+    assert sum(len(p) - 1 for p in prompts) >= 384
+    big = _llm(cfg, syn, max_slots=B, max_positions=96).generate_ids(prompts, 16)
+    monkeypatch.setenv("SPARKMI_PREFILL_CHUNKS", "1")
+    chunked = _llm(cfg, syn, max_slots=B, max_positions=96).generate_ids(prompts, 16)
+    assert big == chunked
+    for b in (0, 5, 11):
+        assert Qwen2Ref(cfg, syn, kv_dtype="bf16").generate_greedy(prompts[b], 16) == big[b]
