@@ -61,9 +61,12 @@ __device__ __forceinline__ float snake_f(float x, float a) {
 __device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // QB: 32-wide time sub-tiles per wave.  KS: waves split the input channels of ONE 32-row output
-// tile (large C, short T) instead of owning a 32-row output tile each.
-template <int QB, bool KS>
+// tile (large C, short T) instead of owning a 32-row output tile each.  CHG: a staged chunk holds
+// 32*CHG input channels (1-tap layers use 128 so a chunk carries enough MFMAs per barrier).  WIDE:
+// the staged row (tile + halo) is wider than 64 columns.
+template <int QB, bool KS, int CHG, bool WIDE>
 __global__ __launch_bounds__(256) void k_conv(ConvP p) {
+  constexpr int kCh = kChunk * CHG;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int QT = QB * 32;
@@ -89,14 +92,15 @@ __global__ __launch_bounds__(256) void k_conv(ConvP p) {
   // The next chunk's rows are requested before the MFMAs of the current one and written to LDS after
   // them, so global latency hides behind the matrix pipe.  With KS each wave multiplies exactly the
   // rows it staged, so only the wave itself has to see its LDS writes (no block barrier).
-  float sreg[8][2];
+  constexpr int RW = 8 * CHG, NC = WIDE ? 2 : 1;   // rows staged per wave, column registers per row
+  float sreg[RW][NC];
   auto stage_load = [&](int c0) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int ci = c0 + wave * 8 + r;
+    for (int r = 0; r < RW; ++r) {
+      const int ci = c0 + wave * RW + r;
       const float* xr = Xb + (long long)ci * p.xstride;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < NC; ++k) {
         const int col = lane + 64 * k, t = q0 - p.halo_l + col;
         sreg[r][k] = (ci < p.Cin && col < xw && t >= 0 && t < len) ? xr[t] : 0.f;
       }
@@ -104,20 +108,20 @@ __global__ __launch_bounds__(256) void k_conv(ConvP p) {
   };
   auto stage_store = [&]() {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      float* lr = lds + (wave * 8 + r) * xw;
+    for (int r = 0; r < RW; ++r) {
+      float* lr = lds + (wave * RW + r) * xw;
       if (lane < xw) lr[lane] = sreg[r][0];
-      if (lane + 64 < xw) lr[lane + 64] = sreg[r][1];
+      if (WIDE && lane + 64 < xw) lr[lane + 64] = sreg[r][NC - 1];
     }
   };
   stage_load(0);
-  for (int c0 = 0; c0 < p.CinP; c0 += kChunk) {
-    if (c0) { if (KS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads(); }   // chunk c0-32 fully read
+  for (int c0 = 0; c0 < p.CinP; c0 += kCh) {
+    if (c0) { if (KS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads(); }   // previous chunk fully read
     stage_store();
     if (KS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads();
-    if (c0 + kChunk < p.CinP) stage_load(c0 + kChunk);
+    if (c0 + kCh < p.CinP) stage_load(c0 + kCh);
     if (live) {
-      const int g0 = KS ? wave : 0, g1 = KS ? wave + 1 : 4;
+      const int g0 = KS ? wave * CHG : 0, g1 = KS ? (wave + 1) * CHG : 4 * CHG;
       for (int tap = 0; tap < ntap; ++tap) {
         const int col0 = p.halo_l + p.off[phase][tap] + (lane & 31);
         for (int g = g0; g < g1; ++g) {
@@ -184,6 +188,37 @@ __global__ __launch_bounds__(256) void k_conv(ConvP p) {
   }
 }
 
+// Linear layer on one vector per utterance (d-vector projection, AdaLN parameters): y[b][co] =
+// bias[co] + sum_ci W[co][ci] x[b][ci], fp32, reading the same packed conv weights (lane l, slot j of
+// group g holds W[32*ct + (l&31)][8g + 2j + (l>>5)]).  One block per 32 outputs, waves split K.
+__global__ __launch_bounds__(256) void k_gemv1(ConvP p) {
+  __shared__ float part[4][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ct = blockIdx.x, b = blockIdx.y;
+  const int groups = p.CinP >> 3;
+  const float4* Wp = (const float4*)p.W + (long long)ct * groups * 64;
+  const float* x = p.X + (long long)b * p.xb;           // xstride == 1: x[ci]
+  float acc = 0.f;
+  for (int g = wave; g < groups; g += 4) {
+    const float4 w = Wp[(long long)g * 64 + lane];
+    const int ci = g * 8 + (lane >> 5);
+    const float x0 = ci < p.Cin ? x[ci] : 0.f, x1 = ci + 2 < p.Cin ? x[ci + 2] : 0.f;
+    const float x2 = ci + 4 < p.Cin ? x[ci + 4] : 0.f, x3 = ci + 6 < p.Cin ? x[ci + 6] : 0.f;
+    acc += (w.x * x0 + w.y * x1) + (w.z * x2 + w.w * x3);
+  }
+  acc += __shfl_xor(acc, 32, 64);
+  if (lane < 32) part[wave][lane] = acc;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int co = ct * 32 + threadIdx.x;
+    if (co < p.Cout) {
+      float y = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+      if (p.bias) y += p.bias[co];
+      p.Y[(long long)b * p.yb + co] = y;
+    }
+  }
+}
+
 // depthwise conv7 (optional) + LayerNorm / AdaLayerNorm over channels, eps 1e-6 (vocos.py:65-110)
 struct LnP {
   const float* X;      // [B][C][stride]
@@ -199,11 +234,11 @@ struct LnP {
   int triple;          // 1: write 3x (SamplingBlock ratio 1 after final_layer_norm)
 };
 
-template <int CPT>  // channels per thread (C <= 8*CPT)
+template <int CPT>  // channels per thread (C <= 32*CPT): 8 time steps x 32 channel groups per block
 __global__ __launch_bounds__(256) void k_dwln(LnP p) {
-  __shared__ float red[8][32];
-  const int tt = threadIdx.x & 31, cg = threadIdx.x >> 5;
-  const int b = blockIdx.y, t = blockIdx.x * 32 + tt;
+  __shared__ float red[32][8];
+  const int tt = threadIdx.x & 7, cg = threadIdx.x >> 3;
+  const int b = blockIdx.y, t = blockIdx.x * 8 + tt;
   const int len = p.lens[b];
   const bool tv = t < len;
   const float* Xb = p.X + (long long)b * p.bs;
@@ -211,7 +246,7 @@ __global__ __launch_bounds__(256) void k_dwln(LnP p) {
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int c = cg + 8 * i;
+    const int c = cg + 32 * i;
     float x = 0.f;
     if (c < p.C && tv) {
       const float* xr = Xb + (long long)c * p.stride;
@@ -235,26 +270,26 @@ __global__ __launch_bounds__(256) void k_dwln(LnP p) {
   __syncthreads();
   float mean = 0.f;
 #pragma unroll
-  for (int g = 0; g < 8; ++g) mean += red[g][tt];
+  for (int g = 0; g < 32; ++g) mean += red[g][tt];
   mean /= (float)p.C;
   __syncthreads();
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int c = cg + 8 * i;
+    const int c = cg + 32 * i;
     if (c < p.C) { const float d = v[i] - mean; q += d * d; }
   }
   red[cg][tt] = q;
   __syncthreads();
   float var = 0.f;
 #pragma unroll
-  for (int g = 0; g < 8; ++g) var += red[g][tt];
+  for (int g = 0; g < 32; ++g) var += red[g][tt];
   const float rstd = 1.0f / sqrtf(var / (float)p.C + 1e-6f);
   if (!tv) return;
   float* Yb = p.Y + (long long)b * p.bs;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int c = cg + 8 * i;
+    const int c = cg + 32 * i;
     if (c >= p.C) continue;
     float y = (v[i] - mean) * rstd;
     if (p.ada) y = y * p.ada[(long long)b * p.ada_stride + c] + p.ada[(long long)b * p.ada_stride + p.C + c];
@@ -467,7 +502,7 @@ struct Launch {
   int kind;          // 0 conv, 1 dwln, 2 codebook, 3 fsq, 4 zero-tail
   std::string name;
   double flops;
-  ConvP cp; int qb; bool ks; dim3 grid; size_t lds;
+  ConvP cp; int qb; bool ks; int chg; bool gemv; dim3 grid; size_t lds;
   LnP lp; int cpt;
   // small kernels keep their args here
   const int64_t* sem; int semstride; const float* cb; int D, cbsize; float* Z; int zstride; long long zb;
@@ -504,19 +539,29 @@ const float* ent(const smi_voc* h, const std::string& name) {
 int run_launch(const Launch& L, hipStream_t st) {
   switch (L.kind) {
     case 0:
-      if (L.ks) {
-        if (L.qb == 1) hipLaunchKernelGGL((k_conv<1, true>), L.grid, dim3(256), L.lds, st, L.cp);
-        else hipLaunchKernelGGL((k_conv<2, true>), L.grid, dim3(256), L.lds, st, L.cp);
+      if (L.gemv) {
+        hipLaunchKernelGGL(k_gemv1, L.grid, dim3(256), 0, st, L.cp);
+      } else if (L.chg == 4) {      // 1-tap layers: 128-channel chunks, narrow rows
+        if (L.ks) {
+          if (L.qb == 1) hipLaunchKernelGGL((k_conv<1, true, 4, false>), L.grid, dim3(256), L.lds, st, L.cp);
+          else hipLaunchKernelGGL((k_conv<2, true, 4, false>), L.grid, dim3(256), L.lds, st, L.cp);
+        } else {
+          if (L.qb == 1) hipLaunchKernelGGL((k_conv<1, false, 4, false>), L.grid, dim3(256), L.lds, st, L.cp);
+          else hipLaunchKernelGGL((k_conv<2, false, 4, false>), L.grid, dim3(256), L.lds, st, L.cp);
+        }
+      } else if (L.ks) {
+        if (L.qb == 1) hipLaunchKernelGGL((k_conv<1, true, 1, true>), L.grid, dim3(256), L.lds, st, L.cp);
+        else hipLaunchKernelGGL((k_conv<2, true, 1, true>), L.grid, dim3(256), L.lds, st, L.cp);
       } else {
-        if (L.qb == 1) hipLaunchKernelGGL((k_conv<1, false>), L.grid, dim3(256), L.lds, st, L.cp);
-        else hipLaunchKernelGGL((k_conv<2, false>), L.grid, dim3(256), L.lds, st, L.cp);
+        if (L.qb == 1) hipLaunchKernelGGL((k_conv<1, false, 1, true>), L.grid, dim3(256), L.lds, st, L.cp);
+        else hipLaunchKernelGGL((k_conv<2, false, 1, true>), L.grid, dim3(256), L.lds, st, L.cp);
       }
       break;
     case 1:
-      if (L.cpt <= 8) hipLaunchKernelGGL(k_dwln<8>, L.grid, dim3(256), 0, st, L.lp);
-      else if (L.cpt <= 16) hipLaunchKernelGGL(k_dwln<16>, L.grid, dim3(256), 0, st, L.lp);
-      else if (L.cpt <= 48) hipLaunchKernelGGL(k_dwln<48>, L.grid, dim3(256), 0, st, L.lp);
-      else hipLaunchKernelGGL(k_dwln<64>, L.grid, dim3(256), 0, st, L.lp);
+      if (L.cpt <= 2) hipLaunchKernelGGL(k_dwln<2>, L.grid, dim3(256), 0, st, L.lp);
+      else if (L.cpt <= 4) hipLaunchKernelGGL(k_dwln<4>, L.grid, dim3(256), 0, st, L.lp);
+      else if (L.cpt <= 12) hipLaunchKernelGGL(k_dwln<12>, L.grid, dim3(256), 0, st, L.lp);
+      else hipLaunchKernelGGL(k_dwln<16>, L.grid, dim3(256), 0, st, L.lp);
       break;
     case 2:
       hipLaunchKernelGGL(k_codebook, L.grid, dim3(128), 0, st, L.sem, L.semstride, L.cb, L.D, L.cbsize, L.lens, L.Z, L.zstride, L.zb);
@@ -562,7 +607,9 @@ Launch make_conv(const smi_voc* h, const std::string& name, const std::string& w
   p.halo_l = g.halo_l;
   p.xw = qt + g.halo_l + g.halo_r;
   L.grid = dim3(nq, L.ks ? cot : (cot + 3) / 4, B * S);
-  size_t lds = (size_t)kChunk * p.xw * 4;
+  L.chg = (S == 1 && K == 1 && Cin >= 128) ? 4 : 1;     // 1-tap layers stage 128 channels per chunk
+  L.gemv = false;   // set by the caller for the per-utterance vector projections (use_gemv)
+  size_t lds = (size_t)kChunk * L.chg * p.xw * 4;
   const size_t red = L.ks ? (size_t)4 * qb * 16 * 64 * 4 : 0;
   L.lds = lds > red ? lds : red;
   double taps = 0;
@@ -715,6 +762,8 @@ int smi_voc_forward(smi_voc* h, const int64_t* sem_dev, const int32_t* lens_host
   P.push_back(make_conv(h, "spk_project", "speaker_encoder.project.weight", "speaker_encoder.project.bias",
                         c.spk_out_dim, latn, 1, 1, 1, 0, lat, 1, latn, dvec, nullptr, nullptr, nullptr, 1, c.spk_out_dim,
                         len1, B, 1, ACT_NONE));
+  auto use_gemv = [&](Launch& L) { L.gemv = true; L.grid = dim3((L.cp.Cout + 31) / 32, B); };
+  use_gemv(P.back());
   // all AdaLayerNorm scale/shift projections of the condition in one GEMM (vocos.py:105-108)
   {
     std::string wn, bn;
@@ -724,6 +773,7 @@ int smi_voc_forward(smi_voc* h, const int64_t* sem_dev, const int32_t* lens_host
     }
     P.push_back(make_conv(h, "adaln_params", wn, bn.c_str(), ada_stride, c.pre_cond_dim, 1, 1, 1, 0, dvec, 1, c.spk_out_dim,
                           ada, nullptr, nullptr, nullptr, 1, ada_stride, len1, B, 1, ACT_NONE));
+    use_gemv(P.back());
   }
   // --- semantic tokens -> codebook rows -> out_project (factorized_vector_quantize.py:154-167)
   float* zc = bufs[0];
@@ -750,7 +800,7 @@ int smi_voc_forward(smi_voc* h, const int64_t* sem_dev, const int32_t* lens_host
     p.X = X; p.Y = Y; p.dww = dww; p.dwb = dwb; p.lens = len0; p.C = D; p.stride = T; p.bs = bs; p.triple = triple;
     if (ada_norm) { p.ada = ada + (size_t)ada_idx * 2 * D; p.ada_stride = ada_stride; ++ada_idx; }
     else { p.w = ent(h, pfx + ".weight"); p.bsh = ent(h, pfx + ".bias"); }
-    L.cpt = (D + 7) / 8; L.grid = dim3((T + 31) / 32, B);
+    L.cpt = (D + 31) / 32; L.grid = dim3((T + 7) / 8, B);
     P.push_back(L);
   };
   // embed conv7 -> norm -> nl x ConvNeXt -> final LN (vocos.py:324-335); consumes cur, leaves result in cur
@@ -836,7 +886,7 @@ int smi_voc_forward(smi_voc* h, const int64_t* sem_dev, const int32_t* lens_host
     if (L.kind == 0) {
       SMI_REQUIRE(L.cp.W, "smi_voc_forward: arena entry for %s not found", L.name.c_str());
       SMI_REQUIRE(L.lds <= 64 * 1024, "smi_voc_forward: %s needs %zu bytes of LDS", L.name.c_str(), L.lds);
-      SMI_REQUIRE(L.cp.xw <= 128, "smi_voc_forward: %s stages %d columns (> 128)", L.name.c_str(), L.cp.xw);
+      SMI_REQUIRE(L.cp.xw <= 128 && (L.chg == 1 || L.cp.xw <= 64), "smi_voc_forward: %s stages %d columns", L.name.c_str(), L.cp.xw);
     }
     int rc = run_launch(L, st);
     if (rc) return rc;
