@@ -607,7 +607,7 @@ Launch make_conv(const smi_voc* h, const std::string& name, const std::string& w
   p.halo_l = g.halo_l;
   p.xw = qt + g.halo_l + g.halo_r;
   L.grid = dim3(nq, L.ks ? cot : (cot + 3) / 4, B * S);
-  L.chg = (S == 1 && K == 1 && Cin >= 128) ? 4 : 1;     // 1-tap layers stage 128 channels per chunk
+  L.chg = (S == 1 && K == 1 && Cin >= 128 && L.ks) ? 4 : 1;   // K-split 1-tap layers stage 128 channels per chunk
   L.gemv = false;   // set by the caller for the per-utterance vector projections (use_gemv)
   size_t lds = (size_t)kChunk * L.chg * p.xw * 4;
   const size_t red = L.ks ? (size_t)4 * qb * 16 * 64 * 4 : 0;
