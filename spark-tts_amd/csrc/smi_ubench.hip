@@ -97,6 +97,28 @@ extern "C" int smi_ubench_xcc(int work_blocks, int helper_blocks, int block, int
   return SMI_OK;
 }
 
+// Records HW_REG_XCC_ID of every block of a chain of kernels with the given grid sizes (graph replay),
+// to see how the dispatcher maps blocks to XCDs from one kernel to the next.
+__global__ void ub_xccmap(unsigned char* out) {
+  if (threadIdx.x == 0) out[blockIdx.x] = (unsigned char)(__builtin_amdgcn_s_getreg(6164) & 7u);
+}
+extern "C" int smi_ubench_xccmap(const int* grids, const int* blocks, int n, int reps, unsigned char* out_dev, int stride, void* stream) {
+  hipStream_t st = (hipStream_t)stream, cs;
+  SMI_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+  hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+  SMI_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+  for (int r = 0; r < reps; ++r)
+    for (int i = 0; i < n; ++i)
+      hipLaunchKernelGGL(ub_xccmap, dim3(grids[i]), dim3(blocks[i]), 0, cs, out_dev + (size_t)(r * n + i) * stride);
+  SMI_HIP(hipStreamEndCapture(cs, &g));
+  SMI_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  SMI_HIP(hipGraphLaunch(ge, st));
+  SMI_HIP(hipGraphLaunch(ge, st));
+  SMI_HIP(hipStreamSynchronize(st));
+  (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g); (void)hipStreamDestroy(cs);
+  return SMI_OK;
+}
+
 // rotate_bytes > 0: kernel i of the chain reads its own region (i * rotate_bytes) mod buf_bytes, so with
 // buf_bytes well above the 256 MB Infinity Cache every kernel streams cold HBM data.
 extern "C" int smi_ubench_chain2(int kind, int grid, int block, int lds_bytes, int loads_per_thread, int n_kernels, int iters,
