@@ -41,6 +41,26 @@ struct RowDesc {  // 16 bytes, lives in device memory
 enum { PRO_PLAIN = 0, PRO_NORM = 1 };
 enum { EPI_RESID = 0, EPI_SWIGLU = 1, EPI_QKV = 2, EPI_LM = 3 };
 
+// Same-XCD L2 prefetch for a LATER kernel: block b of every kernel of a graph lands on XCD (s + b) mod 8
+// (measured: strict round-robin with the same start for every kernel, tools/xccmap.py), so a helper
+// block with blockIdx == c (mod 8) warms exactly the weight slices that consumer blocks == c (mod 8)
+// will read: those then hit the XCD's own 4 MiB L2 (a 17 MB stream: 5 us cold, 2 us L2-warm).  Speed
+// only -- nothing depends on the placement.
+struct PfDesc {
+  const unsigned char* base;   // consumer weight matrix
+  int slice_bytes;             // bytes consumer block b reads: [b * slice_bytes, (b + 1) * slice_bytes)
+  int nslices;                 // consumer work blocks
+  int q0, q1;                  // this producer covers slices s with q0 <= s / 8 < q1
+};
+
+__device__ __forceinline__ void pf_run(const PfDesc& d, int helper, int nhelpers, int tid, int nthreads) {
+  const int c = (int)blockIdx.x & 7, r = helper >> 3, R = (nhelpers + 7) >> 3;
+  for (int q = d.q0 + r; q < d.q1; q += R) {
+    const int sl = q * 8 + c;
+    if (sl < d.nslices) smi_prefetch_range(d.base + (size_t)sl * d.slice_bytes, (size_t)d.slice_bytes, tid, nthreads);
+  }
+}
+
 struct GemmP {
   const uint4* W;        // [NT][KT][64] 16-byte lane pieces (bf16 tiles in MFMA A-operand order)
   int NT, KT, M;         // n tiles, k tiles, rows
@@ -63,7 +83,8 @@ struct GemmP {
   const float* gamma_next;  // RESID: [N] RMSNorm weight of the NEXT norm
   float* ssout;          // RESID: [32][NT] partial sum of squares of h_new (this block writes column nt)
   unsigned long long* stamps;
-  int work_blocks;
+  int work_blocks;       // blocks >= work_blocks are prefetch helpers (pf)
+  PfDesc pf;
   int ldsb;              // few rows: bytes of wave-private LDS for the activation triples (0 = read them from global per tile)
   int lt_shift;          // log2(lanes that fetch one k tile's 12*M pieces)
 };
@@ -93,6 +114,10 @@ template <int MT, int NTB, int NW, int U, int WB, int PRO, int EPI, int KVF32>
 __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= p.work_blocks) {
+    pf_run(p.pf, (int)blockIdx.x - p.work_blocks, (int)gridDim.x - p.work_blocks, tid, NW * 64);
+    return;
+  }
   const int KT = p.KT, M = p.M, NT = p.NT;
   const int nt0 = blockIdx.x * NTB;
 #define SMI_STAMP(i) do { if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -683,9 +708,8 @@ struct AttnP {
   int M;
   int q_dim, n_kv, group, max_pos, n_heads;
   int slot_is_row;     // every row m lives in KV slot m (decode): addresses need no descriptor
-  int work_blocks;     // = n_heads * M; later blocks only prefetch [pf_ptr, pf_ptr + pf_bytes)
-  const void* pf_ptr;
-  size_t pf_bytes;
+  int work_blocks;     // = n_heads * M; later blocks are prefetch helpers
+  PfDesc pf;
 };
 
 constexpr int kAttnWaves = 8;
@@ -710,6 +734,10 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
   __shared__ float sl[kAttnWaves][TPW];
   __shared__ float pw[kAttnWaves][kHeadDim], pl[kAttnWaves];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= p.work_blocks) {
+    pf_run(p.pf, (int)blockIdx.x - p.work_blocks, (int)gridDim.x - p.work_blocks, tid, kAttnWaves * 64);
+    return;
+  }
   const int head = blockIdx.x % p.n_heads, m = blockIdx.x / p.n_heads;
   const int tl = lane / LPT, dl = lane % LPT;
   const int grp = wave * TPW + tl;
@@ -1143,6 +1171,7 @@ struct smi_llm {
   unsigned long long* stamps; int stamps_on;
   int max_steps;
   int tune[4];   // SPARKMI_TUNE block-shape selectors (diagnostics)
+  int prefetch;  // same-XCD L2 prefetch by helper blocks (SPARKMI_NO_PREFETCH=1 turns it off)
   hipGraphExec_t graph; int graph_B;
   hipEvent_t ev0, ev1;
   // host staging
@@ -1156,6 +1185,8 @@ int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
   const int work = (p.NT + NTB - 1) / NTB;
   p.work_blocks = work;
   p.stamps = L->stamps_on ? L->stamps : nullptr;
+  // idle CUs warm the L2 of their own XCD for a later kernel (decode with few rows only)
+  const int helpers = (L->prefetch && p.pf.base && p.M <= 8 && work < 232) ? (256 - work) / 8 * 8 : 0;
   size_t lds = (size_t)NW * NTB * MT * 1024 + 32 * 4 + NTB * 32 * 8;
   p.ldsb = 0; p.lt_shift = 0;
   if (MT == 1 && p.M <= 5) {
@@ -1170,9 +1201,9 @@ int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
     }
   }
   if (L->cfg.kv_dtype)
-    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 1>), dim3(work), dim3(NW * 64), lds, st, p);
+    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 1>), dim3(work + helpers), dim3(NW * 64), lds, st, p);
   else
-    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 0>), dim3(work), dim3(NW * 64), lds, st, p);
+    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 0>), dim3(work + helpers), dim3(NW * 64), lds, st, p);
   SMI_LAUNCH_CHECK();
   return SMI_OK;
 }
@@ -1210,6 +1241,8 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       p.rope = (const float2*)sec(L, SMI_LLM_ROPE, 0);
       p.kcache = kv_layer(L, L->kcache, layer); p.vcache = kv_layer(L, L->vcache, layer);
       p.q_dim = L->Q; p.kv_dim = L->KV; p.n_kv = c.num_kv_heads; p.max_pos = c.max_positions;
+      // helpers: first half of this layer's gate_up slices (consumer block b reads weight tile row b)
+      p.pf = PfDesc{sec(L, SMI_LLM_WGU, layer), L->KTh * 1024, L->NTgu, 0, (L->NTgu / 8 + 1) / 2};
       switch (L->tune[0]) {   // SPARKMI_TUNE=q,o,g,d: block-shape sweeps (diagnostics; NW changes the summation order)
         case 1: return launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_QKV>(L, p, st);
         case 3: return launch_gemm<1, 4, 8, 1, PRO_NORM, EPI_QKV>(L, p, st);
@@ -1223,8 +1256,11 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       a.group = c.num_heads / c.num_kv_heads; a.max_pos = c.max_positions; a.n_heads = c.num_heads;
       a.work_blocks = c.num_heads * M;
       a.slot_is_row = rows == L->rows;   // the live decode rows are (slot b, ...) in order
-      if (c.kv_dtype) hipLaunchKernelGGL(k_attn<1>, dim3(a.work_blocks), dim3(kAttnWaves * 64), 0, st, a);
-      else hipLaunchKernelGGL(k_attn<0>, dim3(a.work_blocks), dim3(kAttnWaves * 64), 0, st, a);
+      // helpers: second half of this layer's gate_up slices
+      a.pf = PfDesc{sec(L, SMI_LLM_WGU, layer), L->KTh * 1024, L->NTgu, (L->NTgu / 8 + 1) / 2, (L->NTgu + 7) / 8};
+      const int helpers = (L->prefetch && M <= 8 && a.work_blocks < 232) ? (256 - a.work_blocks) / 8 * 8 : 0;
+      if (c.kv_dtype) hipLaunchKernelGGL(k_attn<1>, dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
+      else hipLaunchKernelGGL(k_attn<0>, dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
       SMI_LAUNCH_CHECK();
       return SMI_OK;
     }
@@ -1232,6 +1268,8 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       p.W = (const uint4*)sec(L, SMI_LLM_WO, layer); p.NT = L->NTh; p.KT = L->KTq;
       p.XS = L->xs_attn; p.Y = L->h;
       p.XSout = L->xs_h; p.gamma_next = (const float*)sec(L, SMI_LLM_LN2, layer); p.ssout = L->sspart;
+      // helpers: this layer's down_proj slices
+      p.pf = PfDesc{sec(L, SMI_LLM_WD, layer), L->KTi * 1024, L->NTh, 0, (L->NTh + 7) / 8};
       switch (L->tune[1]) {
         case 2: return launch_gemm<1, 16, 2, 1, PRO_PLAIN, EPI_RESID>(L, p, st);
         case 3: return launch_gemm<1, 4, 8, 1, PRO_PLAIN, EPI_RESID>(L, p, st);
@@ -1251,6 +1289,8 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       p.XSout = L->xs_h; p.ssout = L->sspart;
       p.gamma_next = layer + 1 < c.num_layers ? (const float*)sec(L, SMI_LLM_LN1, layer + 1)
                                               : (const float*)sec(L, SMI_LLM_FINAL_NORM, 0);
+      // helpers: the next layer's QKV slices (its o_proj slices ride along: same slice size, contiguous-ish)
+      if (layer + 1 < c.num_layers) p.pf = PfDesc{sec(L, SMI_LLM_WQKV, layer + 1), L->KTh * 1024, L->NTqkv, 0, (L->NTqkv + 7) / 8};
       switch (L->tune[3]) {
         case 2: return launch_gemm<1, 16, 3, 4, PRO_PLAIN, EPI_RESID>(L, p, st);
         case 4: return launch_gemm<1, 8, 10, 2, PRO_PLAIN, EPI_RESID>(L, p, st);
@@ -1457,6 +1497,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->do_sample = 0; L->top_k = 50; L->temperature = 0.8f; L->top_p = 0.95f; L->seed = 0; L->logits = nullptr; L->tok = nullptr; L->stamps = nullptr; L->stamps_on = 0;
   { L->tune[0] = L->tune[1] = L->tune[2] = L->tune[3] = 0; const char* e = getenv("SPARKMI_TUNE"); if (e) sscanf(e, "%d,%d,%d,%d", &L->tune[0], &L->tune[1], &L->tune[2], &L->tune[3]); }
   L->bh = L->bq = nullptr; L->bxs_h = L->bxs_attn = L->bxs_act = nullptr; L->bss = nullptr; L->big_rows = 0;
+  L->prefetch = getenv("SPARKMI_NO_PREFETCH") ? 0 : 1;
   L->graph = nullptr; L->graph_B = 0; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->eos = -1;
   const size_t esz = cfg->kv_dtype ? 4 : 2;
   L->kv_layer_elems = (size_t)cfg->max_slots * cfg->num_kv_heads * cfg->max_positions * kHeadDim;

@@ -21,6 +21,9 @@ print("variant", os.environ.get("SPARKMI_VARIANT", "0"), out, "graph step", step
 ''' % ROOT
 for v in sys.argv[1:] or ["0", "1", "2", "3", "4", "5", "6", "7"]:
     env = dict(os.environ, SPARKMI_VARIANT=v)
+    if v.startswith("env:"):
+        k, val = v[4:].split("=", 1)
+        env = dict(os.environ, SPARKMI_VARIANT=v, **{k: val})
     if v.startswith("tune:"):
         env = dict(os.environ, SPARKMI_TUNE=v[5:], SPARKMI_VARIANT=v)
     if v.startswith("lib:"):
