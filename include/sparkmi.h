@@ -114,7 +114,9 @@ int smi_llm_steps(smi_llm* h);
 /* Per-kernel timing probe used by bench.py: launches ONLY the named decode-step kernel of `layer`
  * `iters` times on `stream` (inputs are whatever the scratch holds), bracketed by HIP events, and
  * returns the average milliseconds per launch.  kernel: 0 qkv, 1 attn, 2 o_proj, 3 gate_up,
- * 4 down, 5 lm_head, 6 finalize, 7 = the whole decode step (graph or eager as configured). */
+ * 4 down, 5 lm_head, 6 finalize, 7 = the whole decode step (graph or eager as configured).
+ * 16 + k (k = 0..4): layer kernel k timed in sequence -- (iters whole layers) minus (the same layers
+ * without k) -- so that it finds the L2 state its producers leave, as inside the decode graph. */
 int smi_llm_time_kernel(smi_llm* h, int kernel, int layer, int iters, float* ms_avg, void* stream);
 
 /* ------------------------------------------------------------------------------------------

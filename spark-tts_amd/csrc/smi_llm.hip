@@ -1268,8 +1268,8 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       p.W = (const uint4*)sec(L, SMI_LLM_WO, layer); p.NT = L->NTh; p.KT = L->KTq;
       p.XS = L->xs_attn; p.Y = L->h;
       p.XSout = L->xs_h; p.gamma_next = (const float*)sec(L, SMI_LLM_LN2, layer); p.ssout = L->sspart;
-      // helpers: this layer's down_proj slices
-      p.pf = PfDesc{sec(L, SMI_LLM_WD, layer), L->KTi * 1024, L->NTh, 0, (L->NTh + 7) / 8};
+      // no helpers here: warming down_proj's 8.7 MB from o_proj (or from attention / gate_up) stretches the
+      // producer by more than the consumer gains (measured, profiles/README.md), so down_proj stays cold
       switch (L->tune[1]) {
         case 2: return launch_gemm<1, 16, 2, 1, PRO_PLAIN, EPI_RESID>(L, p, st);
         case 3: return launch_gemm<1, 4, 8, 1, PRO_PLAIN, EPI_RESID>(L, p, st);
@@ -1769,7 +1769,7 @@ int smi_llm_debug_stamps(smi_llm* L, int kernel, int layer, double* out) {
 
 int smi_llm_time_kernel(smi_llm* L, int kernel, int layer, int iters, float* ms_avg, void* stream) {
   SMI_REQUIRE(L && ms_avg && iters > 0, "smi_llm_time_kernel: bad argument");
-  SMI_REQUIRE(kernel >= 0 && kernel <= 7, "smi_llm_time_kernel: kernel id %d", kernel);
+  SMI_REQUIRE((kernel >= 0 && kernel <= 7) || (kernel >= 16 && kernel <= 16 + KD), "smi_llm_time_kernel: kernel id %d", kernel);
   if (!L->started) { smi_set_error("smi_llm_time_kernel needs a started generation (prefill first)"); return SMI_ESTATE; }
   hipStream_t st = (hipStream_t)stream;
   int rc;
@@ -1778,6 +1778,26 @@ int smi_llm_time_kernel(smi_llm* L, int kernel, int layer, int iters, float* ms_
     SMI_HIP(hipEventRecord(L->ev0, st));
     if ((rc = smi_llm_decode(L, iters, stream))) return rc;
     SMI_HIP(hipEventRecord(L->ev1, st));
+  } else if (kernel >= 16) {
+    // In-sequence cost of one layer kernel: (time of iters layers) - (time of the same layers without it).
+    // Its producers run, so what they leave in L2 (the helper prefetch) is what it finds -- the
+    // duration it has inside the decode graph, which the back-to-back loop below cannot show.
+    const int k = kernel - 16, nl = L->cfg.num_layers;
+    SMI_REQUIRE(k >= KQKV && k <= KD, "smi_llm_time_kernel: in-sequence timing is for the layer kernels");
+    float t[2] = {0.f, 0.f};
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int i = -2; i < iters; ++i) {
+        if (i == 0) SMI_HIP(hipEventRecord(L->ev0, st));
+        const int l = (layer + nl + i) % nl;
+        for (int kk = KQKV; kk <= KD; ++kk)
+          if (!(pass == 1 && kk == k) && (rc = launch_one(L, kk, l, L->rows, L->B, nullptr, st))) return rc;
+      }
+      SMI_HIP(hipEventRecord(L->ev1, st));
+      SMI_HIP(hipEventSynchronize(L->ev1));
+      SMI_HIP(hipEventElapsedTime(&t[pass], L->ev0, L->ev1));
+    }
+    *ms_avg = (t[0] - t[1]) / iters;
+    return SMI_OK;
   } else {
     const int nl = L->cfg.num_layers;
     if (kernel == KFIN) {

@@ -154,10 +154,12 @@ class SparkLLM:
 
     KERNELS = ("qkv", "attn", "o_proj", "gate_up", "down", "lm_head", "finalize", "step")
 
-    def time_kernel(self, name: str, iters: int = 48, layer: int = 0) -> float:
-        """Average milliseconds per launch of one decode-step kernel (HIP events on this stream)."""
+    def time_kernel(self, name: str, iters: int = 48, layer: int = 0, in_sequence: bool = False) -> float:
+        """Average milliseconds per launch of one decode-step kernel (HIP events on this stream).
+        ``in_sequence`` times a layer kernel where it runs -- after its producers, which prefetch
+        part of its weights into L2 -- as (iters layers) - (the same layers without it)."""
         ms = C.c_float(0)
-        _lib.check(self._lib.smi_llm_time_kernel(self._h, self.KERNELS.index(name), layer, iters,
+        _lib.check(self._lib.smi_llm_time_kernel(self._h, self.KERNELS.index(name) + (16 if in_sequence else 0), layer, iters,
                                                  C.byref(ms), self._stream()), "smi_llm_time_kernel")
         return float(ms.value)
 
