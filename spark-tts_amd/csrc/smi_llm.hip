@@ -81,7 +81,7 @@ struct GemmP {
   // producer side: the next consumer's operand, written by the epilogue
   unsigned char* XSout;  // RESID: triples of gamma_next * h_new, [N/32][3][4][M][16]; SWIGLU: triples of act
   const float* gamma_next;  // RESID: [N] RMSNorm weight of the NEXT norm
-  float* ssout;          // RESID: [32][NT] partial sum of squares of h_new (this block writes column nt)
+  float* ssout;          // RESID: [32][NT * 4] partial sums of squares of h_new, one per 4 columns (k_pgemm: [rows][NT])
   unsigned long long* stamps;
   int work_blocks;       // blocks >= work_blocks are prefetch helpers (pf)
   PfDesc pf;
@@ -110,8 +110,12 @@ __device__ __forceinline__ size_t xs_off(int kt, int s, int k8, int m, int M) {
 // result is bit-identical whatever else is in the batch.  PRO_NORM: the operand is gamma * x and the
 // RMSNorm factor rsqrt(mean(x^2) + eps) -- a per-row scalar -- is applied to the accumulator.
 // ------------------------------------------------------------------------------------------
-template <int MT, int NTB, int NW, int U, int WB, int PRO, int EPI, int KVF32>
+// H > 1 (RESID only): the 16 rows of a weight tile are split over H blocks (8 or 4 rows each: only those
+// lanes load, the others feed zeros to the MFMA), so a matrix with few n tiles (N = 896: 56) still
+// spreads its HBM stream over 112 / 224 CUs.  Every output element keeps its own summation order.
+template <int MT, int NTB, int NW, int U, int WB, int PRO, int EPI, int KVF32, int H = 1>
 __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
+  static_assert(H == 1 || ((H == 2 || H == 4) && NTB == 1 && EPI == EPI_RESID), "row-split tiles: RESID, one tile per block");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if ((int)blockIdx.x >= p.work_blocks) {
@@ -119,7 +123,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
     return;
   }
   const int KT = p.KT, M = p.M, NT = p.NT;
-  const int nt0 = blockIdx.x * NTB;
+  const int nblk = p.work_blocks / H;   // blocks per row part; part r of tile t is block r * nblk + t (same XCD for all r)
+  const int part = H > 1 ? (int)blockIdx.x / nblk : 0;
+  const int nt0 = (H > 1 ? (int)blockIdx.x % nblk : (int)blockIdx.x) * NTB;
+  const bool wact = H == 1 || ((lane & 15) >> (H == 2 ? 3 : 2)) == part;   // this lane's weight row is in the part
+  const bool ract = H == 1 || ((lane >> 4) >> (H == 2 ? 1 : 0)) == part;   // this lane's 4 output columns are
 #define SMI_STAMP(i) do { if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   SMI_STAMP(0);
   float4* red = (float4*)smem;                                   // [NW][NTB][MT][64]
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
       for (int nb = 0; nb < NTB; ++nb) {
         int nt = nt0 + nb;
         nt = nt < NT ? nt : NT - 1;
-        dst[u][nb] = p.W[((size_t)nt * KT + j) * 64 + lane];
+        dst[u][nb] = wact ? p.W[((size_t)nt * KT + j) * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
       }
     }
   };
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int m = mt * 16 + em;
-      if (m < M) {
+      if (m < M && ract) {
         if (EPI == EPI_QKV) { erd[mt] = p.rows[m]; epre[mt] = *(const float4*)(p.bias + n); }
         if (EPI == EPI_RESID) epre[mt] = *(const float4*)(p.Y + (size_t)m * (NT * 16) + n);
       }
@@ -281,9 +289,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
       }
       const int m = mt * 16 + em;
       const int n = nt * 16 + 4 * (lane >> 4);
-      const bool valid = m < M;
+      const bool valid = m < M && ract;
       if (PRO == PRO_NORM) {
-        const float r = rarr[valid ? m : 0];
+        const float r = rarr[m < M ? m : 0];
         s.x *= r; s.y *= r; s.z *= r; s.w *= r;
       }
       if (EPI == EPI_RESID) {
@@ -304,10 +312,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
           *(uint2*)(p.XSout + o + pl) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
           *(uint2*)(p.XSout + o + 2 * pl) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
         }
-        // this tile's 16 columns of row m sit in lanes em, em+16, em+32, em+48
-        ssq += __shfl_xor(ssq, 16, 64);
-        ssq += __shfl_xor(ssq, 32, 64);
-        if (lane < 16 && valid) p.ssout[(size_t)m * NT + nt] = ssq;
+        // one partial per 4 columns (this tile's 16 columns of row m sit in lanes em, em+16, em+32, em+48)
+        if (valid) p.ssout[((size_t)m * NT + nt) * 4 + (lane >> 4)] = ssq;
       } else if (EPI == EPI_SWIGLU) {
         if (valid) {
           // rows are (gate, up, gate, up): silu(g) * u, MQ:46-48
@@ -1154,7 +1160,7 @@ struct smi_llm {
   // device scratch
   float *h, *qbuf;
   unsigned char *xs_h, *xs_attn, *xs_act;   // GEMM operands as exact bf16 triples ([K/32][3][4][M][16 B])
-  float* sspart;       // [32][NTh] partial sums of squares of h (RMSNorm)
+  float* sspart;       // [32][NTh * 4] partial sums of squares of h (RMSNorm), one per 4 columns
   // prefill workspace for up to big_rows rows at once (allocated at the first multi-chunk prefill)
   float *bh, *bq; unsigned char *bxs_h, *bxs_attn, *bxs_act; float* bss; int big_rows;
   RowDesc* rows;       // live decode rows [32]
@@ -1180,9 +1186,9 @@ struct smi_llm {
 
 namespace {
 
-template <int MT, int NTB, int NW, int U, int WB, int PRO, int EPI>
+template <int MT, int NTB, int NW, int U, int WB, int PRO, int EPI, int H = 1>
 int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
-  const int work = (p.NT + NTB - 1) / NTB;
+  const int work = (p.NT + NTB - 1) / NTB * H;
   p.work_blocks = work;
   p.stamps = L->stamps_on ? L->stamps : nullptr;
   // idle CUs warm the L2 of their own XCD for a later kernel (decode with few rows only)
@@ -1201,19 +1207,19 @@ int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
     }
   }
   if (L->cfg.kv_dtype)
-    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 1>), dim3(work + helpers), dim3(NW * 64), lds, st, p);
+    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 1, H>), dim3(work + helpers), dim3(NW * 64), lds, st, p);
   else
-    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 0>), dim3(work + helpers), dim3(NW * 64), lds, st, p);
+    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 0, H>), dim3(work + helpers), dim3(NW * 64), lds, st, p);
   SMI_LAUNCH_CHECK();
   return SMI_OK;
 }
 
 // NW (the k-tile -> wave map) is fixed per kernel type for every M; only the batch depth U shrinks
 // for two m-tiles (register budget), which does not change any summation order.
-template <int NTB, int NW, int U, int WB, int PRO, int EPI>
+template <int NTB, int NW, int U, int WB, int PRO, int EPI, int H = 1>
 int launch_gemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
-  if (p.M > 16) return launch_gemm_kv<2, NTB, NW, (NW >= 16 || NTB >= 4 ? 2 : (U > 4 ? 4 : U)), 1, PRO, EPI>(L, p, st);
-  return launch_gemm_kv<1, NTB, NW, U, WB, PRO, EPI>(L, p, st);
+  if (p.M > 16) return launch_gemm_kv<2, NTB, NW, (NW >= 16 || NTB >= 4 ? 2 : (U > 4 ? 4 : U)), 1, PRO, EPI, H>(L, p, st);
+  return launch_gemm_kv<1, NTB, NW, U, WB, PRO, EPI, H>(L, p, st);
 }
 
 const unsigned char* sec(const smi_llm* L, int s, int layer) {
@@ -1232,7 +1238,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
   const smi_llm_cfg& c = L->cfg;
   GemmP p;
   memset(&p, 0, sizeof(p));
-  p.M = M; p.rows = rows; p.eps = c.rms_eps; p.sspart = L->sspart; p.npart = L->NTh;
+  p.M = M; p.rows = rows; p.eps = c.rms_eps; p.sspart = L->sspart; p.npart = L->NTh * 4;
   switch (which) {
     case KQKV:
       p.W = (const uint4*)sec(L, SMI_LLM_WQKV, layer); p.NT = L->NTqkv; p.KT = L->KTh;
@@ -1273,7 +1279,10 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       switch (L->tune[1]) {
         case 2: return launch_gemm<1, 16, 2, 1, PRO_PLAIN, EPI_RESID>(L, p, st);
         case 3: return launch_gemm<1, 4, 8, 1, PRO_PLAIN, EPI_RESID>(L, p, st);
-        default: return launch_gemm<1, 8, 4, 1, PRO_PLAIN, EPI_RESID>(L, p, st);
+        case 4: return launch_gemm<1, 8, 4, 1, PRO_PLAIN, EPI_RESID, 2>(L, p, st);
+        case 5: return launch_gemm<1, 8, 4, 1, PRO_PLAIN, EPI_RESID>(L, p, st);
+        case 6: return launch_gemm<1, 8, 4, 1, PRO_PLAIN, EPI_RESID, 4>(L, p, st);
+        default: return launch_gemm<1, 8, 4, 1, PRO_PLAIN, EPI_RESID>(L, p, st);   // row parts do not pay here (1.6 MB)
       }
     case KGU:
       p.W = (const uint4*)sec(L, SMI_LLM_WGU, layer); p.NT = L->NTgu; p.KT = L->KTh;
@@ -1294,7 +1303,10 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       switch (L->tune[3]) {
         case 2: return launch_gemm<1, 16, 3, 4, PRO_PLAIN, EPI_RESID>(L, p, st);
         case 4: return launch_gemm<1, 8, 10, 2, PRO_PLAIN, EPI_RESID>(L, p, st);
-        default: return launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID>(L, p, st);
+        case 5: return launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID, 2>(L, p, st);
+        case 6: return launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID>(L, p, st);
+        default:   // few rows: 4-row parts (224 blocks, -0.7 us); same bits either way, the zero-fed MFMAs cost at M > 8
+          return M <= 8 ? launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID, 4>(L, p, st) : launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID>(L, p, st);
       }
     case KLM:
       p.W = (const uint4*)sec(L, SMI_LLM_LM_HEAD, 0); p.NT = L->NTlm; p.KT = L->KTh;
@@ -1325,7 +1337,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       f.nblk = (M <= 16 && L->KTh <= 32) ? L->lm_blocks : L->lm_cap;
       f.rows = L->rows; f.hist = L->hist; f.count = L->count; f.finished = L->finished; f.step = L->step;
       f.eos = L->eos; f.Wlm = (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0); f.h = L->h; f.max_steps = L->max_steps;
-      f.gamma0 = (const float*)sec(L, SMI_LLM_LN1, 0); f.xs = L->xs_h; f.sspart = L->sspart; f.npart = L->NTh;
+      f.gamma0 = (const float*)sec(L, SMI_LLM_LN1, 0); f.xs = L->xs_h; f.sspart = L->sspart; f.npart = L->NTh * 4;
       hipLaunchKernelGGL(k_finalize, dim3(M), dim3(256), 0, st, f);
       SMI_LAUNCH_CHECK();
       return SMI_OK;
@@ -1414,7 +1426,7 @@ int ensure_big(smi_llm* L, int rows) {
 
 int launch_embed(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
   hipLaunchKernelGGL(k_embed, dim3((M + 3) / 4), dim3(256), 0, st, (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0), L->KTh, rows, M,
-                     (const float*)sec(L, SMI_LLM_LN1, 0), L->h, L->xs_h, L->sspart, L->NTh);
+                     (const float*)sec(L, SMI_LLM_LN1, 0), L->h, L->xs_h, L->sspart, L->NTh * 4);
   SMI_LAUNCH_CHECK();
   return SMI_OK;
 }
@@ -1513,7 +1525,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   SMI_ALLOC(L->xs_h, (size_t)kMaxRows * L->H * 6);
   SMI_ALLOC(L->xs_attn, (size_t)kMaxRows * L->Q * 6);
   SMI_ALLOC(L->xs_act, (size_t)kMaxRows * L->I * 6);
-  SMI_ALLOC(L->sspart, (size_t)kMaxRows * L->NTh * 4);
+  SMI_ALLOC(L->sspart, (size_t)kMaxRows * L->NTh * 4 * 4);
   SMI_ALLOC(L->rows, kMaxRows * sizeof(RowDesc));
   SMI_ALLOC(L->pval, (size_t)L->lm_cap * 32 * 4);
   SMI_ALLOC(L->pidx, (size_t)L->lm_cap * 32 * 4);
@@ -1532,7 +1544,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
       hipMemset(L->xs_h, 0, (size_t)kMaxRows * L->H * 6) != hipSuccess ||
       hipMemset(L->xs_attn, 0, (size_t)kMaxRows * L->Q * 6) != hipSuccess ||
       hipMemset(L->xs_act, 0, (size_t)kMaxRows * L->I * 6) != hipSuccess ||
-      hipMemset(L->sspart, 0, (size_t)kMaxRows * L->NTh * 4) != hipSuccess ||
+      hipMemset(L->sspart, 0, (size_t)kMaxRows * L->NTh * 4 * 4) != hipSuccess ||
       hipMemset(L->qbuf, 0, (size_t)kMaxRows * L->Q * 4) != hipSuccess ||
       hipMemset(L->rows, 0, kMaxRows * sizeof(RowDesc)) != hipSuccess ||
       hipMemset(L->count, 0, 128) != hipSuccess || hipMemset(L->finished, 0, 128) != hipSuccess ||
