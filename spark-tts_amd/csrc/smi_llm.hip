@@ -123,6 +123,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
     return;
   }
   const int KT = p.KT, M = p.M, NT = p.NT;
+  const int mbase = (int)blockIdx.y * (MT * 16);   // row group (grid.y > 1: a prompt's rows, 32 per block row)
   const int nblk = p.work_blocks / H;   // blocks per row part; part r of tile t is block r * nblk + t (same XCD for all r)
   const int part = H > 1 ? (int)blockIdx.x / nblk : 0;
   const int nt0 = (H > 1 ? (int)blockIdx.x % nblk : (int)blockIdx.x) * NTB;
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
   const int k8 = lane >> 4;
   int mrow[MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) { const int m = mt * 16 + (lane & 15); mrow[mt] = m < M ? m : M - 1; }
+  for (int mt = 0; mt < MT; ++mt) { const int m = mbase + mt * 16 + (lane & 15); mrow[mt] = m < M ? m : M - 1; }
   auto load_w = [&](uint4 (&dst)[U][NTB], int j0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
     if (EPI == EPI_RESID) egam = *(const float4*)(p.gamma_next + n);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int m = mt * 16 + em;
+      const int m = mbase + mt * 16 + em;
       if (m < M && ract) {
         if (EPI == EPI_QKV) { erd[mt] = p.rows[m]; epre[mt] = *(const float4*)(p.bias + n); }
         if (EPI == EPI_RESID) epre[mt] = *(const float4*)(p.Y + (size_t)m * (NT * 16) + n);
@@ -207,11 +208,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
   }
   // ---- RMSNorm factor per row from the producer's partial sums (fixed order: DPP tree over partials)
   if (PRO == PRO_NORM) {
-    for (int m = wave; m < M; m += NW) {
+    for (int ml = wave; ml < MT * 16 && mbase + ml < M; ml += NW) {
       float v = 0.f;
-      for (int i = lane; i < p.npart; i += 64) v += p.sspart[(size_t)m * p.npart + i];
+      for (int i = lane; i < p.npart; i += 64) v += p.sspart[(size_t)(mbase + ml) * p.npart + i];
       v = smi_wave_sum(v);
-      if (lane == 0) rarr[m] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
+      if (lane == 0) rarr[ml] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
     }
   }
   SMI_STAMP(1);
@@ -287,11 +288,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
         const float4 t = red[((wv * NTB + nb) * MT + mt) * 64 + lane];
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
       }
-      const int m = mt * 16 + em;
+      const int ml = mt * 16 + em, m = mbase + ml;
       const int n = nt * 16 + 4 * (lane >> 4);
       const bool valid = m < M && ract;
       if (PRO == PRO_NORM) {
-        const float r = rarr[m < M ? m : 0];
+        const float r = rarr[m < M ? ml : 0];
         s.x *= r; s.y *= r; s.z *= r; s.w *= r;
       }
       if (EPI == EPI_RESID) {
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
           int oi = __shfl_xor(bi, o, 64);
           if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
-        if (lane < 16 && valid) { bestv[nb * 32 + m] = bv; besti[nb * 32 + m] = bi; }
+        if (lane < 16 && valid) { bestv[nb * 32 + ml] = bv; besti[nb * 32 + ml] = bi; }
       }
     }
   }
@@ -581,11 +582,12 @@ __global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
 // k_gemm<EPI_LM>, so the logits are bit-identical to the two-m-tile path.
 // ------------------------------------------------------------------------------------------
 template <int KVF32_UNUSED>
-__global__ __launch_bounds__(256) void k_lm(GemmP p, int ngroups) {
+__global__ __launch_bounds__(256) void k_lm(GemmP p, int ngroups, int m0) {
   constexpr int NTB = 2, NW = 4, U = 8, MT = 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int KT = p.KT, M = p.M, NT = p.NT;
+  const int KT = p.KT, NT = p.NT;
+  const int M = p.M - m0 < 16 ? p.M - m0 : 16;   // this launch: rows m0 .. m0 + M - 1 of the p.M live ones
   float4* red = (float4*)smem;                                   // [NW][NTB][64]
   float* rarr = (float*)(smem + (size_t)NW * NTB * MT * 1024);
   float* bestv = rarr + 32;                                      // [NTB][32] running best of this block
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(256) void k_lm(GemmP p, int ngroups) {
     int j = wave + u * NW;
     j = j < KT ? j : KT - 1;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) bf[u][s] = *(const bf16x8*)(p.XS + xs_off(j, s, k8, mrow, M));
+    for (int s = 0; s < 3; ++s) bf[u][s] = *(const bf16x8*)(p.XS + xs_off(j, s, k8, m0 + mrow, p.M));
   }
   uint4 w[U][NTB];
   auto load_w = [&](int g) {
@@ -618,7 +620,7 @@ __global__ __launch_bounds__(256) void k_lm(GemmP p, int ngroups) {
   if (g < ngroups) load_w(g);
   for (int m = wave; m < M; m += NW) {
     float v = 0.f;
-    for (int i = lane; i < p.npart; i += 64) v += p.sspart[(size_t)m * p.npart + i];
+    for (int i = lane; i < p.npart; i += 64) v += p.sspart[(size_t)(m0 + m) * p.npart + i];
     v = smi_wave_sum(v);
     if (lane == 0) rarr[m] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
   }
@@ -664,7 +666,7 @@ __global__ __launch_bounds__(256) void k_lm(GemmP p, int ngroups) {
         const int n = nt * 16 + 4 * (lane >> 4);
         const bool valid = em < M;
         if (valid && p.Y) {
-          float* y = p.Y + (size_t)em * p.V + n;
+          float* y = p.Y + (size_t)(m0 + em) * p.V + n;
           if (n + 0 < p.V) y[0] = s.x;
           if (n + 1 < p.V) y[1] = s.y;
           if (n + 2 < p.V) y[2] = s.z;
@@ -700,8 +702,8 @@ __global__ __launch_bounds__(256) void k_lm(GemmP p, int ngroups) {
       const int oi = besti[nb * 32 + tid];
       if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
-    p.pval[(size_t)tid * gridDim.x + blockIdx.x] = bv;
-    p.pidx[(size_t)tid * gridDim.x + blockIdx.x] = bi;
+    p.pval[(size_t)(m0 + tid) * gridDim.x + blockIdx.x] = bv;
+    p.pidx[(size_t)(m0 + tid) * gridDim.x + blockIdx.x] = bi;
   }
 }
 
@@ -1178,6 +1180,7 @@ struct smi_llm {
   int max_steps;
   int tune[4];   // SPARKMI_TUNE block-shape selectors (diagnostics)
   int prefetch;  // same-XCD L2 prefetch by helper blocks (SPARKMI_NO_PREFETCH=1 turns it off)
+  int pgemm_min_rows;   // prompt rows from which the prefill GEMM replaces row-grouped decode GEMMs (SPARKMI_PGEMM_MIN_ROWS)
   hipGraphExec_t graph; int graph_B;
   hipEvent_t ev0, ev1;
   // host staging
@@ -1206,19 +1209,36 @@ int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
       lds += per_wave * NW;
     }
   }
+  if (lds > 64 * 1024) {   // more than the default dynamic LDS window: opt in once per instantiation
+    static bool done = false;
+    if (!done) {
+      SMI_HIP(hipFuncSetAttribute((const void*)k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 1, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      SMI_HIP(hipFuncSetAttribute((const void*)k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 0, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      done = true;
+    }
+  }
+  const int groups = MT == 2 ? (p.M + 31) / 32 : 1;   // more than 32 rows (prefill): one block row per 32 rows
+  SMI_REQUIRE(groups == 1 || EPI != EPI_LM, "lm_head takes at most 32 rows per launch");
   if (L->cfg.kv_dtype)
-    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 1, H>), dim3(work + helpers), dim3(NW * 64), lds, st, p);
+    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 1, H>), dim3(work + helpers, groups), dim3(NW * 64), lds, st, p);
   else
-    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 0, H>), dim3(work + helpers), dim3(NW * 64), lds, st, p);
+    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 0, H>), dim3(work + helpers, groups), dim3(NW * 64), lds, st, p);
   SMI_LAUNCH_CHECK();
   return SMI_OK;
 }
 
 // NW (the k-tile -> wave map) is fixed per kernel type for every M; only the batch depth U shrinks
 // for two m-tiles (register budget), which does not change any summation order.
-template <int NTB, int NW, int U, int WB, int PRO, int EPI, int H = 1>
+template <int NTB, int NW, int U, int WB, int PRO, int EPI, int H = 1, int N2 = 1>
 int launch_gemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
-  if (p.M > 16) return launch_gemm_kv<2, NTB, NW, (NW >= 16 || NTB >= 4 ? 2 : (U > 4 ? 4 : U)), 1, PRO, EPI, H>(L, p, st);
+  // two m-tiles: the operand triples (12 * M pieces per k tile) outweigh the weight tile 6:1, so where there are
+  // n tiles to spare (gate_up: 608) a block takes N2 of them per operand fetch.  Any NTB gives the same bits:
+  // a tile's k -> wave map does not change.  (Measured at M = 32: gate_up 19.4 -> 13.7 us with N2 = 2, 14.4 with 4;
+  // QKV / o_proj / down / lm_head lose with fewer blocks.)
+  if (p.M > 16) {
+    if (N2 > 1) return launch_gemm_kv<2, NTB * N2, NW, 1, 1, PRO, EPI>(L, p, st);
+    return launch_gemm_kv<2, NTB, NW, (NW >= 16 || NTB >= 4 ? 2 : (U > 4 ? 4 : U)), 1, PRO, EPI>(L, p, st);
+  }
   return launch_gemm_kv<1, NTB, NW, U, WB, PRO, EPI, H>(L, p, st);
 }
 
@@ -1290,7 +1310,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       switch (L->tune[2]) {
         case 2: return launch_gemm<1, 16, 2, 1, PRO_NORM, EPI_SWIGLU>(L, p, st);
         case 5: return launch_gemm<2, 4, 8, 1, PRO_NORM, EPI_SWIGLU>(L, p, st);
-        default: return launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_SWIGLU>(L, p, st);
+        default: return launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_SWIGLU, 1, 2>(L, p, st);
       }
     case KD:   // h += Wd act; emits the next layer's input-norm operand (or the final norm's)
       p.W = (const uint4*)sec(L, SMI_LLM_WD, layer); p.NT = L->NTh; p.KT = L->KTi;
@@ -1313,11 +1333,13 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       p.XS = L->xs_h;
       p.Y = logits ? logits : (L->do_sample ? L->logits : nullptr);
       p.V = c.vocab_size; p.pval = L->pval; p.pidx = L->pidx;
-      if (M <= 16 && L->KTh <= 32) {   // persistent path (operand resident in registers)
+      if (L->KTh <= 32) {   // persistent path (16 rows' operand resident in registers); 17..32 rows: two passes
         const int ngroups = (L->NTlm + 1) / 2;
         const size_t lds = (size_t)4 * 2 * 1024 + 32 * 4 + 2 * 32 * 8;
-        hipLaunchKernelGGL(k_lm<0>, dim3(L->lm_blocks), dim3(256), lds, st, p, ngroups);
-        SMI_LAUNCH_CHECK();
+        for (int m0 = 0; m0 < M; m0 += 16) {
+          hipLaunchKernelGGL(k_lm<0>, dim3(L->lm_blocks), dim3(256), lds, st, p, ngroups, m0);
+          SMI_LAUNCH_CHECK();
+        }
         return SMI_OK;
       }
       SMI_REQUIRE((L->NTlm + 3) / 4 <= L->lm_cap, "lm_head partial buffer too small");
@@ -1334,7 +1356,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
         f.tok = L->tok;
       }
       f.pval = L->pval; f.pidx = L->pidx; f.M = M; f.KT = L->KTh;
-      f.nblk = (M <= 16 && L->KTh <= 32) ? L->lm_blocks : L->lm_cap;
+      f.nblk = L->KTh <= 32 ? L->lm_blocks : L->lm_cap;
       f.rows = L->rows; f.hist = L->hist; f.count = L->count; f.finished = L->finished; f.step = L->step;
       f.eos = L->eos; f.Wlm = (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0); f.h = L->h; f.max_steps = L->max_steps;
       f.gamma0 = (const float*)sec(L, SMI_LLM_LN1, 0); f.xs = L->xs_h; f.sspart = L->sspart; f.npart = L->NTh * 4;
@@ -1360,19 +1382,23 @@ int launch_pgemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
 
 // All layers for M (> 32) prompt rows living in the big workspace: K/V of every row appended, hidden
 // states of the last layer never needed (no prompt row except each sequence's last feeds lm_head).
+// Up to kPgemmMinRows rows the decode GEMM runs with one block row per 32 rows (same bits as 32-row
+// chunks, one launch instead of M / 32); beyond, the LDS-shared prefill GEMM (k_pgemm) takes over.
 int launch_layers_big(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
   const smi_llm_cfg& c = L->cfg;
+  const bool grouped = M < L->pgemm_min_rows;
+  const int npart = grouped ? L->NTh * 4 : L->NTh;
   int rc;
   for (int l = 0; l < c.num_layers; ++l) {
     GemmP p;
     memset(&p, 0, sizeof(p));
-    p.M = M; p.rows = rows; p.eps = c.rms_eps; p.sspart = L->bss; p.npart = L->NTh;
+    p.M = M; p.rows = rows; p.eps = c.rms_eps; p.sspart = L->bss; p.npart = npart;
     // QKV
     p.W = (const uint4*)sec(L, SMI_LLM_WQKV, l); p.NT = L->NTqkv; p.KT = L->KTh; p.XS = L->bxs_h;
     p.Y = L->bq; p.bias = (const float*)sec(L, SMI_LLM_BQKV, l); p.rope = (const float2*)sec(L, SMI_LLM_ROPE, 0);
     p.kcache = kv_layer(L, L->kcache, l); p.vcache = kv_layer(L, L->vcache, l);
     p.q_dim = L->Q; p.kv_dim = L->KV; p.n_kv = c.num_kv_heads; p.max_pos = c.max_positions;
-    if ((rc = launch_pgemm<PRO_NORM, EPI_QKV>(L, p, st))) return rc;
+    if ((rc = grouped ? launch_gemm<1, 16, 2, 1, PRO_NORM, EPI_QKV>(L, p, st) : launch_pgemm<PRO_NORM, EPI_QKV>(L, p, st))) return rc;
     if (l == c.num_layers - 1) break;
     // attention
     AttnP a;
@@ -1386,23 +1412,23 @@ int launch_layers_big(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
     // o_proj
     GemmP o;
     memset(&o, 0, sizeof(o));
-    o.M = M; o.rows = rows; o.eps = c.rms_eps; o.sspart = L->bss; o.npart = L->NTh;
+    o.M = M; o.rows = rows; o.eps = c.rms_eps; o.sspart = L->bss; o.npart = npart;
     o.W = (const uint4*)sec(L, SMI_LLM_WO, l); o.NT = L->NTh; o.KT = L->KTq; o.XS = L->bxs_attn; o.Y = L->bh;
     o.XSout = L->bxs_h; o.gamma_next = (const float*)sec(L, SMI_LLM_LN2, l); o.ssout = L->bss;
-    if ((rc = launch_pgemm<PRO_PLAIN, EPI_RESID>(L, o, st))) return rc;
+    if ((rc = grouped ? launch_gemm<1, 8, 4, 1, PRO_PLAIN, EPI_RESID>(L, o, st) : launch_pgemm<PRO_PLAIN, EPI_RESID>(L, o, st))) return rc;
     // gate_up
     GemmP g;
     memset(&g, 0, sizeof(g));
-    g.M = M; g.rows = rows; g.eps = c.rms_eps; g.sspart = L->bss; g.npart = L->NTh;
+    g.M = M; g.rows = rows; g.eps = c.rms_eps; g.sspart = L->bss; g.npart = npart;
     g.W = (const uint4*)sec(L, SMI_LLM_WGU, l); g.NT = L->NTgu; g.KT = L->KTh; g.XS = L->bxs_h; g.XSout = L->bxs_act;
-    if ((rc = launch_pgemm<PRO_NORM, EPI_SWIGLU>(L, g, st))) return rc;
+    if ((rc = grouped ? launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_SWIGLU, 1, 2>(L, g, st) : launch_pgemm<PRO_NORM, EPI_SWIGLU>(L, g, st))) return rc;
     // down
     GemmP d;
     memset(&d, 0, sizeof(d));
-    d.M = M; d.rows = rows; d.eps = c.rms_eps; d.sspart = L->bss; d.npart = L->NTh;
+    d.M = M; d.rows = rows; d.eps = c.rms_eps; d.sspart = L->bss; d.npart = npart;
     d.W = (const uint4*)sec(L, SMI_LLM_WD, l); d.NT = L->NTh; d.KT = L->KTi; d.XS = L->bxs_act; d.Y = L->bh;
     d.XSout = L->bxs_h; d.ssout = L->bss; d.gamma_next = (const float*)sec(L, SMI_LLM_LN1, l + 1);
-    if ((rc = launch_pgemm<PRO_PLAIN, EPI_RESID>(L, d, st))) return rc;
+    if ((rc = grouped ? launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID>(L, d, st) : launch_pgemm<PRO_PLAIN, EPI_RESID>(L, d, st))) return rc;
   }
   return SMI_OK;
 }
@@ -1416,7 +1442,7 @@ int ensure_big(smi_llm* L, int rows) {
   const size_t R = (size_t)rows;
   if (hipMalloc((void**)&L->bh, R * L->H * 4) != hipSuccess || hipMalloc((void**)&L->bq, R * L->Q * 4) != hipSuccess ||
       hipMalloc((void**)&L->bxs_h, R * L->H * 6) != hipSuccess || hipMalloc((void**)&L->bxs_attn, R * L->Q * 6) != hipSuccess ||
-      hipMalloc((void**)&L->bxs_act, R * L->I * 6) != hipSuccess || hipMalloc((void**)&L->bss, R * L->NTh * 4) != hipSuccess) {
+      hipMalloc((void**)&L->bxs_act, R * L->I * 6) != hipSuccess || hipMalloc((void**)&L->bss, R * L->NTh * 4 * 4) != hipSuccess) {
     smi_set_error("hipMalloc(prefill workspace for %d rows) failed", rows);
     return SMI_ENOMEM;
   }
@@ -1510,6 +1536,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   { L->tune[0] = L->tune[1] = L->tune[2] = L->tune[3] = 0; const char* e = getenv("SPARKMI_TUNE"); if (e) sscanf(e, "%d,%d,%d,%d", &L->tune[0], &L->tune[1], &L->tune[2], &L->tune[3]); }
   L->bh = L->bq = nullptr; L->bxs_h = L->bxs_attn = L->bxs_act = nullptr; L->bss = nullptr; L->big_rows = 0;
   L->prefetch = getenv("SPARKMI_NO_PREFETCH") ? 0 : 1;
+  { const char* e = getenv("SPARKMI_PGEMM_MIN_ROWS"); L->pgemm_min_rows = e ? atoi(e) : 3072; }
   L->graph = nullptr; L->graph_B = 0; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->eos = -1;
   const size_t esz = cfg->kv_dtype ? 4 : 2;
   L->kv_layer_elems = (size_t)cfg->max_slots * cfg->num_kv_heads * cfg->max_positions * kHeadDim;
@@ -1623,8 +1650,9 @@ int smi_llm_prefill(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, 
   for (int b = 0; b < B; ++b) L->max_len = lens[b] > L->max_len ? lens[b] : L->max_len;
   L->steps_launched = 1;
   if (L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }  // eos / B are baked into the graph
-  // measured crossover (profiles/README.md): 32-row chunks cost ~1.4 ms each, the prefill GEMM ~16 ms + 5 us/row
-  if (total >= 384 && !getenv("SPARKMI_PREFILL_CHUNKS")) {
+  // measured (tools/prefill_time.py, profiles/README.md): 32-row chunks ~1.4 ms each; row-grouped decode GEMMs
+  // ~1.5 ms + 9 us/row; the prefill GEMM ~15 ms + 5 us/row (crossover near 3000 rows)
+  if (total > (size_t)kMaxRows && !getenv("SPARKMI_PREFILL_CHUNKS")) {
     // many prompt rows: whole groups of up to kBigRows rows through the prefill GEMM (k_pgemm)
     constexpr size_t kBigRows = 4096;
     if ((rc = ensure_big(L, (int)(total < kBigRows ? total : kBigRows)))) return rc;
@@ -1632,7 +1660,7 @@ int smi_llm_prefill(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, 
       const int M = (int)((total - r0) < kBigRows ? (total - r0) : kBigRows);
       const RowDesc* rows = L->plan + r0;
       hipLaunchKernelGGL(k_embed, dim3((M + 3) / 4), dim3(256), 0, st, (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0), L->KTh, rows, M,
-                         (const float*)sec(L, SMI_LLM_LN1, 0), L->bh, L->bxs_h, L->bss, L->NTh);
+                         (const float*)sec(L, SMI_LLM_LN1, 0), L->bh, L->bxs_h, L->bss, M < L->pgemm_min_rows ? L->NTh * 4 : L->NTh);
       SMI_LAUNCH_CHECK();
       if ((rc = launch_layers_big(L, rows, M, st))) return rc;
     }

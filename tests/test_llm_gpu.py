@@ -204,17 +204,21 @@ def test_full_size_batch_is_bit_identical_to_single_runs():
     assert int(chunked.argmax()) == step_tok
 
 
-def test_prefill_gemm_path_matches_chunked_prefill(tiny, monkeypatch):
-    """>= 384 prompt rows go through the prefill GEMM (k_pgemm); the generated tokens must equal the
-    32-row-chunk path's and the oracle's."""
+def test_prefill_paths_agree(tiny, monkeypatch):
+    """More than 32 prompt rows run as row-grouped decode GEMMs (one launch per layer kernel), from
+    SPARKMI_PGEMM_MIN_ROWS rows on through the prefill GEMM (k_pgemm); both must give the tokens of
+    the 32-row-chunk path and of the oracle."""
     cfg, syn = tiny
     rng = np.random.Generator(np.random.PCG64(314))
     B = 12
     prompts = [rng.integers(0, cfg.vocab_size, size=int(rng.integers(30, 60))).tolist() for _ in range(B)]
     assert sum(len(p) - 1 for p in prompts) >= 384
-    big = _llm(cfg, syn, max_slots=B, max_positions=96).generate_ids(prompts, 16)
+    grouped = _llm(cfg, syn, max_slots=B, max_positions=96).generate_ids(prompts, 16)
+    monkeypatch.setenv("SPARKMI_PGEMM_MIN_ROWS", "0")
+    pgemm = _llm(cfg, syn, max_slots=B, max_positions=96).generate_ids(prompts, 16)
+    monkeypatch.delenv("SPARKMI_PGEMM_MIN_ROWS")
     monkeypatch.setenv("SPARKMI_PREFILL_CHUNKS", "1")
     chunked = _llm(cfg, syn, max_slots=B, max_positions=96).generate_ids(prompts, 16)
-    assert big == chunked
+    assert grouped == chunked and pgemm == chunked
     for b in (0, 5, 11):
-        assert Qwen2Ref(cfg, syn, kv_dtype="bf16").generate_greedy(prompts[b], 16) == big[b]
+        assert Qwen2Ref(cfg, syn, kv_dtype="bf16").generate_greedy(prompts[b], 16) == grouped[b]

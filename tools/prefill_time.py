@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Prefill wall time by path (GPU box): python tools/prefill_time.py
+   modes: grouped decode GEMMs (default below SPARKMI_PGEMM_MIN_ROWS), k_pgemm (MIN_ROWS=0), 32-row chunks."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+code = r'''
+import os, sys, time, numpy as np
+sys.path.insert(0, os.path.join(%r, "spark-tts_amd"))
+import torch
+from sparkmi import config as Cf, weights as W
+from sparkmi.llm import SparkLLM
+from sparkmi.arena import llm_cfg_struct, pack_llm_arena
+cfg = Cf.spark_0p5b_llm()
+arena = torch.from_numpy(pack_llm_arena(cfg, W.SyntheticLLM(cfg), llm_cfg_struct(cfg, 1, 512, "bf16", True))).to("cuda:0")
+res = []
+for B, P in ((1, 128), (1, 64), (1, 400), (4, 128), (8, 128), (16, 128), (32, 128)):
+    llm = SparkLLM(cfg, None, "cuda:0", max_slots=B, max_positions=512, arena=arena)
+    prompts = [np.random.Generator(np.random.PCG64(1 + b)).integers(0, cfg.vocab_size, size=P).tolist() for b in range(B)]
+    ts = []
+    for it in range(4):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        llm.prefill(prompts); torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    tok = llm.tokens(1)
+    res.append((B, P, round(min(ts), 2), tok[0][0]))
+print(os.environ.get("MODE"), res)
+''' % ROOT
+for mode, env in (("grouped", {"SPARKMI_PGEMM_MIN_ROWS": "100000"}), ("pgemm", {"SPARKMI_PGEMM_MIN_ROWS": "0"}), ("chunks", {"SPARKMI_PREFILL_CHUNKS": "1"})):
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MODE=mode, **env), capture_output=True, text=True)
+    print(r.stdout.strip() or r.stderr[-1500:], flush=True)

@@ -9,13 +9,14 @@ import torch
 from sparkmi import config as Cf, weights as W
 from sparkmi.llm import SparkLLM
 cfg = Cf.spark_0p5b_llm()
-llm = SparkLLM(cfg, W.SyntheticLLM(cfg), "cuda:0", max_positions=512)
-prompt = np.random.Generator(np.random.PCG64(1)).integers(0, cfg.vocab_size, size=128).tolist()
-llm.prefill([prompt]); llm.decode(40); torch.cuda.synchronize()
+B = int(os.environ.get("VARIANTS_B", "1"))
+llm = SparkLLM(cfg, W.SyntheticLLM(cfg), "cuda:0", max_slots=B, max_positions=512)
+prompt = [np.random.Generator(np.random.PCG64(1 + b)).integers(0, cfg.vocab_size, size=128).tolist() for b in range(B)]
+llm.prefill(prompt); llm.decode(40); torch.cuda.synchronize()
 out = []
 for rep in range(2):
     out = [round(llm.time_kernel(n, iters=96) * 1e3, 2) for n in ("qkv", "attn", "o_proj", "gate_up", "down", "lm_head", "finalize")]
-llm.prefill([prompt]); llm.decode(8)
+llm.prefill(prompt); llm.decode(8)
 step = round(llm.time_kernel("step", iters=100) * 1e3, 1)
 print("variant", os.environ.get("SPARKMI_VARIANT", "0"), out, "graph step", step)
 ''' % ROOT
