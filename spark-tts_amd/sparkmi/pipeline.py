@@ -5,12 +5,13 @@ Same constructor and ``inference()`` signature, same attributes (``device``, ``m
 strings, same token parsing, same float32 numpy waveform.  The two heavy calls run on the HIP
 kernels: ``self.model.generate`` (``SparkLLM``) and ``self.audio_tokenizer.detokenize``
 (``BiCodecTokenizer``).  Keyword-only additions: ``do_sample``, ``max_new_tokens``,
-``prompt_tokens`` (pre-computed prompt audio tokens) and ``inference_batch``.
+``prompt_tokens`` (pre-computed prompt audio tokens), ``inference_batch`` and
+``inference_stream`` (chunked vocoding while the LLM generates, the reference's decoupled Triton mode).
 """
 from __future__ import annotations
 
 from pathlib import Path
-from typing import Dict, List, Optional, Sequence, Tuple, Union
+from typing import Dict, Iterator, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
@@ -21,6 +22,7 @@ from .config import LLMConfig, TopConfig
 from .llm import SparkLLM
 from .pipeline_text import (GENDER_MAP, LEVELS_MAP, TASK_TOKEN_MAP, build_clone_prompt,
                             build_control_prompt, parse_global, parse_semantic)
+from .streaming import ChunkScheduler
 from .weights import load_llm_state
 
 
@@ -176,3 +178,60 @@ class SparkTTS:
         wav = wav.squeeze(1).cpu().numpy()
         hop = self.audio_tokenizer.model.hop
         return [wav[b, : lens[b] * hop].copy() for b in range(len(sems))]
+
+    @torch.no_grad()
+    def inference_stream(self, text: str, prompt_speech_path: Path = None, prompt_text: str = None,
+                         gender: str = None, pitch: str = None, speed: str = None,
+                         temperature: float = 0.8, top_k: float = 50, top_p: float = 0.95, *,
+                         do_sample: bool = True, max_new_tokens: int = 3000, seed: Optional[int] = None,
+                         prompt_tokens: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                         audio_chunk_duration: float = 1.0, max_audio_chunk_duration: float = 30.0,
+                         audio_chunk_size_scale_factor: float = 8.0, audio_chunk_overlap_duration: float = 0.1,
+                         decode_stride: int = 10) -> Iterator[np.ndarray]:
+        """Yields float32 waveform chunks while the LLM is still generating, cut and overlapped as
+        the reference's decoupled Triton model does (model.py:347-385; run.sh:53-56 defaults); join
+        them with ``sparkmi.streaming.crossfade(chunks, int(overlap_duration * sample_rate))``
+        (client_grpc.py:390-415).  Every chunk is the vocoder's output for that chunk's tokens alone.
+        ``decode_stride`` = decode steps enqueued between host checks for new tokens."""
+        if gender is not None:
+            prompt, glob = self.process_prompt_control(gender, pitch, speed, text), None
+        else:
+            prompt, g = self.process_prompt(text, prompt_speech_path, prompt_text, prompt_tokens)
+            glob = torch.as_tensor(g).reshape(-1).long()
+        ids = self.tokenizer([prompt], return_tensors="pt").input_ids[0].tolist()
+        if len(ids) + max_new_tokens > self._max_positions:
+            max_new_tokens = self._max_positions - len(ids)
+        voc = self.audio_tokenizer.model
+        ntok, hop = voc.cfg.spk_token_num, voc.hop
+        frame_rate = self.sample_rate // hop
+        sched = ChunkScheduler(audio_chunk_duration, max_audio_chunk_duration, audio_chunk_size_scale_factor,
+                               audio_chunk_overlap_duration, frame_rate)
+        self.model.set_sampling(do_sample, temperature, int(top_k), float(top_p), seed)
+        self.model.prefill([ids], self._eos)
+        produced, n_sem, pending = 1, 0, []
+
+        def vocode(chunk: List[int]) -> np.ndarray:
+            wav = voc.detokenize(torch.tensor([chunk], dtype=torch.long), glob.reshape(1, 1, -1), lengths=[len(chunk)])
+            return wav.reshape(-1)[: len(chunk) * hop].cpu().numpy().copy()
+
+        while True:
+            toks = self.model.tokens(max_new_tokens)[0]
+            sem, gl = self._parse(toks)
+            if glob is None and len(gl) >= ntok:        # voice creation: the speaker tokens are generated first
+                glob = torch.tensor(gl[:ntok], dtype=torch.long)
+            pending += sched.push(sem[n_sem:])
+            n_sem = len(sem)
+            done = produced >= max_new_tokens or self.model.all_done()
+            if done:
+                pending += sched.flush()
+            if glob is not None:
+                for chunk in pending:
+                    yield vocode(chunk)
+                pending = []
+            if done:
+                break
+            n = min(decode_stride, max_new_tokens - produced)
+            self.model.decode(n)
+            produced += n
+        if glob is None:
+            raise ValueError(f"{ntok} global tokens were not generated; the speaker encoder needs them")
