@@ -161,6 +161,56 @@ int smi_voc_debug_stage(smi_voc* h, int stage, float* out_dev, size_t max_floats
 int smi_voc_num_launches(smi_voc* h);
 int smi_voc_time_launch(smi_voc* h, int index, int iters, float* ms_avg, double* flops, char* name, int name_cap, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Prompt encoder (voice cloning): BiCodecTokenizer.tokenize (sparktts/models/audio_tokenizer.py:85-130)
+ * = zero-mean/unit-variance wav -> wav2vec2 (layers below the last tapped hidden state) -> mean of
+ * three hidden states -> BiCodec Encoder -> cosine VQ arg-max (semantic ids); reference clip -> mel
+ * -> ECAPA-TDNN latent -> perceiver resampler -> FSQ (global ids)  (sparktts/models/bicodec.py:151-169).
+ * One utterance per call, as the reference's tokenize().
+ * ---------------------------------------------------------------------------------------- */
+typedef struct smi_enc smi_enc;
+
+typedef struct smi_enc_cfg {
+  /* wav2vec2 (transformers Wav2Vec2Config; layer-norm / stable-layer-norm variant) */
+  int32_t w2v_conv_dim, w2v_nconv;
+  int32_t w2v_kernel[8], w2v_stride[8];
+  int32_t w2v_hidden, w2v_layers /* = max(taps): layers actually run */, w2v_heads, w2v_inter;
+  int32_t w2v_pos_k, w2v_pos_groups;
+  int32_t w2v_taps[3];       /* hidden_states indices averaged (audio_tokenizer.py:96-98) */
+  float w2v_eps;
+  /* BiCodec encoder + quantizer */
+  int32_t enc_in, enc_dim, enc_inter, enc_layers, enc_out, enc_num_down;
+  int32_t codebook_size, codebook_dim;
+  /* mel (bicodec.py:200-211) */
+  int32_t n_fft, win_length, hop_length, num_mels;
+  /* speaker encoder analysis side */
+  int32_t ecapa_channels, ecapa_out, spk_latent, spk_tokens, fsq_dims;
+  int32_t fsq_levels[8];
+  int32_t perc_depth, perc_heads, perc_ff_inner;
+  int32_t max_samples;       /* longest prompt wav (samples) */
+  int32_t max_ref_samples;   /* longest reference clip (samples) */
+} smi_enc_cfg;
+
+/* Arena: like the vocoder's (same entry info and conv packing).  Names are the reference / transformers
+ * state_dict keys ("w2v." + key for wav2vec2), "cat:a|b|c" row concatenations, or derived tensors the host
+ * computes: "bnscale:<bn prefix>" / "bnshift:<bn prefix>" (BatchNorm eval affine), "transpose:<key>",
+ * "mel.dft" ([2*(n_fft/2+1)][n_fft] windowed cos / -sin DFT basis) and "mel.fb" ([num_mels][n_fft/2+1]). */
+int smi_enc_arena_count(const smi_enc_cfg* cfg);
+int smi_enc_arena_entry(const smi_enc_cfg* cfg, int index, char* name, int name_cap,
+                        size_t* offset, size_t* bytes, int32_t* info);
+size_t smi_enc_arena_bytes(const smi_enc_cfg* cfg);
+int smi_enc_create(const smi_enc_cfg* cfg, const void* arena_dev, size_t arena_bytes, smi_enc** out);
+int smi_enc_destroy(smi_enc* h);
+/* wav_dev [n_samples] f32 (volume-normalised, NOT yet zero-mean/unit-var), ref_dev [n_ref] f32 reference clip;
+ * sem_dev [>= frames] int64 out, glob_dev [spk_tokens] int32 out; *n_frames = wav2vec2 frames produced. */
+int smi_enc_forward(smi_enc* h, const float* wav_dev, int n_samples, const float* ref_dev, int n_ref,
+                    int64_t* sem_dev, int32_t* glob_dev, int* n_frames, void* stream);
+/* Test entry: copies a named internal activation of the last forward ("feat", "z", "mel", "ecapa_latent",
+ * "perceiver", "hs0", "conv_feats", "input_values", ...) to out_dev as [rows][cols] f32; dims[2] = {rows, cols}. */
+int smi_enc_debug_stage(smi_enc* h, const char* name, float* out_dev, size_t max_floats, int32_t* dims, void* stream);
+int smi_enc_num_launches(smi_enc* h);
+int smi_enc_time_launch(smi_enc* h, int index, int iters, float* ms_avg, double* flops, char* name, int name_cap, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

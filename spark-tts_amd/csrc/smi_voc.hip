@@ -19,379 +19,9 @@
 // Snake activation (written as a second output), so no standalone elementwise kernel exists.
 // Ragged batches: every kernel masks loads beyond the row's own length, so each row equals an
 // un-padded B=1 run of that row.
-#include "smi_common.h"
-#include <stdio.h>
-#include <string.h>
-#include <string>
-#include <vector>
+#include "smi_net.h"
 
 namespace {
-
-enum { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2 };
-enum { PACK_RAW = 0, PACK_CONV = 1, PACK_CONVT = 2 };
-constexpr int kMaxTaps = 8;     // taps per phase
-constexpr int kMaxPhases = 8;   // ConvTranspose1d stride
-constexpr int kChunk = 32;      // input channels staged per LDS chunk
-
-struct ConvP {
-  const float* X;       // [B][Cin][xstride]
-  const float* W;       // packed, phase-major
-  const float* bias;    // [Cout] or null
-  const float* bbias;   // [B][Cout] per-utterance bias or null
-  const float* gamma;   // [Cout] layer scale or null
-  const float* R;       // residual [B][Cout][ystride] or null (may alias Y)
-  const float* alpha;   // [Cout] Snake alpha for Ys or null
-  float* Y;             // raw output or null
-  float* Ys;            // snake(Y, alpha) or null
-  const int* lens;      // [B] valid INPUT lengths
-  int Cin, CinP, Cout, S, act;
-  int xstride, ystride;
-  long long xb, yb;     // batch strides (floats)
-  int halo_l, xw;       // left halo, staged row width (floats)
-  float out_scale;
-  int ntaps[kMaxPhases];
-  int off[kMaxPhases][kMaxTaps];
-  long long wphase[kMaxPhases];  // float offset of each phase's weights
-};
-
-__device__ __forceinline__ float snake_f(float x, float a) {
-  const float s = sinf(a * x);
-  return x + (1.0f / (a + 1e-9f)) * (s * s);
-}
-__device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
-
-// QB: 32-wide time sub-tiles per wave.  KS: waves split the input channels of ONE 32-row output
-// tile (large C, short T) instead of owning a 32-row output tile each.  CHG: a staged chunk holds
-// 32*CHG input channels (1-tap layers use 128 so a chunk carries enough MFMAs per barrier).  WIDE:
-// the staged row (tile + halo) is wider than 64 columns.
-template <int QB, bool KS, int CHG, bool WIDE>
-__global__ __launch_bounds__(256) void k_conv(ConvP p) {
-  constexpr int kCh = kChunk * CHG;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int QT = QB * 32;
-  const int b = blockIdx.z / p.S, phase = blockIdx.z - b * p.S;
-  const int q0 = blockIdx.x * QT;
-  const int len = p.lens[b];
-  if (q0 >= len) return;
-  const int ct = KS ? blockIdx.y : blockIdx.y * 4 + wave;
-  const bool live = ct * 32 < p.Cout;
-  const int ntap = p.ntaps[phase];
-  const int groups = p.CinP >> 3;
-  const float* Xb = p.X + (long long)b * p.xb;
-  const float4* Wp = (const float4*)(p.W + p.wphase[phase]) + (long long)ct * ntap * groups * 64;
-
-  f32x16 acc[QB];
-#pragma unroll
-  for (int i = 0; i < QB; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-  const int xw = p.xw;
-  // Staging: wave w owns rows 8w..8w+7 of the 32-channel chunk, lanes run along time (coalesced rows).
-  // The next chunk's rows are requested before the MFMAs of the current one and written to LDS after
-  // them, so global latency hides behind the matrix pipe.  With KS each wave multiplies exactly the
-  // rows it staged, so only the wave itself has to see its LDS writes (no block barrier).
-  constexpr int RW = 8 * CHG, NC = WIDE ? 2 : 1;   // rows staged per wave, column registers per row
-  float sreg[RW][NC];
-  auto stage_load = [&](int c0) {
-#pragma unroll
-    for (int r = 0; r < RW; ++r) {
-      const int ci = c0 + wave * RW + r;
-      const float* xr = Xb + (long long)ci * p.xstride;
-#pragma unroll
-      for (int k = 0; k < NC; ++k) {
-        const int col = lane + 64 * k, t = q0 - p.halo_l + col;
-        sreg[r][k] = (ci < p.Cin && col < xw && t >= 0 && t < len) ? xr[t] : 0.f;
-      }
-    }
-  };
-  auto stage_store = [&]() {
-#pragma unroll
-    for (int r = 0; r < RW; ++r) {
-      float* lr = lds + (wave * RW + r) * xw;
-      if (lane < xw) lr[lane] = sreg[r][0];
-      if (WIDE && lane + 64 < xw) lr[lane + 64] = sreg[r][NC - 1];
-    }
-  };
-  stage_load(0);
-  for (int c0 = 0; c0 < p.CinP; c0 += kCh) {
-    if (c0) { if (KS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads(); }   // previous chunk fully read
-    stage_store();
-    if (KS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads();
-    if (c0 + kCh < p.CinP) stage_load(c0 + kCh);
-    if (live) {
-      const int g0 = KS ? wave * CHG : 0, g1 = KS ? (wave + 1) * CHG : 4 * CHG;
-      for (int tap = 0; tap < ntap; ++tap) {
-        const int col0 = p.halo_l + p.off[phase][tap] + (lane & 31);
-        for (int g = g0; g < g1; ++g) {
-          if (c0 + g * 8 >= p.CinP) break;
-          const float4 wv = Wp[((long long)tap * groups + (c0 >> 3) + g) * 64 + lane];
-          const float wa[4] = {wv.x, wv.y, wv.z, wv.w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float* xr = lds + (g * 8 + j * 2 + (lane >> 5)) * xw + col0;
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
-              acc[qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], xr[qb * 32], acc[qb], 0, 0, 0);
-          }
-        }
-      }
-    }
-  }
-
-  if (KS) {
-    // fixed-order reduction of the four waves' partial tiles, then each wave finishes 4 of the 16 rows-groups
-    __syncthreads();
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) lds[((wave * QB + qb) * 16 + r) * 64 + lane] = acc[qb][r];
-    __syncthreads();
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int r = wave * 4 + rr;
-        float s = lds[((0 * QB + qb) * 16 + r) * 64 + lane];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) s += lds[((w * QB + qb) * 16 + r) * 64 + lane];
-        acc[qb][rr] = s;
-      }
-  }
-  if (!live) return;
-
-  const long long yboff = (long long)b * p.yb;
-  const int nreg = KS ? 4 : 16;
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    const int q = q0 + qb * 32 + (lane & 31);
-    if (q >= len) continue;
-    const int t = q * p.S + phase;
-#pragma unroll
-    for (int rr = 0; rr < nreg; ++rr) {
-      const int r = KS ? wave * 4 + rr : rr;
-      const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (co >= p.Cout) continue;
-      float y = acc[qb][rr];
-      if (p.bias) y += p.bias[co];
-      if (p.bbias) y += p.bbias[(long long)b * p.Cout + co];
-      if (p.act == ACT_GELU) y = gelu_f(y);
-      if (p.gamma) y = p.gamma[co] * y;
-      const long long o = yboff + (long long)co * p.ystride + t;
-      if (p.R) y = p.R[o] + y;
-      if (p.act == ACT_TANH) y = tanhf(y);
-      if (p.out_scale != 1.0f) y = (y + y) + y;  // SamplingBlock(ratio 1): x + x + x
-      if (p.Y) p.Y[o] = y;
-      if (p.Ys) p.Ys[o] = snake_f(y, p.alpha[co]);
-    }
-  }
-}
-
-// Linear layer on one vector per utterance (d-vector projection, AdaLN parameters): y[b][co] =
-// bias[co] + sum_ci W[co][ci] x[b][ci], fp32, reading the same packed conv weights (lane l, slot j of
-// group g holds W[32*ct + (l&31)][8g + 2j + (l>>5)]).  One block per 32 outputs, waves split K.
-__global__ __launch_bounds__(256) void k_gemv1(ConvP p) {
-  __shared__ float part[4][32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ct = blockIdx.x, b = blockIdx.y;
-  const int groups = p.CinP >> 3;
-  const float4* Wp = (const float4*)p.W + (long long)ct * groups * 64;
-  const float* x = p.X + (long long)b * p.xb;           // xstride == 1: x[ci]
-  float acc = 0.f;
-  for (int g = wave; g < groups; g += 4) {
-    const float4 w = Wp[(long long)g * 64 + lane];
-    const int ci = g * 8 + (lane >> 5);
-    const float x0 = ci < p.Cin ? x[ci] : 0.f, x1 = ci + 2 < p.Cin ? x[ci + 2] : 0.f;
-    const float x2 = ci + 4 < p.Cin ? x[ci + 4] : 0.f, x3 = ci + 6 < p.Cin ? x[ci + 6] : 0.f;
-    acc += (w.x * x0 + w.y * x1) + (w.z * x2 + w.w * x3);
-  }
-  acc += __shfl_xor(acc, 32, 64);
-  if (lane < 32) part[wave][lane] = acc;
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    const int co = ct * 32 + threadIdx.x;
-    if (co < p.Cout) {
-      float y = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-      if (p.bias) y += p.bias[co];
-      p.Y[(long long)b * p.yb + co] = y;
-    }
-  }
-}
-
-// depthwise conv7 (optional) + LayerNorm / AdaLayerNorm over channels, eps 1e-6 (vocos.py:65-110)
-struct LnP {
-  const float* X;      // [B][C][stride]
-  float* Y;
-  const float* dww;    // [C][7] or null
-  const float* dwb;    // [C]
-  const float* w;      // LN weight [C] (plain) or null
-  const float* bsh;    // LN bias [C]
-  const float* ada;    // AdaLN: [B][ada_stride] with scale at +0, shift at +C; or null
-  const int* lens;
-  int C, stride, ada_stride;
-  long long bs;
-  int triple;          // 1: write 3x (SamplingBlock ratio 1 after final_layer_norm)
-};
-
-template <int CPT>  // channels per thread (C <= 32*CPT): 8 time steps x 32 channel groups per block
-__global__ __launch_bounds__(256) void k_dwln(LnP p) {
-  __shared__ float red[32][8];
-  const int tt = threadIdx.x & 7, cg = threadIdx.x >> 3;
-  const int b = blockIdx.y, t = blockIdx.x * 8 + tt;
-  const int len = p.lens[b];
-  const bool tv = t < len;
-  const float* Xb = p.X + (long long)b * p.bs;
-  float v[CPT];
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < CPT; ++i) {
-    const int c = cg + 32 * i;
-    float x = 0.f;
-    if (c < p.C && tv) {
-      const float* xr = Xb + (long long)c * p.stride;
-      if (p.dww) {
-        x = 0.f;
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
-          const int tj = t + j - 3;
-          const float xv = (tj >= 0 && tj < len) ? xr[tj] : 0.f;
-          x += p.dww[c * 7 + j] * xv;
-        }
-        x += p.dwb[c];
-      } else {
-        x = xr[t];
-      }
-    }
-    v[i] = x;
-    s += x;
-  }
-  red[cg][tt] = s;
-  __syncthreads();
-  float mean = 0.f;
-#pragma unroll
-  for (int g = 0; g < 32; ++g) mean += red[g][tt];
-  mean /= (float)p.C;
-  __syncthreads();
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < CPT; ++i) {
-    const int c = cg + 32 * i;
-    if (c < p.C) { const float d = v[i] - mean; q += d * d; }
-  }
-  red[cg][tt] = q;
-  __syncthreads();
-  float var = 0.f;
-#pragma unroll
-  for (int g = 0; g < 32; ++g) var += red[g][tt];
-  const float rstd = 1.0f / sqrtf(var / (float)p.C + 1e-6f);
-  if (!tv) return;
-  float* Yb = p.Y + (long long)b * p.bs;
-#pragma unroll
-  for (int i = 0; i < CPT; ++i) {
-    const int c = cg + 32 * i;
-    if (c >= p.C) continue;
-    float y = (v[i] - mean) * rstd;
-    if (p.ada) y = y * p.ada[(long long)b * p.ada_stride + c] + p.ada[(long long)b * p.ada_stride + p.C + c];
-    else y = y * p.w[c] + p.bsh[c];
-    if (p.triple) y = (y + y) + y;
-    Yb[(long long)c * p.stride + t] = y;
-  }
-}
-
-// codebook lookup: Z[b][d][t] = codebook[sem[b][t]][d]   (factorized_vector_quantize.py:160-167)
-__global__ void k_codebook(const int64_t* sem, int semstride, const float* cb, int D, int cbsize,
-                           const int* lens, float* Z, int zstride, long long zb) {
-  const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= lens[b]) return;
-  long long id = sem[(long long)b * semstride + t];
-  id = id < 0 ? 0 : (id >= cbsize ? cbsize - 1 : id);
-  for (int d = 0; d < D; ++d) Z[(long long)b * zb + (long long)d * zstride + t] = cb[id * D + d];
-}
-
-// FSQ index -> level codes -> Linear(nd -> latent), written d-major: out[b][d*Ntok + t]
-// (finite_scalar_quantization.py:143-162, residual_fsq.py:191-199, speaker_encoder.py:109-110)
-struct FsqP {
-  const int32_t* glob;  // [B][Ntok]
-  const float* W1;      // [latent][nd]
-  const float* b1;      // [latent]
-  float* out;           // [B][latent*Ntok]
-  int Ntok, latent, nd;
-  int levels[8];
-};
-__global__ void k_fsq(FsqP p) {
-  const int b = blockIdx.x;
-  for (int i = threadIdx.x; i < p.latent * p.Ntok; i += blockDim.x) {
-    const int d = i / p.Ntok, t = i - d * p.Ntok;
-    int idx = p.glob[b * p.Ntok + t];
-    float acc = 0.f;
-    int basis = 1;
-    for (int j = 0; j < p.nd; ++j) {
-      const int L = p.levels[j], half = L / 2;
-      const int lvl = (idx / basis) % L;
-      const float code = (float)(lvl - half) / (float)half;
-      acc += code * p.W1[d * p.nd + j];
-      basis *= L;
-    }
-    p.out[(long long)b * p.latent * p.Ntok + i] = acc + p.b1[d];
-  }
-}
-
-__global__ void k_zero_tail(float* wav, int stride, const int* lens, int hop) {
-  const int b = blockIdx.y;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < stride && t >= lens[b] * hop) wav[(long long)b * stride + t] = 0.f;
-}
-
-// ------------------------------------------------------------------------------------------
-// arena description
-// ------------------------------------------------------------------------------------------
-struct Entry {
-  std::string name;   // reference state_dict key (after remove_weight_norm); "cat:a|b|c" = rows concatenated
-  int kind;           // PACK_*
-  int Cout, Cin, K;   // logical dims (K taps)
-  int S, pad;         // ConvTranspose1d stride / padding
-  size_t offset, bytes;
-};
-
-struct ConvGeom {
-  int S;
-  int ntaps[kMaxPhases];
-  int off[kMaxPhases][kMaxTaps];
-  int tapk[kMaxPhases][kMaxTaps];   // kernel index j of each (phase, tap)
-  long long wphase[kMaxPhases];
-  int halo_l, halo_r;
-  long long floats;
-};
-
-inline int pad8(int c) { return (c + 7) / 8 * 8; }
-inline int pad32(int c) { return (c + 31) / 32 * 32; }
-
-// Conv1d (S = 1): tap j reads x[t + j*dil - pad].  ConvTranspose1d (stride S, padding pad):
-// out[q*S + r] += W[ci][co][j] * x[ci][(q*S + r + pad - j)/S] for j == (r + pad) mod S.
-ConvGeom conv_geom(int Cout, int Cin, int K, int dil, int pad, int S) {
-  ConvGeom g;
-  memset(&g, 0, sizeof(g));
-  g.S = S;
-  long long o = 0;
-  int lo = 0, hi = 0;
-  const long long per_tap = (long long)(pad32(Cout) / 32) * (pad8(Cin) / 8) * 256;
-  for (int r = 0; r < S; ++r) {
-    g.wphase[r] = o;
-    int n = 0;
-    if (S == 1) {
-      for (int j = 0; j < K; ++j) { g.off[r][n] = j * dil - pad; g.tapk[r][n] = j; ++n; }
-    } else {
-      const int j0 = (r + pad) % S, c = (r + pad) / S;
-      for (int i = 0; j0 + S * i < K; ++i) { g.off[r][n] = c - i; g.tapk[r][n] = j0 + S * i; ++n; }
-    }
-    g.ntaps[r] = n;
-    for (int i = 0; i < n; ++i) { lo = g.off[r][i] < lo ? g.off[r][i] : lo; hi = g.off[r][i] > hi ? g.off[r][i] : hi; }
-    o += per_tap * n;
-  }
-  g.halo_l = -lo; g.halo_r = hi; g.floats = o;
-  return g;
-}
 
 struct VocLayout {
   std::vector<Entry> e;
@@ -498,19 +128,6 @@ VocLayout voc_layout(const smi_voc_cfg* c) {
   return L;
 }
 
-struct Launch {
-  int kind;          // 0 conv, 1 dwln, 2 codebook, 3 fsq, 4 zero-tail
-  std::string name;
-  double flops;
-  ConvP cp; int qb; bool ks; int chg; bool gemv; dim3 grid; size_t lds;
-  LnP lp; int cpt;
-  // small kernels keep their args here
-  const int64_t* sem; int semstride; const float* cb; int D, cbsize; float* Z; int zstride; long long zb;
-  FsqP fp; int B;
-  float* wav; int wstride, hop, tmaxhop;
-  const int* lens;
-};
-
 }  // namespace
 
 struct smi_voc {
@@ -536,86 +153,12 @@ const float* ent(const smi_voc* h, const std::string& name) {
   return nullptr;
 }
 
-int run_launch(const Launch& L, hipStream_t st) {
-  switch (L.kind) {
-    case 0:
-      if (L.gemv) {
-        hipLaunchKernelGGL(k_gemv1, L.grid, dim3(256), 0, st, L.cp);
-      } else if (L.chg == 4) {      // 1-tap layers: 128-channel chunks, narrow rows
-        if (L.ks) {
-          if (L.qb == 1) hipLaunchKernelGGL((k_conv<1, true, 4, false>), L.grid, dim3(256), L.lds, st, L.cp);
-          else hipLaunchKernelGGL((k_conv<2, true, 4, false>), L.grid, dim3(256), L.lds, st, L.cp);
-        } else {
-          if (L.qb == 1) hipLaunchKernelGGL((k_conv<1, false, 4, false>), L.grid, dim3(256), L.lds, st, L.cp);
-          else hipLaunchKernelGGL((k_conv<2, false, 4, false>), L.grid, dim3(256), L.lds, st, L.cp);
-        }
-      } else if (L.ks) {
-        if (L.qb == 1) hipLaunchKernelGGL((k_conv<1, true, 1, true>), L.grid, dim3(256), L.lds, st, L.cp);
-        else hipLaunchKernelGGL((k_conv<2, true, 1, true>), L.grid, dim3(256), L.lds, st, L.cp);
-      } else {
-        if (L.qb == 1) hipLaunchKernelGGL((k_conv<1, false, 1, true>), L.grid, dim3(256), L.lds, st, L.cp);
-        else hipLaunchKernelGGL((k_conv<2, false, 1, true>), L.grid, dim3(256), L.lds, st, L.cp);
-      }
-      break;
-    case 1:
-      if (L.cpt <= 2) hipLaunchKernelGGL(k_dwln<2>, L.grid, dim3(256), 0, st, L.lp);
-      else if (L.cpt <= 4) hipLaunchKernelGGL(k_dwln<4>, L.grid, dim3(256), 0, st, L.lp);
-      else if (L.cpt <= 12) hipLaunchKernelGGL(k_dwln<12>, L.grid, dim3(256), 0, st, L.lp);
-      else hipLaunchKernelGGL(k_dwln<16>, L.grid, dim3(256), 0, st, L.lp);
-      break;
-    case 2:
-      hipLaunchKernelGGL(k_codebook, L.grid, dim3(128), 0, st, L.sem, L.semstride, L.cb, L.D, L.cbsize, L.lens, L.Z, L.zstride, L.zb);
-      break;
-    case 3:
-      hipLaunchKernelGGL(k_fsq, dim3(L.B), dim3(256), 0, st, L.fp);
-      break;
-    case 4:
-      hipLaunchKernelGGL(k_zero_tail, L.grid, dim3(256), 0, st, L.wav, L.wstride, L.lens, L.hop);
-      break;
-  }
-  SMI_LAUNCH_CHECK();
-  return SMI_OK;
-}
-
-// Build one conv launch.  X/Y strides are in floats; Lmax = padded INPUT length (time units).
 Launch make_conv(const smi_voc* h, const std::string& name, const std::string& wname, const char* bname,
                  int Cout, int Cin, int K, int dil, int S, int pad, const float* X, int xstride, long long xb,
                  float* Y, float* Ys, const float* alpha, const float* R, int ystride, long long yb,
                  const int* lens, int B, int Lmax, int act) {
-  Launch L;
-  L.kind = 0; L.name = name;
-  ConvGeom g = conv_geom(Cout, Cin, K, dil, pad, S);
-  ConvP& p = L.cp;
-  memset(&p, 0, sizeof(p));
-  p.X = X; p.W = ent(h, wname); p.bias = bname ? ent(h, bname) : nullptr;
-  p.R = R; p.alpha = alpha; p.Y = Y; p.Ys = Ys; p.lens = lens;
-  p.Cin = Cin; p.CinP = pad8(Cin); p.Cout = Cout; p.S = S; p.act = act;
-  p.xstride = xstride; p.ystride = ystride; p.xb = xb; p.yb = yb;
-  p.out_scale = 1.0f;
-  for (int r = 0; r < S; ++r) {
-    p.ntaps[r] = g.ntaps[r];
-    p.wphase[r] = g.wphase[r];
-    for (int i = 0; i < g.ntaps[r]; ++i) p.off[r][i] = g.off[r][i];
-  }
-  const int cot = pad32(Cout) / 32;
-  // waves split the input channels when there are few time tiles and many channels
-  const int qb = (Lmax <= 32) ? 1 : 2;
-  const int qt = qb * 32, nq = (Lmax + qt - 1) / qt;
-  const long long blocks_cosplit = (long long)nq * ((cot + 3) / 4) * B * S;
-  L.ks = (blocks_cosplit < 512 || cot % 4 != 0) && Cin >= 8;
-  L.qb = qb;
-  p.halo_l = g.halo_l;
-  p.xw = qt + g.halo_l + g.halo_r;
-  L.grid = dim3(nq, L.ks ? cot : (cot + 3) / 4, B * S);
-  L.chg = (S == 1 && K == 1 && Cin >= 128 && L.ks) ? 4 : 1;   // K-split 1-tap layers stage 128 channels per chunk
-  L.gemv = false;   // set by the caller for the per-utterance vector projections (use_gemv)
-  size_t lds = (size_t)kChunk * L.chg * p.xw * 4;
-  const size_t red = L.ks ? (size_t)4 * qb * 16 * 64 * 4 : 0;
-  L.lds = lds > red ? lds : red;
-  double taps = 0;
-  for (int r = 0; r < S; ++r) taps += g.ntaps[r];
-  L.flops = 2.0 * Cout * Cin * taps * Lmax * B;   // all phases together cover S*Lmax outputs
-  return L;
+  return make_conv_w(name, ent(h, wname), bname ? ent(h, bname) : nullptr, Cout, Cin, K, dil, S, pad, X, xstride, xb, Y, Ys,
+                     alpha, R, ystride, yb, lens, B, Lmax, act);
 }
 
 }  // namespace
@@ -798,6 +341,7 @@ int smi_voc_forward(smi_voc* h, const int64_t* sem_dev, const int32_t* lens_host
     Launch L; L.kind = 1; L.name = name; L.flops = (dww ? 14.0 : 0.0) * D * T * B + 8.0 * D * T * B;
     LnP& p = L.lp; memset(&p, 0, sizeof(p));
     p.X = X; p.Y = Y; p.dww = dww; p.dwb = dwb; p.lens = len0; p.C = D; p.stride = T; p.bs = bs; p.triple = triple;
+    p.eps = 1e-6f;
     if (ada_norm) { p.ada = ada + (size_t)ada_idx * 2 * D; p.ada_stride = ada_stride; ++ada_idx; }
     else { p.w = ent(h, pfx + ".weight"); p.bsh = ent(h, pfx + ".bias"); }
     L.cpt = (D + 31) / 32; L.grid = dim3((T + 7) / 8, B);

@@ -37,6 +37,17 @@ class VocCfg(C.Structure):
         + [("max_batch", C.c_int32), ("max_frames", C.c_int32)])
 
 
+class EncCfg(C.Structure):
+    _fields_ = ([("w2v_conv_dim", C.c_int32), ("w2v_nconv", C.c_int32), ("w2v_kernel", C.c_int32 * 8), ("w2v_stride", C.c_int32 * 8)]
+                + [(n, C.c_int32) for n in ("w2v_hidden", "w2v_layers", "w2v_heads", "w2v_inter", "w2v_pos_k", "w2v_pos_groups")]
+                + [("w2v_taps", C.c_int32 * 3), ("w2v_eps", C.c_float)]
+                + [(n, C.c_int32) for n in ("enc_in", "enc_dim", "enc_inter", "enc_layers", "enc_out", "enc_num_down",
+                                            "codebook_size", "codebook_dim", "n_fft", "win_length", "hop_length", "num_mels",
+                                            "ecapa_channels", "ecapa_out", "spk_latent", "spk_tokens", "fsq_dims")]
+                + [("fsq_levels", C.c_int32 * 8)]
+                + [(n, C.c_int32) for n in ("perc_depth", "perc_heads", "perc_ff_inner", "max_samples", "max_ref_samples")])
+
+
 # section ids of enum smi_llm_section
 (LLM_LN1, LLM_WQKV, LLM_BQKV, LLM_WO, LLM_LN2, LLM_WGU, LLM_WD,
  LLM_FINAL_NORM, LLM_LM_HEAD, LLM_ROPE) = range(10)
@@ -69,6 +80,15 @@ SYMBOLS = {
     "smi_voc_debug_stage": (_I, [_VP, _I, _VP, _SZ, _P(_SZ), _VP]),
     "smi_voc_num_launches": (_I, [_VP]),
     "smi_voc_time_launch": (_I, [_VP, _I, _I, _P(C.c_float), _P(C.c_double), C.c_char_p, _I, _VP]),
+    "smi_enc_arena_count": (_I, [_P(EncCfg)]),
+    "smi_enc_arena_entry": (_I, [_P(EncCfg), _I, C.c_char_p, _I, _P(_SZ), _P(_SZ), _P(C.c_int32)]),
+    "smi_enc_arena_bytes": (_SZ, [_P(EncCfg)]),
+    "smi_enc_create": (_I, [_P(EncCfg), _VP, _SZ, _P(_VP)]),
+    "smi_enc_destroy": (_I, [_VP]),
+    "smi_enc_forward": (_I, [_VP, _VP, _I, _VP, _I, _VP, _VP, _P(_I), _VP]),
+    "smi_enc_debug_stage": (_I, [_VP, C.c_char_p, _VP, _SZ, _P(C.c_int32), _VP]),
+    "smi_enc_num_launches": (_I, [_VP]),
+    "smi_enc_time_launch": (_I, [_VP, _I, _I, _P(C.c_float), _P(C.c_double), C.c_char_p, _I, _VP]),
 }
 
 _lib = None

@@ -1,0 +1,176 @@
+"""Configs of the voice-clone prompt encode: ``BiCodecTokenizer.tokenize``
+(``sparktts/models/audio_tokenizer.py:85-130``) = wav2vec2-large-xlsr-53 features -> BiCodec
+encoder -> cosine VQ (semantic tokens), and mel -> ECAPA-TDNN -> perceiver -> FSQ (global tokens)."""
+from __future__ import annotations
+
+import json
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import List, Tuple
+
+import yaml
+
+
+@dataclass
+class Wav2Vec2Cfg:
+    """``{model_dir}/wav2vec2-large-xlsr-53/config.json`` (transformers ``Wav2Vec2Config``)."""
+
+    conv_dim: List[int] = field(default_factory=lambda: [512] * 7)
+    conv_kernel: List[int] = field(default_factory=lambda: [10, 3, 3, 3, 3, 2, 2])
+    conv_stride: List[int] = field(default_factory=lambda: [5, 2, 2, 2, 2, 2, 2])
+    conv_bias: bool = True
+    hidden_size: int = 1024
+    num_hidden_layers: int = 24
+    num_attention_heads: int = 16
+    intermediate_size: int = 4096
+    num_conv_pos_embeddings: int = 128
+    num_conv_pos_embedding_groups: int = 16
+    layer_norm_eps: float = 1e-5
+    feat_extract_norm: str = "layer"
+    do_stable_layer_norm: bool = True
+    hidden_act: str = "gelu"
+    feat_extract_activation: str = "gelu"
+    # hidden states the tokenizer averages (audio_tokenizer.py:96-98); only layers < max(taps) run
+    taps: Tuple[int, int, int] = (11, 14, 16)
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+    @property
+    def used_layers(self) -> int:
+        return max(self.taps)
+
+    @property
+    def hop(self) -> int:
+        h = 1
+        for s in self.conv_stride:
+            h *= s
+        return h
+
+    def frames(self, samples: int) -> int:
+        n = samples
+        for k, s in zip(self.conv_kernel, self.conv_stride):
+            n = (n - k) // s + 1
+        return n
+
+    @classmethod
+    def from_json(cls, path) -> "Wav2Vec2Cfg":
+        raw = json.loads(Path(path).read_text())
+        keys = set(cls.__dataclass_fields__) - {"taps"}
+        return cls(**{k: (list(v) if isinstance(v, list) else v) for k, v in raw.items() if k in keys})
+
+    def to_json(self, path) -> None:
+        d = {k: getattr(self, k) for k in self.__dataclass_fields__ if k != "taps"}
+        d.update(model_type="wav2vec2", architectures=["Wav2Vec2Model"], num_feat_extract_layers=len(self.conv_dim),
+                 hidden_dropout=0.0, activation_dropout=0.0, attention_dropout=0.0, feat_proj_dropout=0.0,
+                 layerdrop=0.0, vocab_size=32)
+        Path(path).write_text(json.dumps(d, indent=1))
+
+    def validate(self) -> None:
+        if self.feat_extract_norm != "layer" or not self.do_stable_layer_norm:
+            raise ValueError("only the layer-norm / stable-layer-norm wav2vec2 variant (xlsr-53) is on the path")
+        if self.head_dim != 64:
+            raise ValueError(f"attention head_dim must be 64 (got {self.head_dim})")
+        if self.conv_dim[0] % 32 or len(set(self.conv_dim)) != 1:
+            raise ValueError("conv_dim must be one value, a multiple of 32")
+        if self.used_layers > self.num_hidden_layers:
+            raise ValueError("hidden-state tap beyond num_hidden_layers")
+        if self.num_conv_pos_embeddings % 2:
+            raise ValueError("odd positional-conv kernels are not handled (xlsr-53 uses 128)")
+        if self.hidden_size % self.num_conv_pos_embedding_groups:
+            raise ValueError("hidden_size not divisible by the positional-conv groups")
+
+
+def xlsr53() -> Wav2Vec2Cfg:
+    return Wav2Vec2Cfg()
+
+
+def tiny_wav2vec2() -> Wav2Vec2Cfg:
+    """Same structure at reduced dims (2 heads x 64, 4 layers, taps 2/3/4)."""
+    return Wav2Vec2Cfg(conv_dim=[32] * 7, hidden_size=128, num_hidden_layers=5, num_attention_heads=2,
+                       intermediate_size=256, num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4,
+                       taps=(2, 3, 4))
+
+
+@dataclass
+class TokCfg:
+    """The tokenize half of ``BiCodec/config.yaml['audio_tokenizer']``: encoder, mel_params and the
+    analysis side of speaker_encoder (the quantizer / speaker dims shared with ``BiCodecConfig``)."""
+
+    # encoder (feat_encoder.py Encoder)
+    enc_input_channels: int = 1024
+    enc_vocos_dim: int = 384
+    enc_intermediate_dim: int = 2048
+    enc_num_layers: int = 12
+    enc_out_channels: int = 1024
+    enc_sample_ratios: List[int] = field(default_factory=lambda: [1, 1])
+    # quantizer
+    codebook_size: int = 8192
+    codebook_dim: int = 8
+    # mel_params (bicodec.py:200-211)
+    sample_rate: int = 16000
+    n_fft: int = 1024
+    win_length: int = 640
+    hop_length: int = 320
+    mel_fmin: float = 10.0
+    mel_fmax: float = None
+    num_mels: int = 128
+    # speaker encoder (speaker_encoder.py:55-69): ECAPA_TDNN_GLOB_c512, perceiver, FSQ
+    ecapa_channels: int = 512
+    ecapa_out: int = 1536   # ECAPA_TDNN hard-codes 512 * 3 (ecapa_tdnn.py:171), as does the perceiver's dim_context
+    spk_latent_dim: int = 128
+    spk_token_num: int = 32
+    fsq_levels: List[int] = field(default_factory=lambda: [4, 4, 4, 4, 4, 4])
+    perceiver_depth: int = 2
+    perceiver_heads: int = 8
+    perceiver_dim_head: int = 64
+    perceiver_ff_mult: int = 4
+
+    @property
+    def ff_inner(self) -> int:
+        return int(self.spk_latent_dim * self.perceiver_ff_mult * 2 / 3)
+
+    @classmethod
+    def from_yaml(cls, path) -> "TokCfg":
+        raw = yaml.safe_load(Path(path).read_text())
+        at = raw["audio_tokenizer"] if "audio_tokenizer" in raw else raw
+        e, q, s, m = at["encoder"], at["quantizer"], at["speaker_encoder"], at["mel_params"]
+        return cls(enc_input_channels=e["input_channels"], enc_vocos_dim=e["vocos_dim"],
+                   enc_intermediate_dim=e["vocos_intermediate_dim"], enc_num_layers=e["vocos_num_layers"],
+                   enc_out_channels=e["out_channels"], enc_sample_ratios=list(e.get("sample_ratios", [1, 1])),
+                   codebook_size=q["codebook_size"], codebook_dim=q["codebook_dim"],
+                   sample_rate=m["sample_rate"], n_fft=m["n_fft"], win_length=m["win_length"],
+                   hop_length=m["hop_length"], mel_fmin=m["mel_fmin"], mel_fmax=m.get("mel_fmax"),
+                   num_mels=m["num_mels"], spk_latent_dim=s["latent_dim"], spk_token_num=s["token_num"],
+                   fsq_levels=list(s["fsq_levels"]))
+
+    def to_yaml_dict(self) -> dict:
+        return {"encoder": {"input_channels": self.enc_input_channels, "vocos_dim": self.enc_vocos_dim,
+                            "vocos_intermediate_dim": self.enc_intermediate_dim,
+                            "vocos_num_layers": self.enc_num_layers, "out_channels": self.enc_out_channels,
+                            "sample_ratios": list(self.enc_sample_ratios)},
+                "mel_params": {"sample_rate": self.sample_rate, "n_fft": self.n_fft, "win_length": self.win_length,
+                               "hop_length": self.hop_length, "mel_fmin": self.mel_fmin, "mel_fmax": self.mel_fmax,
+                               "num_mels": self.num_mels}}
+
+    def validate(self) -> None:
+        if self.enc_sample_ratios != [1] * len(self.enc_sample_ratios):
+            raise ValueError("encoder sample_ratios other than 1 are not on the path")
+        if self.ecapa_channels % 8 or (self.ecapa_channels // 8) % 8:
+            raise ValueError("ECAPA channels must split into 8 Res2Net branches of a multiple of 8")
+        if self.perceiver_dim_head != 64:
+            raise ValueError("perceiver dim_head must be 64")
+        if self.n_fft % 2 or self.win_length > self.n_fft:
+            raise ValueError("mel: n_fft must be even and win_length <= n_fft")
+
+
+def spark_0p5b_tok() -> TokCfg:
+    return TokCfg()
+
+
+def tiny_tok() -> TokCfg:
+    return TokCfg(enc_input_channels=128, enc_vocos_dim=32, enc_intermediate_dim=96, enc_num_layers=2,
+                  enc_out_channels=64, codebook_size=256, codebook_dim=8, n_fft=256, win_length=160,
+                  hop_length=80, num_mels=24, ecapa_channels=64, spk_latent_dim=16,
+                  spk_token_num=8, perceiver_heads=2)

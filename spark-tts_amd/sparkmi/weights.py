@@ -254,3 +254,167 @@ def load_bicodec_state(bicodec_dir) -> Dict[str, np.ndarray]:
         for k in sf.keys():
             out[k] = sf.get_tensor(k).to(torch.float32).numpy()
     return out
+
+
+# --------------------------------------------------------------------------- prompt encode
+def wav2vec2_state(cfg, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Synthetic ``Wav2Vec2Model`` state dict under transformers' key names (layers beyond the last
+    hidden-state tap are not generated: the tokenizer never runs them)."""
+    sd: Dict[str, np.ndarray] = {}
+    N = lambda name, shape, std=1.0, mean=0.0: normal("w2v." + name, shape, std, mean, seed)  # noqa: E731
+    cin = 1
+    for i, (c, k) in enumerate(zip(cfg.conv_dim, cfg.conv_kernel)):
+        p = f"feature_extractor.conv_layers.{i}"
+        sd[p + ".conv.weight"] = N(p + ".conv.weight", (c, cin, k), 1.4 / np.sqrt(cin * k))
+        if cfg.conv_bias:
+            sd[p + ".conv.bias"] = N(p + ".conv.bias", (c,), 0.05)
+        sd[p + ".layer_norm.weight"] = N(p + ".layer_norm.weight", (c,), 0.1, 1.0)
+        sd[p + ".layer_norm.bias"] = N(p + ".layer_norm.bias", (c,), 0.05)
+        cin = c
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    sd["feature_projection.layer_norm.weight"] = N("feature_projection.layer_norm.weight", (cin,), 0.1, 1.0)
+    sd["feature_projection.layer_norm.bias"] = N("feature_projection.layer_norm.bias", (cin,), 0.05)
+    sd["feature_projection.projection.weight"] = N("feature_projection.projection.weight", (H, cin), 1.0 / np.sqrt(cin))
+    sd["feature_projection.projection.bias"] = N("feature_projection.projection.bias", (H,), 0.02)
+    K, G = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
+    pc = "encoder.pos_conv_embed.conv"
+    sd[pc + ".parametrizations.weight.original1"] = N(pc + ".v", (H, H // G, K), 1.0)
+    g = np.sqrt(H * (H // G)) * 0.7 / np.sqrt(K * (H // G)) * (1.0 + 0.1 * N(pc + ".g", (1, 1, K), 1.0))
+    sd[pc + ".parametrizations.weight.original0"] = g.astype(np.float32)
+    sd[pc + ".bias"] = N(pc + ".bias", (H,), 0.02)
+    for l in range(cfg.used_layers):
+        p = f"encoder.layers.{l}"
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[f"{p}.attention.{nm}.weight"] = N(f"{p}.attention.{nm}.weight", (H, H), (1.6 if nm in ("q_proj", "k_proj") else 0.8) / np.sqrt(H))
+            sd[f"{p}.attention.{nm}.bias"] = N(f"{p}.attention.{nm}.bias", (H,), 0.02)
+        for nm in ("layer_norm", "final_layer_norm"):
+            sd[f"{p}.{nm}.weight"] = N(f"{p}.{nm}.weight", (H,), 0.1, 1.0)
+            sd[f"{p}.{nm}.bias"] = N(f"{p}.{nm}.bias", (H,), 0.05)
+        sd[f"{p}.feed_forward.intermediate_dense.weight"] = N(f"{p}.ffn.in.weight", (I, H), 1.0 / np.sqrt(H))
+        sd[f"{p}.feed_forward.intermediate_dense.bias"] = N(f"{p}.ffn.in.bias", (I,), 0.02)
+        sd[f"{p}.feed_forward.output_dense.weight"] = N(f"{p}.ffn.out.weight", (H, I), 0.8 / np.sqrt(I))
+        sd[f"{p}.feed_forward.output_dense.bias"] = N(f"{p}.ffn.out.bias", (H,), 0.02)
+    return sd
+
+
+def fold_pos_conv_weight_norm(sd: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """``encoder.pos_conv_embed.conv.weight`` from its weight-norm parametrization (dim=2:
+    ``w = g * v / ||v||`` with the norm over dims (0, 1)), under either key spelling."""
+    import torch
+    out = dict(sd)
+    pc = "encoder.pos_conv_embed.conv"
+    for gk, vk in ((pc + ".parametrizations.weight.original0", pc + ".parametrizations.weight.original1"),
+                   (pc + ".weight_g", pc + ".weight_v")):
+        if gk in out:
+            g = torch.from_numpy(np.ascontiguousarray(out.pop(gk), dtype=np.float32))
+            v = torch.from_numpy(np.ascontiguousarray(out.pop(vk), dtype=np.float32))
+            out[pc + ".weight"] = torch._weight_norm(v, g, 2).numpy()
+    return out
+
+
+def load_wav2vec2_state(w2v_dir) -> Dict[str, np.ndarray]:
+    """``wav2vec2-large-xlsr-53/`` weights (safetensors or pytorch_model.bin) as fp32 numpy; a
+    ``wav2vec2.`` prefix (``Wav2Vec2ForPreTraining`` checkpoints) is stripped."""
+    import torch
+    d = Path(w2v_dir)
+    out = {}
+    files = sorted(d.glob("*.safetensors"))
+    if files:
+        from safetensors import safe_open
+        for f in files:
+            with safe_open(str(f), framework="pt") as sf:
+                for k in sf.keys():
+                    out[k] = sf.get_tensor(k).to(torch.float32).numpy()
+    elif (d / "pytorch_model.bin").exists():
+        for k, v in torch.load(str(d / "pytorch_model.bin"), map_location="cpu", weights_only=True).items():
+            out[k] = v.to(torch.float32).numpy()
+    else:
+        raise FileNotFoundError(f"no wav2vec2 weights under {d}")
+    return {(k[len("wav2vec2."):] if k.startswith("wav2vec2.") else k): v for k, v in out.items()}
+
+
+def bicodec_tok_state(tcfg, vq_input_dim: int, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Synthetic state dict for the parameters ``BiCodec.tokenize`` touches (bicodec.py:151-169),
+    reference key names: ``encoder.*``, ``quantizer.in_project`` + codebook, and the analysis side
+    of ``speaker_encoder.*`` (ECAPA-TDNN up to its latent, perceiver, FSQ project_in)."""
+    sd: Dict[str, np.ndarray] = {}
+    N = lambda name, shape, std=1.0, mean=0.0: normal(name, shape, std, mean, seed)  # noqa: E731
+    D, I = tcfg.enc_vocos_dim, tcfg.enc_intermediate_dim
+
+    def lin(prefix, o, i, std=None, bias=True):
+        sd[prefix + ".weight"] = N(prefix + ".weight", (o, i), std or 1.0 / np.sqrt(i))
+        if bias:
+            sd[prefix + ".bias"] = N(prefix + ".bias", (o,), 0.02)
+
+    def lnorm(prefix, d):
+        sd[prefix + ".weight"] = N(prefix + ".weight", (d,), 0.1, 1.0)
+        sd[prefix + ".bias"] = N(prefix + ".bias", (d,), 0.05)
+
+    def vocos(prefix, cin, nlayers):
+        sd[prefix + ".embed.weight"] = N(prefix + ".embed.weight", (D, cin, 7), 1.0 / np.sqrt(7 * cin))
+        sd[prefix + ".embed.bias"] = N(prefix + ".embed.bias", (D,), 0.02)
+        lnorm(prefix + ".norm", D)
+        for j in range(nlayers):
+            b = f"{prefix}.convnext.{j}"
+            sd[b + ".gamma"] = N(b + ".gamma", (D,), 0.05, 0.5)
+            sd[b + ".dwconv.weight"] = N(b + ".dwconv.weight", (D, 1, 7), 1.0 / np.sqrt(7))
+            sd[b + ".dwconv.bias"] = N(b + ".dwconv.bias", (D,), 0.02)
+            lnorm(b + ".norm", D)
+            lin(b + ".pwconv1", I, D)
+            lin(b + ".pwconv2", D, I)
+        lnorm(prefix + ".final_layer_norm", D)
+
+    vocos("encoder.encoder", tcfg.enc_input_channels, tcfg.enc_num_layers)
+    for i in range(len(tcfg.enc_sample_ratios)):
+        vocos(f"encoder.downsample.{i}.1", D, 2)
+    lin("encoder.project", tcfg.enc_out_channels, D)
+    sd["quantizer.codebook.weight"] = N("quantizer.codebook.weight", (tcfg.codebook_size, tcfg.codebook_dim), 1.0)
+    _wn(sd, "quantizer.in_project", (tcfg.codebook_dim, vq_input_dim, 1), gain=1.0, seed=seed)
+
+    # ECAPA-TDNN (ecapa_tdnn.py:152-208), only what produces `latent`
+    C, F, W = tcfg.ecapa_channels, tcfg.num_mels, tcfg.ecapa_channels // 8
+    se = "speaker_encoder.speaker_encoder"
+
+    def bn(prefix, c):
+        sd[prefix + ".weight"] = N(prefix + ".weight", (c,), 0.1, 1.0)
+        sd[prefix + ".bias"] = N(prefix + ".bias", (c,), 0.05)
+        sd[prefix + ".running_mean"] = N(prefix + ".running_mean", (c,), 0.1, 0.2)
+        sd[prefix + ".running_var"] = np.abs(N(prefix + ".running_var", (c,), 0.1, 0.5)).astype(np.float32) + 0.1
+
+    def conv(prefix, o, i, k, std=None):
+        sd[prefix + ".weight"] = N(prefix + ".weight", (o, i, k), std or 1.4 / np.sqrt(i * k))
+        sd[prefix + ".bias"] = N(prefix + ".bias", (o,), 0.05)
+
+    conv(se + ".layer1.conv", C, F, 5)
+    bn(se + ".layer1.bn", C)
+    for li in (2, 3, 4):
+        b = f"{se}.layer{li}.se_res2block"
+        conv(b + ".0.conv", C, C, 1)
+        bn(b + ".0.bn", C)
+        for j in range(7):
+            conv(f"{b}.1.convs.{j}", W, W, 3)
+            bn(f"{b}.1.bns.{j}", W)
+        conv(b + ".2.conv", C, C, 1)
+        bn(b + ".2.bn", C)
+        lin(b + ".3.linear1", 128, C)
+        lin(b + ".3.linear2", C, 128)
+    conv(se + ".conv", tcfg.ecapa_out, 3 * C, 1)
+
+    # perceiver resampler (perceiver_encoder.py:297-350)
+    ps = "speaker_encoder.perceiver_sampler"
+    L, inner = tcfg.spk_latent_dim, tcfg.perceiver_heads * tcfg.perceiver_dim_head
+    lin(ps + ".proj_context", L, tcfg.ecapa_out)
+    sd[ps + ".latents"] = N(ps + ".latents", (tcfg.spk_token_num, L), 1.0)
+    for i in range(tcfg.perceiver_depth):
+        a = f"{ps}.layers.{i}.0"
+        lin(a + ".to_q", inner, L, std=1.5 / np.sqrt(L), bias=False)
+        lin(a + ".to_kv", 2 * inner, L, std=1.5 / np.sqrt(L), bias=False)
+        lin(a + ".to_out", L, inner, bias=False)
+        f = f"{ps}.layers.{i}.1"
+        lin(f + ".0", 2 * tcfg.ff_inner, L)
+        lin(f + ".2", L, tcfg.ff_inner)
+    sd[ps + ".norm.gamma"] = N(ps + ".norm.gamma", (L,), 0.1, 1.0)
+    nl = len(tcfg.fsq_levels)
+    sd["speaker_encoder.quantizer.project_in.weight"] = N("speaker_encoder.quantizer.project_in.weight", (nl, L), 1.2 / np.sqrt(L))
+    sd["speaker_encoder.quantizer.project_in.bias"] = N("speaker_encoder.quantizer.project_in.bias", (nl,), 0.1)
+    return sd

