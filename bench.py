@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probes", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=32, help="decode tokens in the bounded CPU sample")
+    ap.add_argument("--clone", action="store_true",
+                    help="voice-clone path (BASELINE configs[4]): every utterance first encodes a prompt wav on the GPU "
+                         "(wav2vec2 + BiCodec encoder + speaker encoder), its tokens join the LLM prompt; use with --batch 8")
+    ap.add_argument("--prompt-seconds", type=float, default=6.0, help="--clone: length of each synthetic prompt wav")
     return ap.parse_args()
 
 
@@ -146,6 +150,11 @@ def main():
     llm_cfg, voc_cfg = C.spark_0p5b_llm(), C.spark_0p5b_bicodec()
     B, P, N = a.batch, a.prompt_len, a.new_tokens
     max_pos = P + N + 80
+    if a.clone:
+        from sparkmi import config_tok as T
+        from sparkmi.encoder import BiCodecEncoder, get_ref_clip
+        wcfg, tcfg = T.xlsr53(), T.spark_0p5b_tok()
+        max_pos += wcfg.frames(int(16000 * a.prompt_seconds)) + tcfg.spk_token_num
     cs_llm = A.llm_cfg_struct(llm_cfg, B, max_pos, a.kv, not a.no_graph)
     cs_voc = BC.voc_cfg_struct(voc_cfg, B, N + 10)
 
@@ -164,6 +173,23 @@ def main():
     llm = SparkLLM(llm_cfg, None, dev, max_slots=B, max_positions=max_pos, kv_dtype=a.kv,
                    use_graph=not a.no_graph, arena=llm_arena)
     voc = BiCodecVocoder(voc_cfg, None, dev, max_batch=B, max_frames=N + 10, arena=voc_arena)
+    enc = None
+    if a.clone:
+        if rank == 0:
+            log("building the prompt encoder (wav2vec2-large-xlsr-53 shape, 16 layers + BiCodec tokenizer side)")
+        # every rank builds its own copy of the 1 GB encoder arena from the same seeds (no second broadcast path)
+        enc = BiCodecEncoder(wcfg, tcfg, W.fold_pos_conv_weight_norm(W.wav2vec2_state(wcfg)),
+                             W.fold_weight_norm(W.bicodec_tok_state(tcfg, voc_cfg.vq_input_dim)), dev,
+                             max_seconds=a.prompt_seconds, ref_seconds=6.0)
+        tt = np.arange(int(16000 * a.prompt_seconds)) / 16000.0
+        pwavs, prefs = [], []
+        for i in range(B):
+            f0 = 100 + 15 * i + 30 * np.sin(2 * np.pi * 0.7 * tt + i)
+            ph = 2 * np.pi * np.cumsum(f0) / 16000.0
+            x = (0.3 * (0.5 + 0.5 * np.sin(2 * np.pi * 2.3 * tt) ** 2) * (0.5 * np.sin(ph) + 0.3 * np.sin(2 * ph) + 0.2 * np.sin(3 * ph))
+                 + 0.02 * np.random.Generator(np.random.PCG64(4000 + rank * 100 + i)).standard_normal(len(tt))).astype(np.float32)
+            pwavs.append(x)
+            prefs.append(get_ref_clip(x, 16000, 6.0, 320).astype(np.float32))
 
     # ---- synthetic inputs: prompt ids ~ U[0,V) PCG64(1234+i), global ids PCG64(1235+i)
     prompts, globs = [], []
@@ -173,10 +199,23 @@ def main():
         globs.append(np.random.Generator(np.random.PCG64(1235 + 2 * s)).integers(0, 4096, size=voc_cfg.spk_token_num))
     glob_t = torch.from_numpy(np.stack(globs)).to(dev, torch.int32).unsqueeze(1)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    decode_ms, voc_ms = [], []
+    decode_ms, voc_ms, enc_ms = [], [], []
 
     def step(timed=False):
-        llm.prefill(prompts, None)
+        nonlocal glob_t
+        pr = prompts
+        if enc is not None:
+            # prompt encode: (global, semantic) ids of each prompt wav, appended to the text prompt the way
+            # process_prompt does (cli/SparkTTS.py:83-104); ids are mapped into the synthetic vocabulary
+            t0 = time.perf_counter()
+            toks = [enc.tokenize_arrays(pwavs[i], prefs[i]) for i in range(B)]
+            glob_t = torch.cat([g for g, _ in toks], 0)
+            sem_h = [s_.reshape(-1).cpu().numpy() for _, s_ in toks]
+            g_h = glob_t.reshape(B, -1).cpu().numpy()
+            pr = [prompts[i] + (g_h[i] % llm_cfg.vocab_size).tolist() + (sem_h[i] % llm_cfg.vocab_size).tolist() for i in range(B)]
+            if timed:
+                enc_ms.append((time.perf_counter() - t0) * 1e3)
+        llm.prefill(pr, None)
         if timed:
             ev[0].record()
         llm.decode(N - 1)
@@ -227,14 +266,16 @@ def main():
                  else "bf16 weights, fp32 KV/activations (LLM); fp32 (vocoder)",
         "data": "synthetic (seeded prompts and weights; no checkpoint or dataset offline)",
         "config": {"workload": f"Spark-TTS-0.5B, batch={B} greedy, {P}-token prompt -> {N} tokens -> "
-                               f"{N * voc_cfg.hop / 16000.0:.1f} s audio per utterance (BASELINE.json configs[{1 if B == 1 else 2}])",
+                               f"{N * voc_cfg.hop / 16000.0:.1f} s audio per utterance (BASELINE.json configs[{4 if a.clone else (1 if B == 1 else 2)}])",
+                   **({"voice_clone": f"each utterance encodes a {a.prompt_seconds:.1f} s prompt wav on the GPU first (BASELINE.json configs[4])"} if a.clone else {}),
                    "batch_per_gpu": B, "prompt_len": P, "new_tokens": N, "kv_cache": a.kv,
                    "hipgraph": not a.no_graph, "parallelism": f"utterance-parallel x{world}", "device": arch},
         "rtf": el / audio_s, "x_realtime": audio_s / el,
         "utterances_per_s": world * a.steps * B / el,
         "weights": {"build_s_rank0": t_build, "rccl_broadcast_ms": bcast_ms,
                     "llm_arena_bytes": int(llm_arena.numel()), "voc_arena_bytes": int(voc_arena.numel()) * 4},
-        "stage_ms": {"decode_149_steps": float(np.median(decode_ms)), "vocoder": float(np.median(voc_ms))},
+        "stage_ms": {"decode_149_steps": float(np.median(decode_ms)), "vocoder": float(np.median(voc_ms)),
+                     **({"prompt_encode_all": float(np.median(enc_ms))} if enc_ms else {})},
         "first_tokens": toks[0][:8], "wav_std": float(wav.std()),
     }
 

@@ -5,6 +5,7 @@
 #pragma once
 #include "smi_common.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <functional>
 #include <string>
@@ -486,7 +487,9 @@ Launch make_conv_w(const std::string& name, const float* W, const float* bias,
   }
   const int cot = pad32(Cout) / 32;
   // waves split the input channels when there are few time tiles and many channels
-  const int qb = (Lmax <= 32) ? 1 : 2;
+  // 64-column time tiles unless that leaves most CUs idle (short sequences): then 32-column tiles double the blocks
+  const long long blocks64 = (long long)((Lmax + 63) / 64) * cot * B * S;
+  const int qb = (Lmax <= 32 || (blocks64 < 256 && getenv("SPARKMI_QB2") == nullptr)) ? 1 : 2;
   const int qt = qb * 32, nq = (Lmax + qt - 1) / qt;
   const long long blocks_cosplit = (long long)nq * ((cot + 3) / 4) * B * S;
   L.ks = (blocks_cosplit < 512 || cot % 4 != 0) && Cin >= 8;

@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 from pathlib import Path
-from typing import Dict, List, Mapping, Optional, Sequence, Union
+from typing import Tuple,  Dict, List, Mapping, Optional, Sequence, Union
 
 import numpy as np
 import torch
@@ -195,28 +195,74 @@ class BiCodecVocoder:
 
 
 class BiCodecTokenizer:
-    """Drop-in for the detokenize half of ``sparktts.models.audio_tokenizer.BiCodecTokenizer``.
-    ``tokenize`` (voice-clone prompt encode: wav2vec2 + encoder + speaker encoder) is the next row
-    of SURVEY section 8f and is not built in this round."""
+    """Drop-in for ``sparktts.models.audio_tokenizer.BiCodecTokenizer``: ``tokenize`` (voice-clone prompt
+    encode: wav2vec2 + BiCodec encoder / VQ + speaker encoder, ``sparkmi/encoder.py``) and ``detokenize``
+    (the vocoder).  The prompt encoder (a 1 GB arena at full size) is built on the first ``tokenize``."""
 
     def __init__(self, model_dir: Optional[Path] = None, device: Union[str, torch.device] = None,
                  cfg: Optional[BiCodecConfig] = None, state: Optional[Mapping[str, np.ndarray]] = None,
-                 max_batch: int = 1, max_frames: int = 3000, **kwargs):
+                 max_batch: int = 1, max_frames: int = 3000, max_prompt_seconds: float = 30.0, **kwargs):
         self.device = torch.device(device if device is not None else "cuda:0")
         self.model_dir = model_dir
+        self._state = None
         if cfg is None:
             bdir = Path(model_dir) / "BiCodec"
             cfg = BiCodecConfig.from_yaml(bdir / "config.yaml")
             state = load_bicodec_state(bdir)
+            self._state = state
             self.config = TopConfig.from_yaml(Path(model_dir) / "config.yaml")
         else:
             self.config = TopConfig()
         self.model = BiCodecVocoder(cfg, state, self.device, max_batch=max_batch, max_frames=max_frames)
+        self._enc = None
+        self._max_prompt_seconds = max_prompt_seconds
 
-    def tokenize(self, audio_path: str):
-        raise NotImplementedError(
-            "voice-clone prompt encoding (wav2vec2 + BiCodec encoder + speaker encoder) is not built yet "
-            "(SURVEY section 8f item 1); pass gender/pitch/speed for controllable TTS")
+    # ---------------------------------------------------------------- prompt encode (audio_tokenizer.py:57-130)
+    def _encoder(self):
+        if self._enc is None:
+            from .config_tok import TokCfg, Wav2Vec2Cfg
+            from .encoder import BiCodecEncoder
+            from .weights import fold_pos_conv_weight_norm, fold_weight_norm, load_wav2vec2_state
+            if self.model_dir is None:
+                raise _lib.SparkMIError("tokenize needs a model directory (wav2vec2-large-xlsr-53/ and BiCodec/)")
+            wdir = Path(self.model_dir) / "wav2vec2-large-xlsr-53"
+            if not (wdir / "config.json").exists():
+                raise FileNotFoundError(f"{wdir}/config.json: the wav2vec2 feature extractor of the prompt encoder is missing")
+            wcfg = Wav2Vec2Cfg.from_json(wdir / "config.json")
+            tcfg = TokCfg.from_yaml(Path(self.model_dir) / "BiCodec" / "config.yaml")
+            self._enc = BiCodecEncoder(wcfg, tcfg, fold_pos_conv_weight_norm(load_wav2vec2_state(wdir)),
+                                       fold_weight_norm(self._state), self.device, max_seconds=self._max_prompt_seconds,
+                                       ref_seconds=float(self.config.ref_segment_duration))
+        return self._enc
+
+    def get_ref_clip(self, wav: np.ndarray) -> np.ndarray:
+        """Reference clip for the speaker embedding (audio_tokenizer.py:57-72)."""
+        from .encoder import get_ref_clip
+        return get_ref_clip(wav, self.config.sample_rate, self.config.ref_segment_duration, self.config.latent_hop_length)
+
+    def process_audio(self, wav_path) -> Tuple[np.ndarray, torch.Tensor]:
+        """Load the prompt and cut its reference clip (audio_tokenizer.py:74-83)."""
+        from .encoder import load_audio
+        wav = load_audio(wav_path, sampling_rate=self.config.sample_rate, volume_normalize=self.config.volume_normalize)
+        ref = torch.from_numpy(self.get_ref_clip(wav)).unsqueeze(0).float()
+        return wav, ref
+
+    def extract_wav2vec2_features(self, wavs) -> torch.Tensor:
+        """(1, T, hidden) mean of the tapped wav2vec2 hidden states (audio_tokenizer.py:85-100)."""
+        wav = np.asarray(wavs, dtype=np.float32).reshape(-1)
+        enc = self._encoder()
+        enc.tokenize_arrays(wav, self.get_ref_clip(wav))
+        return enc.debug_stage("feat").t().unsqueeze(0)
+
+    def tokenize(self, audio_path: str) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Prompt audio file -> (global ids (1, 1, Ntok), semantic ids (1, T)) (audio_tokenizer.py:119-130)."""
+        wav, ref = self.process_audio(audio_path)
+        return self._encoder().tokenize_arrays(wav, ref.numpy())
+
+    def tokenize_batch(self, batch) -> Tuple[torch.Tensor, torch.Tensor]:
+        """audio_tokenizer.py:102-117 for a list of equally long prompts: {"wav": [...], "ref_wav": (B, L)}."""
+        g, s = zip(*[self._encoder().tokenize_arrays(np.asarray(w), np.asarray(r)) for w, r in zip(batch["wav"], batch["ref_wav"])])
+        return torch.cat(g, 0), torch.cat(s, 0)
 
     def detokenize(self, global_tokens: torch.Tensor, semantic_tokens: torch.Tensor) -> np.ndarray:
         """(B, Ntok) global ids, (B, T) semantic ids -> waveform: (hop*T,) for B == 1 else (B, hop*T)."""

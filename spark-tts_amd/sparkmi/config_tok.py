@@ -58,13 +58,18 @@ class Wav2Vec2Cfg:
     def from_json(cls, path) -> "Wav2Vec2Cfg":
         raw = json.loads(Path(path).read_text())
         keys = set(cls.__dataclass_fields__) - {"taps"}
-        return cls(**{k: (list(v) if isinstance(v, list) else v) for k, v in raw.items() if k in keys})
+        kw = {k: (list(v) if isinstance(v, list) else v) for k, v in raw.items() if k in keys}
+        if "sparkmi_hidden_state_taps" in raw:      # reduced test models only; the reference hard-codes 11 / 14 / 16
+            kw["taps"] = tuple(raw["sparkmi_hidden_state_taps"])
+        return cls(**kw)
 
     def to_json(self, path) -> None:
         d = {k: getattr(self, k) for k in self.__dataclass_fields__ if k != "taps"}
         d.update(model_type="wav2vec2", architectures=["Wav2Vec2Model"], num_feat_extract_layers=len(self.conv_dim),
                  hidden_dropout=0.0, activation_dropout=0.0, attention_dropout=0.0, feat_proj_dropout=0.0,
                  layerdrop=0.0, vocab_size=32)
+        if tuple(self.taps) != (11, 14, 16):
+            d["sparkmi_hidden_state_taps"] = list(self.taps)
         Path(path).write_text(json.dumps(d, indent=1))
 
     def validate(self) -> None:
@@ -143,7 +148,10 @@ class TokCfg:
                    sample_rate=m["sample_rate"], n_fft=m["n_fft"], win_length=m["win_length"],
                    hop_length=m["hop_length"], mel_fmin=m["mel_fmin"], mel_fmax=m.get("mel_fmax"),
                    num_mels=m["num_mels"], spk_latent_dim=s["latent_dim"], spk_token_num=s["token_num"],
-                   fsq_levels=list(s["fsq_levels"]))
+                   fsq_levels=list(s["fsq_levels"]),
+                   # not in the reference's yaml (ECAPA_TDNN_GLOB_c512 / PerceiverResampler defaults, speaker_encoder.py:55-61);
+                   # read when present so that reduced test models can be described
+                   ecapa_channels=s.get("ecapa_channels", 512), perceiver_heads=s.get("perceiver_heads", 8))
 
     def to_yaml_dict(self) -> dict:
         return {"encoder": {"input_channels": self.enc_input_channels, "vocos_dim": self.enc_vocos_dim,
@@ -152,7 +160,8 @@ class TokCfg:
                             "sample_ratios": list(self.enc_sample_ratios)},
                 "mel_params": {"sample_rate": self.sample_rate, "n_fft": self.n_fft, "win_length": self.win_length,
                                "hop_length": self.hop_length, "mel_fmin": self.mel_fmin, "mel_fmax": self.mel_fmax,
-                               "num_mels": self.num_mels}}
+                               "num_mels": self.num_mels},
+                "speaker_encoder_extra": {"ecapa_channels": self.ecapa_channels, "perceiver_heads": self.perceiver_heads}}
 
     def validate(self) -> None:
         if self.enc_sample_ratios != [1] * len(self.enc_sample_ratios):

@@ -21,7 +21,8 @@ import yaml
 
 from .config import BiCodecConfig, LLMConfig, tiny_bicodec
 from .pipeline_text import TASK_TOKEN_MAP
-from .weights import SyntheticLLM, bicodec_detok_state
+from .config_tok import TokCfg, Wav2Vec2Cfg, tiny_tok, tiny_wav2vec2
+from .weights import SyntheticLLM, bicodec_detok_state, bicodec_tok_state, wav2vec2_state
 
 CONTROL_TOKENS = (
     list(TASK_TOKEN_MAP.values())
@@ -46,7 +47,8 @@ def build_tokenizer(n_global: int, n_semantic: int):
     return fast
 
 
-def make_model_dir(path, llm_cfg: LLMConfig = None, voc_cfg: BiCodecConfig = None, seed: int = 0) -> Tuple[LLMConfig, BiCodecConfig]:
+def make_model_dir(path, llm_cfg: LLMConfig = None, voc_cfg: BiCodecConfig = None, seed: int = 0,
+                   w2v_cfg: Wav2Vec2Cfg = None, tok_cfg: TokCfg = None, with_prompt_encoder: bool = True) -> Tuple[LLMConfig, BiCodecConfig]:
     from safetensors.torch import save_file
     path = Path(path)
     voc_cfg = voc_cfg or tiny_bicodec()
@@ -68,7 +70,25 @@ def make_model_dir(path, llm_cfg: LLMConfig = None, voc_cfg: BiCodecConfig = Non
     syn = SyntheticLLM(llm_cfg, seed=seed)
     save_file({n: torch.from_numpy(syn[n]).to(torch.bfloat16 if syn[n].ndim == 2 else torch.float32)
                for n in syn.names()}, str(path / "LLM" / "model.safetensors"))
-    (path / "BiCodec" / "config.yaml").write_text(yaml.safe_dump(voc_cfg.to_yaml_dict()))
-    save_file({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in bicodec_detok_state(voc_cfg, seed=seed).items()},
-              str(path / "BiCodec" / "model.safetensors"))
+    ycfg = voc_cfg.to_yaml_dict()
+    state = dict(bicodec_detok_state(voc_cfg, seed=seed))
+    if with_prompt_encoder:
+        # the tokenize half (voice cloning): wav2vec2 directory + encoder / speaker-encoder weights in the same BiCodec file
+        w2v_cfg = w2v_cfg or tiny_wav2vec2()
+        tok_cfg = tok_cfg or tiny_tok()
+        extra = tok_cfg.to_yaml_dict()
+        ycfg["audio_tokenizer"]["encoder"] = extra["encoder"]
+        ycfg["audio_tokenizer"]["mel_params"] = extra["mel_params"]
+        ycfg["audio_tokenizer"]["speaker_encoder"].update(extra["speaker_encoder_extra"], input_dim=tok_cfg.num_mels)
+        state.update(bicodec_tok_state(tok_cfg, voc_cfg.vq_input_dim, seed=seed))
+        wdir = path / "wav2vec2-large-xlsr-53"
+        wdir.mkdir(parents=True, exist_ok=True)
+        w2v_cfg.to_json(wdir / "config.json")
+        (wdir / "preprocessor_config.json").write_text(json.dumps({
+            "do_normalize": True, "feature_extractor_type": "Wav2Vec2FeatureExtractor", "feature_size": 1,
+            "padding_side": "right", "padding_value": 0, "return_attention_mask": True, "sampling_rate": 16000}))
+        save_file({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in wav2vec2_state(w2v_cfg, seed=seed).items()},
+                  str(wdir / "model.safetensors"))
+    (path / "BiCodec" / "config.yaml").write_text(yaml.safe_dump(ycfg))
+    save_file({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in state.items()}, str(path / "BiCodec" / "model.safetensors"))
     return llm_cfg, voc_cfg

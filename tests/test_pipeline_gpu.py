@@ -51,8 +51,8 @@ def test_attributes_and_prompt_builders(model_dir):
     g = torch.arange(vcfg.spk_token_num).reshape(1, 1, -1)
     s, gid = tts.process_prompt("abc", None, "pt", prompt_tokens=(g, torch.tensor([[4, 5]])))
     assert s.endswith("<|start_semantic_token|><|bicodec_semantic_4|><|bicodec_semantic_5|>") and gid is not None
-    with pytest.raises(NotImplementedError):
-        tts.process_prompt("abc", "missing.wav")      # prompt audio encode is the next row
+    with pytest.raises((FileNotFoundError, RuntimeError, OSError)):
+        tts.process_prompt("abc", "missing.wav")      # a prompt wav that does not exist
 
 
 @pytest.mark.parametrize("prompt_text", [None, "spoken before"])
@@ -103,3 +103,52 @@ def test_control_mode_needs_the_speaker_tokens(model_dir):
     tts = SparkTTS(d, torch.device("cuda:0"), max_positions=512, max_frames=256)
     with pytest.raises(ValueError, match="global tokens"):
         tts.inference("hello", gender="male", pitch="low", speed="high", do_sample=False, max_new_tokens=16)
+
+
+def _write_wav(path, x, sr=16000):
+    import wave
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr)
+        w.writeframes((np.clip(x, -1, 1) * 32767.0).astype("<i2").tobytes())
+
+
+def test_voice_clone_from_prompt_audio_matches_oracle_pipeline(model_dir, tmp_path):
+    """cli/SparkTTS.py:83-104 with a prompt wav: tokenize (audio_tokenizer.py:119-130) on the HIP prompt
+    encoder, then generate + detokenize; every step against the CPU oracles."""
+    from oracle.tokenize_ref import BiCodecTokRef, audio_volume_normalize, get_ref_clip
+    from oracle.wav2vec2_ref import Wav2Vec2Ref
+    from sparkmi import config_tok as T
+    from sparkmi.pipeline import SparkTTS
+    d, (lcfg, vcfg) = model_dir
+    t = np.arange(int(16000 * 1.7)) / 16000.0
+    x = 0.25 * np.sin(2 * np.pi * (140 + 30 * np.sin(2 * np.pi * 1.3 * t)) * t) * (0.6 + 0.4 * np.sin(2 * np.pi * 3 * t)) \
+        + 0.01 * np.random.default_rng(4).standard_normal(len(t))
+    wavp = tmp_path / "prompt.wav"
+    _write_wav(wavp, x)
+    tts = SparkTTS(d, torch.device("cuda:0"), max_positions=1024, max_frames=256)
+    glob, sem = tts.audio_tokenizer.tokenize(str(wavp))
+    # oracle tokenize on the same file
+    import wave
+    with wave.open(str(wavp), "rb") as w:
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").astype(np.float64) / 32768.0
+    wav = audio_volume_normalize(pcm)
+    ref = get_ref_clip(wav, 16000, 6, vcfg.hop)
+    wcfg = T.Wav2Vec2Cfg.from_json(d / "wav2vec2-large-xlsr-53" / "config.json")
+    tcfg = T.TokCfg.from_yaml(d / "BiCodec" / "config.yaml")
+    feat = Wav2Vec2Ref(wcfg, W.load_wav2vec2_state(d / "wav2vec2-large-xlsr-53")).features(wav.astype(np.float32))
+    ost = {}
+    osem, oglob = BiCodecTokRef(tcfg, W.fold_weight_norm(W.load_bicodec_state(d / "BiCodec"))).tokenize(
+        feat, torch.from_numpy(ref.astype(np.float32))[None], ost)
+    assert glob.shape == (1, 1, vcfg.spk_token_num) and sem.shape == (1, wcfg.frames(len(wav)))
+    safe = ost["vq_margin"].numpy() > 1e-4
+    np.testing.assert_array_equal(sem.cpu().numpy()[safe], osem.numpy()[safe])
+    bd = ost["fsq_bounded"][0].numpy()
+    safe_g = (np.abs(bd - np.floor(bd) - 0.5) > 1e-3).all(axis=1)
+    np.testing.assert_array_equal(glob.cpu().numpy()[0, 0][safe_g], oglob.numpy()[0, 0][safe_g])
+    # end to end: the drop-in's inference() with prompt_speech_path == the oracle pipeline fed the GPU's prompt tokens
+    wavout = tts.inference("A short sentence.", prompt_speech_path=str(wavp), prompt_text="hello", do_sample=False, max_new_tokens=40)
+    want, osem2, _ = _oracle_inference(d, (lcfg, vcfg), "A short sentence.", glob.reshape(-1).tolist(), sem.reshape(-1).tolist(), "hello", 40)
+    assert wavout.shape == want.shape and np.abs(wavout - want).max() < 2e-4
+    feats = tts.audio_tokenizer.extract_wav2vec2_features(wav.astype(np.float32))
+    assert feats.shape == (1, wcfg.frames(len(wav)), wcfg.hidden_size)
+    assert np.abs(feats[0].cpu().numpy() - feat[0].numpy()).max() < 3e-4

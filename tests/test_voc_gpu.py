@@ -90,8 +90,8 @@ def test_facade_and_determinism(tiny):
     assert a.shape == (21 * cfg.hop,) and a.dtype == np.float32
     assert np.array_equal(a, b)
     assert np.abs(a - ref.detokenize_numpy(glob, sem)).max() < WAV_ATOL
-    with pytest.raises(NotImplementedError):
-        tok.tokenize("x.wav")
+    with pytest.raises(FileNotFoundError):
+        tok.tokenize("x.wav")      # no such prompt file (tokenize itself: tests/test_enc_gpu.py, test_pipeline_gpu.py)
 
 
 def test_bad_arguments_are_reported(tiny):
