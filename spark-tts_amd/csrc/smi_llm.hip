@@ -1824,17 +1824,42 @@ int smi_llm_time_kernel(smi_llm* L, int kernel, int layer, int iters, float* ms_
     // duration it has inside the decode graph, which the back-to-back loop below cannot show.
     const int k = kernel - 16, nl = L->cfg.num_layers;
     SMI_REQUIRE(k >= KQKV && k <= KD, "smi_llm_time_kernel: in-sequence timing is for the layer kernels");
+    // both sequences are captured into hipGraphs and replayed, like the decode step itself: eager launches of
+    // 5-us kernels can be bound by the host's launch rate, which would then be what the difference measures
     float t[2] = {0.f, 0.f};
     for (int pass = 0; pass < 2; ++pass) {
-      for (int i = -2; i < iters; ++i) {
-        if (i == 0) SMI_HIP(hipEventRecord(L->ev0, st));
-        const int l = (layer + nl + i) % nl;
-        for (int kk = KQKV; kk <= KD; ++kk)
-          if (!(pass == 1 && kk == k) && (rc = launch_one(L, kk, l, L->rows, L->B, nullptr, st))) return rc;
+      hipStream_t cs;
+      SMI_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+      hipGraph_t g = nullptr;
+      hipGraphExec_t ge = nullptr;
+      rc = SMI_OK;
+      hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+      if (e == hipSuccess) {
+        for (int i = 0; i < iters && rc == SMI_OK; ++i) {
+          const int l = (layer + i) % nl;
+          for (int kk = KQKV; kk <= KD && rc == SMI_OK; ++kk)
+            if (!(pass == 1 && kk == k)) rc = launch_one(L, kk, l, L->rows, L->B, nullptr, cs);
+        }
+        e = hipStreamEndCapture(cs, &g);
       }
-      SMI_HIP(hipEventRecord(L->ev1, st));
-      SMI_HIP(hipEventSynchronize(L->ev1));
-      SMI_HIP(hipEventElapsedTime(&t[pass], L->ev0, L->ev1));
+      if (e == hipSuccess && rc == SMI_OK && g) e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+      if (g) (void)hipGraphDestroy(g);
+      (void)hipStreamDestroy(cs);
+      if (e != hipSuccess || rc != SMI_OK || !ge) {
+        if (ge) (void)hipGraphExecDestroy(ge);
+        (void)hipGetLastError();
+        if (rc != SMI_OK) return rc;
+        smi_set_error("smi_llm_time_kernel: graph capture of the layer sequence failed");
+        return SMI_EHIP;
+      }
+      hipError_t le = hipGraphLaunch(ge, st);                       // warm (also brings the L2 / MALL into steady state)
+      if (le == hipSuccess) le = hipEventRecord(L->ev0, st);
+      if (le == hipSuccess) le = hipGraphLaunch(ge, st);
+      if (le == hipSuccess) le = hipEventRecord(L->ev1, st);
+      if (le == hipSuccess) le = hipEventSynchronize(L->ev1);
+      if (le == hipSuccess) le = hipEventElapsedTime(&t[pass], L->ev0, L->ev1);
+      (void)hipGraphExecDestroy(ge);
+      if (le != hipSuccess) { smi_set_error("smi_llm_time_kernel: graph replay failed: %s", hipGetErrorString(le)); return SMI_EHIP; }
     }
     *ms_avg = (t[0] - t[1]) / iters;
     return SMI_OK;
