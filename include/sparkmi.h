@@ -106,6 +106,17 @@ int smi_llm_all_done(smi_llm* h, int* all_done, void* stream);
 /* Synchronises; copies the generated ids: out_host [B][cap] int64 (row b holds lens_host[b] ids,
  * the eos included when one was emitted). */
 int smi_llm_get_tokens(smi_llm* h, int64_t* out_host, int32_t* lens_host, int cap, void* stream);
+/* Continuous (in-flight) batching: sequences join and leave between decode steps, each in its own KV slot;
+ * the functional analogue of the reference's Triton / TensorRT-LLM in-flight batching
+ * (runtime/triton_trtllm/run.sh:50-65).  smi_llm_session_begin starts an empty session; smi_llm_admit
+ * prefills n new prompts into free slots (returned in slots_out) and emits their first token without
+ * touching the live sequences; smi_llm_decode then steps every live sequence; smi_llm_slot_tokens reads one
+ * sequence's tokens so far and whether it has produced eos; smi_llm_retire frees its slot.  A sequence's
+ * tokens do not depend on what else is live (rows are independent in every kernel). */
+int smi_llm_session_begin(smi_llm* h, int64_t eos_id, void* stream);
+int smi_llm_admit(smi_llm* h, const int64_t* ids_host, const int32_t* lens_host, int n, int P_max, int32_t* slots_out, void* stream);
+int smi_llm_retire(smi_llm* h, int slot, void* stream);
+int smi_llm_slot_tokens(smi_llm* h, int slot, int64_t* out_host, int cap, int32_t* n_out, int32_t* finished, void* stream);
 /* Test/teacher-forcing entry: feeds ids_host[0..S) at positions 0..S-1 of slot 0 (cache reset) and
  * writes every position's logits to logits_dev [S][vocab_size] f32. */
 int smi_llm_forward_logits(smi_llm* h, const int64_t* ids_host, int S, float* logits_dev, void* stream);

@@ -1089,10 +1089,11 @@ __global__ __launch_bounds__(256) void k_finalize(FinP p) {
     tok_s = bi;
     RowDesc rd = p.rows[m];
     const int step = rd.flags;                 // tokens this row has emitted so far
-    if (step < p.max_steps) p.hist[(size_t)step * 32 + m] = bi;
-    if (!p.finished[m]) {
-      p.count[m] = step + 1;
-      if ((int64_t)bi == p.eos) p.finished[m] = 1;
+    const int sl = rd.slot;                    // history / counters live per KV slot (== m outside sessions)
+    if (step < p.max_steps) p.hist[(size_t)step * 32 + sl] = bi;
+    if (!p.finished[sl]) {
+      p.count[sl] = step + 1;
+      if ((int64_t)bi == p.eos) p.finished[sl] = 1;
     }
     rd.token = bi;
     rd.pos += 1;
@@ -1172,6 +1173,9 @@ struct smi_llm {
   int64_t* hist; int32_t *count, *finished, *step;
   void *kcache, *vcache; size_t kv_layer_elems;
   int B; int64_t eos; int started;
+  // continuous batching (smi_llm_session_*): live rows map to arbitrary KV slots
+  int session, identity_slots;
+  int slot_busy[32], slot_len[32];      // host: slot in use; prompt length + tokens emitted (cache positions used)
   int max_len, steps_launched;  // host-side bound on cache positions in use
   // sampling state (smi_llm_set_sampling)
   int do_sample, top_k; float temperature, top_p; unsigned long long seed;
@@ -1281,7 +1285,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       a.rows = rows; a.xs_out = L->xs_attn; a.M = M; a.q_dim = L->Q; a.n_kv = c.num_kv_heads;
       a.group = c.num_heads / c.num_kv_heads; a.max_pos = c.max_positions; a.n_heads = c.num_heads;
       a.work_blocks = c.num_heads * M;
-      a.slot_is_row = rows == L->rows;   // the live decode rows are (slot b, ...) in order
+      a.slot_is_row = rows == L->rows && L->identity_slots;   // the live decode rows are (slot b, ...) in order
       // helpers: second half of this layer's gate_up slices
       a.pf = PfDesc{sec(L, SMI_LLM_WGU, layer), L->KTh * 1024, L->NTgu, (L->NTgu / 8 + 1) / 2, (L->NTgu + 7) / 8};
       const int helpers = (L->prefetch && M <= 8 && a.work_blocks < 232) ? (256 - a.work_blocks) / 8 * 8 : 0;
@@ -1538,6 +1542,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->prefetch = getenv("SPARKMI_NO_PREFETCH") ? 0 : 1;
   { const char* e = getenv("SPARKMI_PGEMM_MIN_ROWS"); L->pgemm_min_rows = e ? atoi(e) : 3072; }
   L->graph = nullptr; L->graph_B = 0; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->eos = -1;
+  L->session = 0; L->identity_slots = 1; memset(L->slot_busy, 0, sizeof(L->slot_busy)); memset(L->slot_len, 0, sizeof(L->slot_len));
   const size_t esz = cfg->kv_dtype ? 4 : 2;
   L->kv_layer_elems = (size_t)cfg->max_slots * cfg->num_kv_heads * cfg->max_positions * kHeadDim;
   const size_t kvbytes = L->kv_layer_elems * esz * cfg->num_layers;
@@ -1616,10 +1621,10 @@ int smi_llm_set_sampling(smi_llm* L, int do_sample, float temperature, int top_k
   return SMI_OK;
 }
 
-int smi_llm_prefill(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, int P_max, int64_t eos_id, void* stream) {
-  SMI_REQUIRE(L && ids && lens, "smi_llm_prefill: null argument");
-  SMI_REQUIRE(B >= 1 && B <= L->cfg.max_slots, "smi_llm_prefill: B=%d outside 1..%d", B, L->cfg.max_slots);
-  hipStream_t st = (hipStream_t)stream;
+// Runs every prompt token but each sequence's last through the layers (K/V appended at slots[b]) and leaves the n
+// "last prompt token" rows at L->plan + *tail_off (device) and in L->host_rows (host) for the first step.
+static int prefill_prompts(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, int P_max, const int32_t* slots,
+                           size_t* tail_off, hipStream_t st) {
   size_t total = 0;
   for (int b = 0; b < B; ++b) {
     SMI_REQUIRE(lens[b] >= 1 && lens[b] <= P_max, "smi_llm_prefill: lens[%d]=%d outside 1..%d", b, lens[b], P_max);
@@ -1638,18 +1643,10 @@ int smi_llm_prefill(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, 
   L->host_rows.assign(nchunks * kMaxRows + kMaxRows, RowDesc{0, 0, 0, 0});
   size_t r = 0;
   for (int b = 0; b < B; ++b)
-    for (int t = 0; t + 1 < lens[b]; ++t) L->host_rows[r++] = RowDesc{b, t, (int32_t)ids[(size_t)b * P_max + t], 0};
+    for (int t = 0; t + 1 < lens[b]; ++t) L->host_rows[r++] = RowDesc{slots[b], t, (int32_t)ids[(size_t)b * P_max + t], 0};
   for (int b = 0; b < B; ++b)
-    L->host_rows[nchunks * kMaxRows + b] = RowDesc{b, lens[b] - 1, (int32_t)ids[(size_t)b * P_max + lens[b] - 1], 0};   // flags = tokens emitted
+    L->host_rows[nchunks * kMaxRows + b] = RowDesc{slots[b], lens[b] - 1, (int32_t)ids[(size_t)b * P_max + lens[b] - 1], 0};   // flags = tokens emitted
   SMI_HIP(hipMemcpyAsync(L->plan, L->host_rows.data(), L->host_rows.size() * sizeof(RowDesc), hipMemcpyHostToDevice, st));
-  SMI_HIP(hipMemsetAsync(L->count, 0, 128, st));
-  SMI_HIP(hipMemsetAsync(L->finished, 0, 128, st));
-  SMI_HIP(hipMemsetAsync(L->step, 0, 4, st));
-  L->B = B; L->eos = eos_id; L->started = 1;
-  L->max_len = 0;
-  for (int b = 0; b < B; ++b) L->max_len = lens[b] > L->max_len ? lens[b] : L->max_len;
-  L->steps_launched = 1;
-  if (L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }  // eos / B are baked into the graph
   // measured (tools/prefill_time.py, profiles/README.md): 32-row chunks ~1.4 ms each; row-grouped decode GEMMs
   // ~1.5 ms + 9 us/row; the prefill GEMM ~15 ms + 5 us/row (crossover near 3000 rows)
   if (total > (size_t)kMaxRows && !getenv("SPARKMI_PREFILL_CHUNKS")) {
@@ -1672,18 +1669,154 @@ int smi_llm_prefill(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, 
       if ((rc = launch_layers(L, rows, M, true, st))) return rc;
     }
   }
-  SMI_HIP(hipMemcpyAsync(L->rows, L->plan + nchunks * kMaxRows, kMaxRows * sizeof(RowDesc), hipMemcpyDeviceToDevice, st));
+  *tail_off = nchunks * kMaxRows;
+  return SMI_OK;
+}
+
+int smi_llm_prefill(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, int P_max, int64_t eos_id, void* stream) {
+  SMI_REQUIRE(L && ids && lens, "smi_llm_prefill: null argument");
+  SMI_REQUIRE(B >= 1 && B <= L->cfg.max_slots, "smi_llm_prefill: B=%d outside 1..%d", B, L->cfg.max_slots);
+  hipStream_t st = (hipStream_t)stream;
+  int32_t slots[kMaxRows];
+  for (int b = 0; b < kMaxRows; ++b) slots[b] = b;
+  SMI_HIP(hipMemsetAsync(L->count, 0, 128, st));
+  SMI_HIP(hipMemsetAsync(L->finished, 0, 128, st));
+  SMI_HIP(hipMemsetAsync(L->step, 0, 4, st));
+  L->B = B; L->eos = eos_id; L->started = 1; L->session = 0; L->identity_slots = 1;
+  L->max_len = 0;
+  for (int b = 0; b < B; ++b) L->max_len = lens[b] > L->max_len ? lens[b] : L->max_len;
+  L->steps_launched = 1;
+  if (L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }  // eos / B are baked into the graph
+  size_t tail = 0;
+  int rc;
+  if ((rc = prefill_prompts(L, ids, lens, B, P_max, slots, &tail, st))) { L->started = 0; return rc; }
+  SMI_HIP(hipMemcpyAsync(L->rows, L->plan + tail, kMaxRows * sizeof(RowDesc), hipMemcpyDeviceToDevice, st));
   if ((rc = launch_embed(L, L->rows, B, st))) return rc;
   return launch_step(L, B, st);
+}
+
+// ---- continuous batching: sequences join (admit) and leave (retire) between decode steps ----
+int smi_llm_session_begin(smi_llm* L, int64_t eos_id, void* stream) {
+  SMI_REQUIRE(L, "smi_llm_session_begin: null handle");
+  hipStream_t st = (hipStream_t)stream;
+  SMI_HIP(hipMemsetAsync(L->count, 0, 128, st));
+  SMI_HIP(hipMemsetAsync(L->finished, 0, 128, st));
+  SMI_HIP(hipMemsetAsync(L->step, 0, 4, st));
+  L->B = 0; L->eos = eos_id; L->started = 1; L->session = 1; L->identity_slots = 1;
+  L->max_len = 0; L->steps_launched = 0;
+  memset(L->slot_busy, 0, sizeof(L->slot_busy));
+  memset(L->slot_len, 0, sizeof(L->slot_len));
+  if (L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }
+  return SMI_OK;
+}
+
+// the live row set changed: refresh the device rows, the per-row residual / operand state, and drop the graph
+static int session_set_rows(smi_llm* L, const std::vector<RowDesc>& live, hipStream_t st) {
+  L->B = (int)live.size();
+  L->identity_slots = 1;
+  for (int b = 0; b < L->B; ++b) L->identity_slots &= live[b].slot == b;
+  if (L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }
+  if (L->B == 0) return SMI_OK;
+  L->host_rows.assign(kMaxRows, RowDesc{0, 0, 0, 0});
+  for (int b = 0; b < L->B; ++b) L->host_rows[b] = live[b];
+  SMI_HIP(hipMemcpyAsync(L->rows, L->host_rows.data(), kMaxRows * sizeof(RowDesc), hipMemcpyHostToDevice, st));
+  SMI_HIP(hipStreamSynchronize(st));    // host_rows is reused by the next call
+  return launch_embed(L, L->rows, L->B, st);   // h = E[token], first-norm operand, sum of squares of every live row
+}
+
+static int session_live_rows(smi_llm* L, std::vector<RowDesc>& live, hipStream_t st) {
+  live.assign((size_t)L->B, RowDesc{0, 0, 0, 0});
+  SMI_HIP(hipStreamSynchronize(st));
+  if (L->B) SMI_HIP(hipMemcpy(live.data(), L->rows, (size_t)L->B * sizeof(RowDesc), hipMemcpyDeviceToHost));
+  return SMI_OK;
+}
+
+int smi_llm_admit(smi_llm* L, const int64_t* ids, const int32_t* lens, int n, int P_max, int32_t* slots_out, void* stream) {
+  SMI_REQUIRE(L && ids && lens && slots_out, "smi_llm_admit: null argument");
+  if (!L->started || !L->session) { smi_set_error("smi_llm_admit outside a session (smi_llm_session_begin first)"); return SMI_ESTATE; }
+  SMI_REQUIRE(n >= 1 && L->B + n <= L->cfg.max_slots && L->B + n <= kMaxRows, "smi_llm_admit: %d new + %d live sequences exceed %d slots", n,
+              L->B, L->cfg.max_slots < kMaxRows ? L->cfg.max_slots : kMaxRows);
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  std::vector<RowDesc> live;
+  if ((rc = session_live_rows(L, live, st))) return rc;
+  int32_t slots[kMaxRows];
+  int k = 0;
+  for (int sl = 0; sl < L->cfg.max_slots && k < n; ++sl)
+    if (!L->slot_busy[sl]) slots[k++] = sl;
+  SMI_REQUIRE(k == n, "smi_llm_admit: no free KV slot");
+  size_t tail = 0;
+  if ((rc = prefill_prompts(L, ids, lens, n, P_max, slots, &tail, st))) return rc;
+  // first token of the new sequences: one step over the new rows alone
+  int32_t zeros[kMaxRows] = {0};
+  for (int b = 0; b < n; ++b) {
+    SMI_HIP(hipMemcpyAsync(L->count + slots[b], zeros, 4, hipMemcpyHostToDevice, st));
+    SMI_HIP(hipMemcpyAsync(L->finished + slots[b], zeros, 4, hipMemcpyHostToDevice, st));
+  }
+  SMI_HIP(hipMemcpyAsync(L->rows, L->plan + tail, kMaxRows * sizeof(RowDesc), hipMemcpyDeviceToDevice, st));
+  if (L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }
+  const int oldB = L->B;
+  L->B = n;
+  L->identity_slots = 1;
+  for (int b = 0; b < n; ++b) L->identity_slots &= slots[b] == b;
+  if ((rc = launch_embed(L, L->rows, n, st)) || (rc = launch_step(L, n, st))) { L->B = oldB; return rc; }
+  std::vector<RowDesc> fresh;
+  if ((rc = session_live_rows(L, fresh, st))) return rc;
+  for (int b = 0; b < n; ++b) {
+    live.push_back(fresh[b]);
+    L->slot_busy[slots[b]] = 1;
+    L->slot_len[slots[b]] = lens[b] + 1;
+    slots_out[b] = slots[b];
+  }
+  return session_set_rows(L, live, st);
+}
+
+int smi_llm_retire(smi_llm* L, int slot, void* stream) {
+  SMI_REQUIRE(L && slot >= 0 && slot < kMaxRows, "smi_llm_retire: bad argument");
+  if (!L->started || !L->session) { smi_set_error("smi_llm_retire outside a session"); return SMI_ESTATE; }
+  SMI_REQUIRE(L->slot_busy[slot], "smi_llm_retire: slot %d is not live", slot);
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  std::vector<RowDesc> live;
+  if ((rc = session_live_rows(L, live, st))) return rc;
+  for (size_t i = 0; i < live.size(); ++i)
+    if (live[i].slot == slot) { live.erase(live.begin() + (long)i); break; }
+  L->slot_busy[slot] = 0;
+  L->slot_len[slot] = 0;
+  return session_set_rows(L, live, st);
+}
+
+// Tokens a live (or just finished) slot has emitted since it was admitted; *finished: it has produced eos.
+int smi_llm_slot_tokens(smi_llm* L, int slot, int64_t* out, int cap, int32_t* n_out, int32_t* finished, void* stream) {
+  SMI_REQUIRE(L && out && n_out && finished && slot >= 0 && slot < kMaxRows && cap >= 0, "smi_llm_slot_tokens: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  int32_t cnt = 0, fin = 0;
+  SMI_HIP(hipMemcpyAsync(&cnt, L->count + slot, 4, hipMemcpyDeviceToHost, st));
+  SMI_HIP(hipMemcpyAsync(&fin, L->finished + slot, 4, hipMemcpyDeviceToHost, st));
+  SMI_HIP(hipStreamSynchronize(st));
+  int n = cnt < cap ? cnt : cap;
+  if (n > L->max_steps) n = L->max_steps;
+  if (n > 0) SMI_HIP(hipMemcpy2D(out, 8, L->hist + slot, 32 * 8, 8, (size_t)n, hipMemcpyDeviceToHost));
+  *n_out = n;
+  *finished = fin;
+  return SMI_OK;
 }
 
 int smi_llm_decode(smi_llm* L, int n_steps, void* stream) {
   SMI_REQUIRE(L, "smi_llm_decode: null handle");
   if (!L->started) { smi_set_error("smi_llm_decode before smi_llm_prefill"); return SMI_ESTATE; }
   SMI_REQUIRE(n_steps >= 0, "smi_llm_decode: n_steps < 0");
-  SMI_REQUIRE(L->max_len + L->steps_launched + n_steps <= L->cfg.max_positions,
-              "smi_llm_decode: %d more steps would pass max_positions=%d (prompt %d, %d steps so far)", n_steps,
-              L->cfg.max_positions, L->max_len, L->steps_launched);
+  if (L->session) {
+    if (L->B == 0 || n_steps == 0) return SMI_OK;
+    for (int sl = 0; sl < kMaxRows; ++sl)
+      if (L->slot_busy[sl])
+        SMI_REQUIRE(L->slot_len[sl] + n_steps <= L->cfg.max_positions, "smi_llm_decode: %d more steps would take slot %d past max_positions=%d",
+                    n_steps, sl, L->cfg.max_positions);
+  } else {
+    SMI_REQUIRE(L->max_len + L->steps_launched + n_steps <= L->cfg.max_positions,
+                "smi_llm_decode: %d more steps would pass max_positions=%d (prompt %d, %d steps so far)", n_steps,
+                L->cfg.max_positions, L->max_len, L->steps_launched);
+  }
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (L->cfg.use_graph && n_steps > 0 && (!L->graph || L->graph_B != L->B)) {
@@ -1713,6 +1846,9 @@ int smi_llm_decode(smi_llm* L, int n_steps, void* stream) {
     }
   }
   L->steps_launched += n_steps;
+  if (L->session)
+    for (int sl = 0; sl < kMaxRows; ++sl)
+      if (L->slot_busy[sl]) L->slot_len[sl] += n_steps;
   return SMI_OK;
 }
 

@@ -142,6 +142,63 @@ class SparkLLM:
             out[b, ids.shape[1]: ids.shape[1] + len(t)] = t
         return torch.from_numpy(out).to(input_ids.device)
 
+    # ------------------------------------------------------------------ continuous batching
+    def session_begin(self, eos_token_id: Optional[int] = None) -> None:
+        """Empty in-flight-batching session: sequences are admitted and retired between decode steps."""
+        _lib.check(self._lib.smi_llm_session_begin(self._h, -1 if eos_token_id is None else int(eos_token_id), self._stream()),
+                   "smi_llm_session_begin")
+
+    def admit(self, prompts: Sequence[Sequence[int]]) -> List[int]:
+        """Prefill new prompts into free KV slots (first token emitted); returns their slot ids."""
+        n = len(prompts)
+        lens = np.array([len(p) for p in prompts], dtype=np.int32)
+        pmax = int(lens.max())
+        ids = np.zeros((n, pmax), dtype=np.int64)
+        for b, p in enumerate(prompts):
+            ids[b, : len(p)] = np.asarray(p, dtype=np.int64)
+        slots = np.zeros(n, dtype=np.int32)
+        _lib.check(self._lib.smi_llm_admit(self._h, ids.ctypes.data_as(C.POINTER(C.c_int64)), lens.ctypes.data_as(C.POINTER(C.c_int32)),
+                                           n, pmax, slots.ctypes.data_as(C.POINTER(C.c_int32)), self._stream()), "smi_llm_admit")
+        return slots.tolist()
+
+    def retire(self, slot: int) -> None:
+        _lib.check(self._lib.smi_llm_retire(self._h, int(slot), self._stream()), "smi_llm_retire")
+
+    def slot_tokens(self, slot: int, cap: int):
+        """(tokens emitted so far by the sequence in ``slot``, finished flag)."""
+        out = np.zeros(max(cap, 1), dtype=np.int64)
+        n, fin = C.c_int32(0), C.c_int32(0)
+        _lib.check(self._lib.smi_llm_slot_tokens(self._h, int(slot), out.ctypes.data_as(C.POINTER(C.c_int64)), cap, C.byref(n),
+                                                 C.byref(fin), self._stream()), "smi_llm_slot_tokens")
+        return out[: n.value].tolist(), bool(fin.value)
+
+    def serve(self, requests, max_live: Optional[int] = None, decode_stride: int = 8):
+        """In-flight batching driver: ``requests`` yields (key, prompt ids, max_new_tokens, eos id or None -- one eos for
+        the session: the first request's); yields (key, new ids) as each sequence finishes.  New requests are admitted
+        whenever a slot is free, so short utterances never wait for long ones."""
+        it = iter(requests)
+        max_live = min(max_live or self.max_slots, self.max_slots)
+        live = {}                      # slot -> (key, max_new)
+        pending = next(it, None)
+        started = False
+        while pending is not None or live:
+            while pending is not None and len(live) < max_live:
+                key, prompt, max_new, eos = pending
+                if not started:
+                    self.session_begin(eos)
+                    started = True
+                (slot,) = self.admit([list(prompt)])
+                live[slot] = (key, int(max_new))
+                pending = next(it, None)
+            self.decode(decode_stride)
+            for slot in list(live):
+                key, max_new = live[slot]
+                toks, fin = self.slot_tokens(slot, max_new)
+                if fin or len(toks) >= max_new:
+                    self.retire(slot)
+                    del live[slot]
+                    yield key, toks
+
     # ------------------------------------------------------------------ test / bench entries
     def forward_logits(self, ids: Sequence[int]) -> torch.Tensor:
         """Teacher-forced logits (S, V) for one sequence fed at positions 0..S-1."""

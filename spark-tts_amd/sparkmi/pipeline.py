@@ -235,3 +235,38 @@ class SparkTTS:
             produced += n
         if glob is None:
             raise ValueError(f"{ntok} global tokens were not generated; the speaker encoder needs them")
+
+    @torch.no_grad()
+    def serve(self, requests, temperature: float = 0.8, top_k: float = 50, top_p: float = 0.95, *, do_sample: bool = True,
+              max_new_tokens: int = 3000, seed: Optional[int] = None, decode_stride: int = 8):
+        """In-flight batching front end (the functional analogue of the reference's Triton deployment,
+        runtime/triton_trtllm/run.sh:50-65): ``requests`` is an iterable of the dicts ``inference_batch`` takes;
+        yields ``(index, waveform)`` as each utterance finishes.  Up to ``max_batch`` utterances are live; a new
+        request is admitted into the LLM's free KV slot as soon as one retires, so short utterances do not wait for
+        long ones.  Greedy results equal ``inference()`` of the same request."""
+        voc = self.audio_tokenizer.model
+        ntok, hop = voc.cfg.spk_token_num, voc.hop
+        globals_: Dict[int, Optional[torch.Tensor]] = {}
+        self.model.set_sampling(do_sample, temperature, int(top_k), float(top_p), seed)
+
+        def llm_requests():
+            for i, r in enumerate(requests):
+                if r.get("gender") is not None:
+                    prompt, g = self.process_prompt_control(r["gender"], r.get("pitch"), r.get("speed"), r["text"]), None
+                else:
+                    prompt, g = self.process_prompt(r["text"], r.get("prompt_speech_path"), r.get("prompt_text"), r.get("prompt_tokens"))
+                globals_[i] = g
+                ids = self.tokenizer([prompt], return_tensors="pt").input_ids[0].tolist()
+                yield i, ids, min(max_new_tokens, self._max_positions - len(ids) - decode_stride), self._eos
+
+        for i, toks in self.model.serve(llm_requests(), max_live=self._max_batch, decode_stride=decode_stride):
+            if self._eos is not None and self._eos in toks:
+                toks = toks[: toks.index(self._eos) + 1]
+            sem, glob = self._parse(toks)
+            g = torch.tensor(glob, dtype=torch.long) if globals_[i] is None else torch.as_tensor(globals_[i]).reshape(-1).long()
+            if g.numel() != ntok:
+                raise ValueError(f"request {i}: {g.numel()} global tokens, the speaker encoder needs {ntok}")
+            if not sem:
+                raise ValueError(f"request {i}: the model generated no semantic tokens")
+            wav = voc.detokenize(torch.tensor([sem], dtype=torch.long), g.reshape(1, 1, -1), lengths=[len(sem)])
+            yield i, wav.reshape(-1)[: len(sem) * hop].cpu().numpy().copy()

@@ -222,3 +222,46 @@ def test_prefill_paths_agree(tiny, monkeypatch):
     assert grouped == chunked and pgemm == chunked
     for b in (0, 5, 11):
         assert Qwen2Ref(cfg, syn, kv_dtype="bf16").generate_greedy(prompts[b], 16) == grouped[b]
+
+
+def test_continuous_batching_equals_standalone_runs(tiny):
+    """Sequences admitted and retired between decode steps (in-flight batching) produce exactly the tokens of
+    their own B = 1 runs, whatever else is live and whichever KV slot they land in."""
+    cfg, syn = tiny
+    rng = np.random.Generator(np.random.PCG64(77))
+    reqs = []
+    for i in range(9):
+        prompt = rng.integers(0, cfg.vocab_size, size=int(rng.integers(2, 50))).tolist()
+        reqs.append((i, prompt, int(rng.integers(3, 40))))
+    single = _llm(cfg, syn, max_slots=1, max_positions=128)
+    want = {i: single.generate_ids([p], n)[0] for i, p, n in reqs}
+    longest = max(want, key=lambda i: len(want[i]))
+    eos = want[longest][len(want[longest]) // 2]   # a token one of the sequences emits: it must stop there
+    want = {i: single.generate_ids([p], n, eos_token_id=eos)[0] for i, p, n in reqs}
+    llm = _llm(cfg, syn, max_slots=4, max_positions=128)
+    for stride in (1, 5):
+        got = dict(llm.serve(((i, p, n, eos) for i, p, n in reqs), max_live=3, decode_stride=stride))
+        assert set(got) == set(want)
+        for i, p, n in reqs:
+            w = want[i]
+            g = got[i][: len(w)]           # the driver checks for eos every `stride` steps: extra tokens after it are ignored
+            assert g == w, f"request {i} (stride {stride})"
+            assert len(got[i]) <= n
+    # the low-level calls: slots are reused, a retired slot's history does not leak into the next sequence
+    llm.session_begin(None)
+    a, = llm.admit([reqs[0][1]])
+    b, = llm.admit([reqs[1][1]])
+    llm.decode(6)
+    ta, _ = llm.slot_tokens(a, 64)
+    assert ta == single.generate_ids([reqs[0][1]], 7)[0]
+    llm.retire(a)
+    c, = llm.admit([reqs[2][1]])
+    assert c == a                          # the freed slot
+    llm.decode(4)
+    assert llm.slot_tokens(c, 64)[0] == single.generate_ids([reqs[2][1]], 5)[0]
+    assert llm.slot_tokens(b, 64)[0] == single.generate_ids([reqs[1][1]], 11)[0]
+    from sparkmi._lib import SparkMIError
+    with pytest.raises(SparkMIError):
+        llm.retire(3)                      # not live
+    with pytest.raises(SparkMIError):
+        llm.admit([[1, 2]] * 4)            # 2 live + 4 new > 4 slots

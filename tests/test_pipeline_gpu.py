@@ -152,3 +152,33 @@ def test_voice_clone_from_prompt_audio_matches_oracle_pipeline(model_dir, tmp_pa
     feats = tts.audio_tokenizer.extract_wav2vec2_features(wav.astype(np.float32))
     assert feats.shape == (1, wcfg.frames(len(wav)), wcfg.hidden_size)
     assert np.abs(feats[0].cpu().numpy() - feat[0].numpy()).max() < 3e-4
+
+
+def test_serve_in_flight_batching_equals_inference(model_dir):
+    from sparkmi.pipeline import SparkTTS
+    d, (lcfg, vcfg) = model_dir
+    rng = np.random.Generator(np.random.PCG64(21))
+    tts = SparkTTS(d, torch.device("cuda:0"), max_batch=3, max_positions=512, max_frames=256)
+    reqs = []
+    for i in range(6):
+        ptoks = (torch.tensor(rng.integers(0, 4096, size=(1, 1, vcfg.spk_token_num))),
+                 torch.tensor(rng.integers(0, vcfg.codebook_size, size=(1, int(rng.integers(3, 20))))))
+        reqs.append(dict(text="utterance number %d " % i * (1 + i % 3), prompt_tokens=ptoks, prompt_text=None))
+    want = []
+    for r in reqs:
+        try:
+            want.append(tts.inference(**r, do_sample=False, max_new_tokens=60))
+        except ValueError:                      # random weights: this request produced no semantic token
+            want.append(None)
+    got = {}
+    try:
+        for i, wav in tts.serve((r for r in reqs), do_sample=False, max_new_tokens=60, decode_stride=4):
+            got[i] = wav
+    except ValueError:
+        pass
+    checked = 0
+    for i, w in enumerate(want):
+        if w is not None and i in got:
+            assert got[i].shape == w.shape and np.array_equal(got[i], w), f"request {i}"
+            checked += 1
+    assert checked >= 3
