@@ -113,8 +113,8 @@ __device__ __forceinline__ size_t xs_off(int kt, int s, int k8, int m, int M) {
 // H > 1 (RESID only): the 16 rows of a weight tile are split over H blocks (8 or 4 rows each: only those
 // lanes load, the others feed zeros to the MFMA), so a matrix with few n tiles (N = 896: 56) still
 // spreads its HBM stream over 112 / 224 CUs.  Every output element keeps its own summation order.
-template <int MT, int NTB, int NW, int U, int WB, int PRO, int EPI, int KVF32, int H = 1>
-__global__ __launch_bounds__(NW * 64) void k_gemm(GemmP p) {
+template <int MT, int NTB, int NW, int U, int WB, int PRO, int EPI, int KVF32, int H = 1, int OCC = 1>
+__global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
   static_assert(H == 1 || ((H == 2 || H == 4) && NTB == 1 && EPI == EPI_RESID), "row-split tiles: RESID, one tile per block");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1193,7 +1193,7 @@ struct smi_llm {
 
 namespace {
 
-template <int MT, int NTB, int NW, int U, int WB, int PRO, int EPI, int H = 1>
+template <int MT, int NTB, int NW, int U, int WB, int PRO, int EPI, int H = 1, int OCC = 1>
 int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
   const int work = (p.NT + NTB - 1) / NTB * H;
   p.work_blocks = work;
@@ -1216,24 +1216,24 @@ int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
   if (lds > 64 * 1024) {   // more than the default dynamic LDS window: opt in once per instantiation
     static bool done = false;
     if (!done) {
-      SMI_HIP(hipFuncSetAttribute((const void*)k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 1, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      SMI_HIP(hipFuncSetAttribute((const void*)k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 0, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      SMI_HIP(hipFuncSetAttribute((const void*)k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 1, H, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      SMI_HIP(hipFuncSetAttribute((const void*)k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 0, H, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       done = true;
     }
   }
   const int groups = MT == 2 ? (p.M + 31) / 32 : 1;   // more than 32 rows (prefill): one block row per 32 rows
   SMI_REQUIRE(groups == 1 || EPI != EPI_LM, "lm_head takes at most 32 rows per launch");
   if (L->cfg.kv_dtype)
-    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 1, H>), dim3(work + helpers, groups), dim3(NW * 64), lds, st, p);
+    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 1, H, OCC>), dim3(work + helpers, groups), dim3(NW * 64), lds, st, p);
   else
-    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 0, H>), dim3(work + helpers, groups), dim3(NW * 64), lds, st, p);
+    hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 0, H, OCC>), dim3(work + helpers, groups), dim3(NW * 64), lds, st, p);
   SMI_LAUNCH_CHECK();
   return SMI_OK;
 }
 
 // NW (the k-tile -> wave map) is fixed per kernel type for every M; only the batch depth U shrinks
 // for two m-tiles (register budget), which does not change any summation order.
-template <int NTB, int NW, int U, int WB, int PRO, int EPI, int H = 1, int N2 = 1>
+template <int NTB, int NW, int U, int WB, int PRO, int EPI, int H = 1, int N2 = 1, int OCC = 1>
 int launch_gemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
   // two m-tiles: the operand triples (12 * M pieces per k tile) outweigh the weight tile 6:1, so where there are
   // n tiles to spare (gate_up: 608) a block takes N2 of them per operand fetch.  Any NTB gives the same bits:
@@ -1243,7 +1243,7 @@ int launch_gemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
     if (N2 > 1) return launch_gemm_kv<2, NTB * N2, NW, 1, 1, PRO, EPI>(L, p, st);
     return launch_gemm_kv<2, NTB, NW, (NW >= 16 || NTB >= 4 ? 2 : (U > 4 ? 4 : U)), 1, PRO, EPI>(L, p, st);
   }
-  return launch_gemm_kv<1, NTB, NW, U, WB, PRO, EPI, H>(L, p, st);
+  return launch_gemm_kv<1, NTB, NW, U, WB, PRO, EPI, H, OCC>(L, p, st);
 }
 
 const unsigned char* sec(const smi_llm* L, int s, int layer) {
@@ -1314,7 +1314,10 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       switch (L->tune[2]) {
         case 2: return launch_gemm<1, 16, 2, 1, PRO_NORM, EPI_SWIGLU>(L, p, st);
         case 5: return launch_gemm<2, 4, 8, 1, PRO_NORM, EPI_SWIGLU>(L, p, st);
-        default: return launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_SWIGLU, 1, 2>(L, p, st);
+        case 6: return launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_SWIGLU, 1, 2, 6>(L, p, st);   // spills at 80 VGPRs: 2.4x slower
+        case 7: return launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_SWIGLU, 1, 2>(L, p, st);      // 114 VGPRs: 2 blocks per CU, 96 of 608 wait
+        default:   // 69 VGPRs (>= 6 waves per SIMD): all 608 blocks are resident at once, no second round (step 745 -> 705 us)
+          return launch_gemm<1, 8, 2, 2, PRO_NORM, EPI_SWIGLU, 1, 2, 6>(L, p, st);
       }
     case KD:   // h += Wd act; emits the next layer's input-norm operand (or the final norm's)
       p.W = (const uint4*)sec(L, SMI_LLM_WD, layer); p.NT = L->NTh; p.KT = L->KTi;
