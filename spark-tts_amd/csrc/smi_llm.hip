@@ -1184,6 +1184,7 @@ struct smi_llm {
   int max_steps;
   int tune[4];   // SPARKMI_TUNE block-shape selectors (diagnostics)
   int prefetch;  // same-XCD L2 prefetch by helper blocks (SPARKMI_NO_PREFETCH=1 turns it off)
+  int tune2;     // SPARKMI_TUNE2 bit mask (diagnostics)
   int pgemm_min_rows;   // prompt rows from which the prefill GEMM replaces row-grouped decode GEMMs (SPARKMI_PGEMM_MIN_ROWS)
   hipGraphExec_t graph; int graph_B;
   hipEvent_t ev0, ev1;
@@ -1221,7 +1222,7 @@ int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
       done = true;
     }
   }
-  const int groups = MT == 2 ? (p.M + 31) / 32 : 1;   // more than 32 rows (prefill): one block row per 32 rows
+  const int groups = (p.M + MT * 16 - 1) / (MT * 16);   // one block row per MT*16 rows (more than one: prefill, or 17..32 rows as 2 x 16)
   SMI_REQUIRE(groups == 1 || EPI != EPI_LM, "lm_head takes at most 32 rows per launch");
   if (L->cfg.kv_dtype)
     hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 1, H, OCC>), dim3(work + helpers, groups), dim3(NW * 64), lds, st, p);
@@ -1240,7 +1241,10 @@ int launch_gemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
   // a tile's k -> wave map does not change.  (Measured at M = 32: gate_up 19.4 -> 13.7 us with N2 = 2, 14.4 with 4;
   // QKV / o_proj / down / lm_head lose with fewer blocks.)
   if (p.M > 16) {
-    if (N2 > 1) return launch_gemm_kv<2, NTB * N2, NW, 1, 1, PRO, EPI>(L, p, st);
+    if constexpr (N2 > 1) return launch_gemm_kv<2, NTB * N2, NW, 1, 1, PRO, EPI>(L, p, st);
+    // few n tiles (N = 896 / 1152): 16-row blocks in two block rows put twice the CUs to work and halve the operand
+    // bytes per CU (measured at M = 32; SPARKMI_TUNE2 bit 0 keeps 32-row blocks)
+    if constexpr (N2 == 0) { if (!(L->tune2 & 1)) return launch_gemm_kv<1, NTB, NW, U, 1, PRO, EPI>(L, p, st); }
     return launch_gemm_kv<2, NTB, NW, (NW >= 16 || NTB >= 4 ? 2 : (U > 4 ? 4 : U)), 1, PRO, EPI>(L, p, st);
   }
   return launch_gemm_kv<1, NTB, NW, U, WB, PRO, EPI, H, OCC>(L, p, st);
@@ -1276,7 +1280,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       switch (L->tune[0]) {   // SPARKMI_TUNE=q,o,g,d: block-shape sweeps (diagnostics; NW changes the summation order)
         case 1: return launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_QKV>(L, p, st);
         case 3: return launch_gemm<1, 4, 8, 1, PRO_NORM, EPI_QKV>(L, p, st);
-        default: return launch_gemm<1, 16, 2, 1, PRO_NORM, EPI_QKV>(L, p, st);   // measured best (profiles/README.md)
+        default: return launch_gemm<1, 16, 2, 1, PRO_NORM, EPI_QKV, 1, 0>(L, p, st);   // measured best (profiles/README.md)
       }
     case KATTN: {
       AttnP a;
@@ -1306,7 +1310,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
         case 4: return launch_gemm<1, 8, 4, 1, PRO_PLAIN, EPI_RESID, 2>(L, p, st);
         case 5: return launch_gemm<1, 8, 4, 1, PRO_PLAIN, EPI_RESID>(L, p, st);
         case 6: return launch_gemm<1, 8, 4, 1, PRO_PLAIN, EPI_RESID, 4>(L, p, st);
-        default: return launch_gemm<1, 8, 4, 1, PRO_PLAIN, EPI_RESID>(L, p, st);   // row parts do not pay here (1.6 MB)
+        default: return launch_gemm<1, 8, 4, 1, PRO_PLAIN, EPI_RESID, 1, 0>(L, p, st);   // row parts do not pay here (1.6 MB)
       }
     case KGU:
       p.W = (const uint4*)sec(L, SMI_LLM_WGU, layer); p.NT = L->NTgu; p.KT = L->KTh;
@@ -1333,7 +1337,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
         case 5: return launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID, 2>(L, p, st);
         case 6: return launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID>(L, p, st);
         default:   // few rows: 4-row parts (224 blocks, -0.7 us); same bits either way, the zero-fed MFMAs cost at M > 8
-          return M <= 8 ? launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID, 4>(L, p, st) : launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID>(L, p, st);
+          return M <= 8 ? launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID, 4>(L, p, st) : launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID, 1, 0>(L, p, st);
       }
     case KLM:
       p.W = (const uint4*)sec(L, SMI_LLM_LM_HEAD, 0); p.NT = L->NTlm; p.KT = L->KTh;
@@ -1543,6 +1547,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   { L->tune[0] = L->tune[1] = L->tune[2] = L->tune[3] = 0; const char* e = getenv("SPARKMI_TUNE"); if (e) sscanf(e, "%d,%d,%d,%d", &L->tune[0], &L->tune[1], &L->tune[2], &L->tune[3]); }
   L->bh = L->bq = nullptr; L->bxs_h = L->bxs_attn = L->bxs_act = nullptr; L->bss = nullptr; L->big_rows = 0;
   L->prefetch = getenv("SPARKMI_NO_PREFETCH") ? 0 : 1;
+  { const char* e = getenv("SPARKMI_TUNE2"); L->tune2 = e ? atoi(e) : 0; }
   { const char* e = getenv("SPARKMI_PGEMM_MIN_ROWS"); L->pgemm_min_rows = e ? atoi(e) : 3072; }
   L->graph = nullptr; L->graph_B = 0; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->eos = -1;
   L->session = 0; L->identity_slots = 1; memset(L->slot_busy, 0, sizeof(L->slot_busy)); memset(L->slot_len, 0, sizeof(L->slot_len));
