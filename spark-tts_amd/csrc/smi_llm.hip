@@ -920,6 +920,8 @@ struct SampleP {
   unsigned long long seed;
   const int32_t* step;
   int* tok;             // [32] sampled token per row
+  const float* pval;    // [M][nblk] the lm_head blocks' best logits (a bound for the top-k threshold) or null
+  int nblk;
 };
 
 __device__ __forceinline__ uint32_t sortable(float f) {
@@ -942,59 +944,115 @@ __device__ inline uint32_t philox_u32(unsigned long long seed, uint32_t c0, uint
 }
 
 constexpr int kSampleCap = 256;  // top_k upper bound
+constexpr int kCandCap = 1024;   // candidates at or above the threshold taken from the lm_head blocks' maxima
 
-__global__ __launch_bounds__(1024) void k_sample(SampleP p) {
-  __shared__ unsigned int hist[256];
-  __shared__ unsigned int s_prefix, s_need, s_cnt;
-  __shared__ float cv[kSampleCap], sv[kSampleCap];
-  __shared__ int ci[kSampleCap], si[kSampleCap];
-  const int m = blockIdx.x, tid = threadIdx.x;
-  const float* lg = p.logits + (size_t)m * p.V;
-  // radix select: key of the k-th largest logit
-  if (tid == 0) { s_prefix = 0; s_need = (unsigned)p.top_k; }
+// Exact key of the k-th largest logit by 4 passes of 8-bit radix selection (fallback path: one block walks
+// the whole row 4 times, with LDS-atomic histograms).
+__device__ uint32_t radix_kth_key(const float* lg, int V, int top_k, unsigned int* hist, unsigned int* s_prefix, unsigned int* s_need) {
+  const int tid = threadIdx.x;
+  if (tid == 0) { *s_prefix = 0; *s_need = (unsigned)top_k; }
   __syncthreads();
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 24 - 8 * pass;
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
-    const uint32_t prefix = s_prefix;
+    const uint32_t prefix = *s_prefix;
     const uint32_t mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-    for (int i = tid; i < p.V; i += 1024) {
+    for (int i = tid; i < V; i += 1024) {
       const uint32_t k = sortable(lg[i]);
       if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
     }
     __syncthreads();
     if (tid == 0) {
-      unsigned need = s_need;
+      unsigned need = *s_need;
       int b = 255;
       for (; b > 0; --b) {
         if (hist[b] >= need) break;
         need -= hist[b];
       }
-      s_need = need;                       // rank inside bin b
-      s_prefix = prefix | ((uint32_t)b << shift);
+      *s_need = need;                       // rank inside bin b
+      *s_prefix = prefix | ((uint32_t)b << shift);
     }
     __syncthreads();
   }
-  const uint32_t thr = s_prefix;           // exact key of the k-th largest
-  if (tid == 0) s_cnt = 0;
+  return *s_prefix;
+}
+
+// One block per row.  The top_k-th largest of the lm_head blocks' maxima is a lower bound of the top_k-th
+// largest logit (those maxima are top_k distinct logits at or above it), so ONE pass over the row collects a
+// short candidate list that contains the whole top-k; the candidates are rank-sorted exactly (value descending,
+// index ascending on ties), then temperature -> top-k -> top-p -> multinomial on one thread.
+__global__ __launch_bounds__(1024) void k_sample(SampleP p) {
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned int s_prefix, s_need, s_cnt;
+  __shared__ float s_thr;
+  __shared__ float cv[kCandCap], sv[kSampleCap];
+  __shared__ int ci[kCandCap], si[kSampleCap];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const float* lg = p.logits + (size_t)m * p.V;
+  if (tid == 0) { s_cnt = 0; s_thr = -INFINITY; }
   __syncthreads();
-  for (int i = tid; i < p.V; i += 1024) {
-    const float v = lg[i];
-    if (sortable(v) >= thr) {
-      const unsigned pos = atomicAdd(&s_cnt, 1u);
-      if (pos < kSampleCap) { cv[pos] = v; ci[pos] = i; }
+  if (p.pval && p.nblk <= kCandCap && p.nblk >= p.top_k) {
+    const float mine = tid < p.nblk ? p.pval[(size_t)m * p.nblk + tid] : -INFINITY;
+    cv[tid] = mine;
+    __syncthreads();
+    if (tid < p.nblk) {
+      int r = 0;
+      for (int j = 0; j < p.nblk; ++j) r += (cv[j] > mine) || (cv[j] == mine && j < tid);
+      if (r == p.top_k - 1) s_thr = mine;
     }
+    __syncthreads();
   }
-  __syncthreads();
-  const int n = s_cnt < (unsigned)kSampleCap ? (int)s_cnt : kSampleCap;
-  // rank sort: descending value, ascending index on ties
+  const float thr0 = s_thr;
+  __syncthreads();   // cv is reused for the candidates
+  if (thr0 > -INFINITY) {
+    const bool vec = (p.V & 3) == 0;
+    if (vec) {
+      const float4* l4 = (const float4*)lg;
+      for (int i = tid; i < p.V / 4; i += 1024) {
+        const float4 v = l4[i];
+        const float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (a[e] >= thr0) {
+            const unsigned pos = atomicAdd(&s_cnt, 1u);
+            if (pos < kCandCap) { cv[pos] = a[e]; ci[pos] = 4 * i + e; }
+          }
+      }
+    } else {
+      for (int i = tid; i < p.V; i += 1024) {
+        const float v = lg[i];
+        if (v >= thr0) {
+          const unsigned pos = atomicAdd(&s_cnt, 1u);
+          if (pos < kCandCap) { cv[pos] = v; ci[pos] = i; }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (thr0 == -INFINITY || s_cnt > (unsigned)kCandCap) {
+    // no usable bound (or a pathological row with > 1024 logits above it): exact radix selection of the k-th key
+    __syncthreads();
+    const uint32_t thr = radix_kth_key(lg, p.V, p.top_k, hist, &s_prefix, &s_need);
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    for (int i = tid; i < p.V; i += 1024) {
+      const float v = lg[i];
+      if (sortable(v) >= thr) {
+        const unsigned pos = atomicAdd(&s_cnt, 1u);
+        if (pos < kCandCap) { cv[pos] = v; ci[pos] = i; }
+      }
+    }
+    __syncthreads();
+  }
+  const int n = s_cnt < (unsigned)kCandCap ? (int)s_cnt : kCandCap;
+  // rank sort: descending value, ascending index on ties; only the first top_k ranks are kept
   if (tid < n) {
     const float v = cv[tid];
     const int ix = ci[tid];
     int r = 0;
     for (int j = 0; j < n; ++j) r += (cv[j] > v) || (cv[j] == v && ci[j] < ix);
-    sv[r] = v; si[r] = ix;
+    if (r < kSampleCap) { sv[r] = v; si[r] = ix; }
   }
   __syncthreads();
   if (tid == 0) {
@@ -1362,6 +1420,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
         SampleP sp;
         sp.logits = L->logits; sp.V = c.vocab_size; sp.top_k = L->top_k; sp.inv_temp = 1.0f / L->temperature;
         sp.top_p = L->top_p; sp.seed = L->seed; sp.step = L->step; sp.tok = L->tok;
+        sp.pval = L->pval; sp.nblk = L->KTh <= 32 ? L->lm_blocks : L->lm_cap;
         hipLaunchKernelGGL(k_sample, dim3(M), dim3(1024), 0, st, sp);
         SMI_LAUNCH_CHECK();
         f.tok = L->tok;

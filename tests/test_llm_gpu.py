@@ -265,3 +265,26 @@ def test_continuous_batching_equals_standalone_runs(tiny):
         llm.retire(3)                      # not live
     with pytest.raises(SparkMIError):
         llm.admit([[1, 2]] * 4)            # 2 live + 4 new > 4 slots
+
+
+def test_full_size_sampling_fast_path_matches_the_warper_chain():
+    """0.5B vocabulary (166 000 logits, 512 lm_head blocks): the sampler's one-pass candidate collection (threshold from
+    the blocks' maxima) must give the same distribution as transformers' temperature -> top-k -> top-p chain."""
+    cfg = C.spark_0p5b_llm()
+    syn = W.SyntheticLLM(cfg)
+    prompt = np.random.Generator(np.random.PCG64(5)).integers(0, cfg.vocab_size, size=24).tolist()
+    llm = _llm(cfg, syn, max_slots=32, max_positions=64)
+    logits = llm.forward_logits(prompt)[-1].cpu()
+    T_, K, P = 0.8, 50, 0.95
+    want = _expected_sampling_probs(logits, T_, K, P).numpy()
+    counts = np.zeros(cfg.vocab_size)
+    n = 0
+    for seed in range(40):
+        for t in llm.generate_ids([prompt] * 32, 1, do_sample=True, temperature=T_, top_k=K, top_p=P, seed=seed):
+            counts[t[0]] += 1
+            n += 1
+    assert (counts[want == 0] == 0).all(), "sampled a token outside the top-k / nucleus set"
+    tv = 0.5 * np.abs(counts / n - want).sum()
+    assert tv < 0.1, f"total variation distance {tv}"
+    greedy = llm.generate_ids([prompt], 12)[0]
+    assert llm.generate_ids([prompt], 12, do_sample=True, top_k=1, seed=3)[0] == greedy
