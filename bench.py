@@ -321,6 +321,15 @@ def main():
                                "traffic": pmc.get(dom["kernel"]) if std else None,
                                "bytes_per_launch": dom["bytes"], "avg_us": dom["avg_us"]}
             res["kernels"] = ks
+            # the reference's default mode (temperature 0.8 / top-k 50 / top-p 0.95): decode step with the sampler in the graph
+            llm.set_sampling(True, 0.8, 50, 0.95, 1234)
+            llm.prefill(prompts, None)
+            llm.decode(8)
+            res["sampling_step_us"] = llm.time_kernel("step", iters=64) * 1e3
+            llm.set_sampling(False)
+            llm.prefill(prompts, None)
+            llm.decode(8)
+            res["greedy_step_us"] = llm.time_kernel("step", iters=64) * 1e3
             if B == 1:
                 # streaming mode: wall time to the first 1.0 s chunk on the host, and to all chunks
                 from sparkmi.streaming import ChunkScheduler
