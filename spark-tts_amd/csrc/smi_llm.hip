@@ -806,12 +806,9 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
     // wave max: inside a 16-lane row on the DPP path, across the four rows by readlane
     lmax = fmaxf(lmax, smi_dpp<0x128>(lmax));   // row_ror:8
     const float wm = fmaxf(fmaxf(smi_readlane(lmax, 0), smi_readlane(lmax, 16)), fmaxf(smi_readlane(lmax, 32), smi_readlane(lmax, 48)));
-    if (lane == 0) wmax[wave] = wm;
-    __syncthreads();
-    float bm = wmax[0];
-#pragma unroll
-    for (int w = 1; w < kAttnWaves; ++w) bm = fmaxf(bm, wmax[w]);
-    const float mn = fmaxf(m_run, bm);
+    // running max per WAVE (wave-uniform, no LDS, no barrier in the chunk loop); the waves' streams are brought to a
+    // common scale once, in the final merge
+    const float mn = fmaxf(m_run, wm);
     const float a = exp2f((m_run - mn) * LOG2E);
     lrun *= a;
 #pragma unroll
@@ -833,10 +830,10 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
       }
     }
     m_run = mn;
-    if (c0 + NGRP * UNR < ctx) __syncthreads();   // wmax is rewritten by the next chunk
     c0 += NGRP * UNR;
   } while (c0 < ctx);
-  // every stream is at scale exp(-m_run): plain sums in fixed order.  Step 1, inside the wave.
+  // every stream of a wave is at that wave's scale exp(-m_run): plain sums in fixed order inside the wave (step 1);
+  // across the waves (step 2) each wave's sums are rescaled to the block maximum.
 #pragma unroll
   for (int i = 0; i < DPL; i += 4)
     *(float4*)&so[wave][tl][dl * DPL + i] = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
@@ -847,13 +844,19 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
 #pragma unroll
     for (int g = 0; g < TPW; ++g) { O += so[wave][g][lane]; Ls += sl[wave][g]; }
     pw[wave][lane] = O;
-    if (lane == 0) pl[wave] = Ls;
+    if (lane == 0) { pl[wave] = Ls; wmax[wave] = m_run; }
   }
   __syncthreads();
   if (tid < kHeadDim) {   // step 2, across the waves
+    float bm = wmax[0];
+#pragma unroll
+    for (int w = 1; w < kAttnWaves; ++w) bm = fmaxf(bm, wmax[w]);
     float O = 0.f, Ls = 0.f;
 #pragma unroll
-    for (int w = 0; w < kAttnWaves; ++w) { O += pw[w][tid]; Ls += pl[w]; }
+    for (int w = 0; w < kAttnWaves; ++w) {
+      const float sc = exp2f((wmax[w] - bm) * LOG2E);   // 0 for a wave that saw no valid token (m_run = NEG)
+      O += pw[w][tid] * sc; Ls += pl[w] * sc;
+    }
     uint32_t hi, mi, lo;
     split3(O / Ls, hi, mi, lo);
     const int k = head * kHeadDim + tid;
