@@ -313,8 +313,10 @@ def main():
                            "us_per_step": ms * 1e3 * count[name]})
             dom = max(ks, key=lambda k: k["us_per_step"])
             # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes on this build and shape
-            # (profiles/r01_pmc_hbm_traffic.txt; FETCH_SIZE doubled per the gfx950 rule); null for other shapes
-            pmc = {"gate_up": 17.63e6, "down": 9.13e6, "qkv": 2.23e6, "o_proj": 1.78e6, "lm_head": 297.66e6, "attn": 0.83e6}
+            # (profiles/r01_pmc_hbm_traffic_v13.txt; FETCH_SIZE doubled per the gfx950 rule); null for other shapes
+            # (profiles/r01_pmc_hbm_traffic_v13.txt: a producer's helper-block prefetch is part of ITS launch's traffic; gate_up's own
+            # in-graph traffic cannot be observed -- counter collection runs every kernel alone with the L2 invalidated)
+            pmc = {"gate_up": None, "down": 11.17e6, "qkv": 10.95e6, "o_proj": 1.77e6, "lm_head": 297.63e6, "attn": 9.61e6}
             std = B == 1 and P == 128 and a.kv == "bf16"
             res["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS,
