@@ -288,3 +288,21 @@ def test_full_size_sampling_fast_path_matches_the_warper_chain():
     assert tv < 0.1, f"total variation distance {tv}"
     greedy = llm.generate_ids([prompt], 12)[0]
     assert llm.generate_ids([prompt], 12, do_sample=True, top_k=1, seed=3)[0] == greedy
+
+
+def test_cache_boundaries_and_long_contexts(tiny):
+    """Generation right up to max_positions, and contexts that cross the attention kernel's 256-token chunks
+    (1, 2 and 3 chunks; the last chunk partially filled), against the oracle."""
+    cfg, syn = tiny
+    rng = np.random.Generator(np.random.PCG64(123))
+    ref = Qwen2Ref(cfg, syn, kv_dtype="bf16")
+    p10 = rng.integers(0, cfg.vocab_size, size=10).tolist()
+    llm = _llm(cfg, syn, max_positions=64)
+    assert llm.generate_ids([p10], 54)[0] == ref.generate_greedy(p10, 54)      # 10 + 54 == max_positions
+    with pytest.raises(ValueError):
+        llm.generate_ids([p10], 55)
+    long_prompt = rng.integers(0, cfg.vocab_size, size=250).tolist()
+    llm = _llm(cfg, syn, max_slots=2, max_positions=640)
+    got = llm.generate_ids([long_prompt, long_prompt[:77]], 300)               # ctx 250 -> 550 and 77 -> 377
+    assert got[0] == ref.generate_greedy(long_prompt, 300)
+    assert got[1] == ref.generate_greedy(long_prompt[:77], 300)
