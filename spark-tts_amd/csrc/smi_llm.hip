@@ -716,11 +716,16 @@ struct AttnP {
   int M;
   int q_dim, n_kv, group, max_pos, n_heads;
   int slot_is_row;     // every row m lives in KV slot m (decode): addresses need no descriptor
-  int work_blocks;     // = n_heads * M; later blocks are prefetch helpers
+  int work_blocks;     // = n_heads * M * nseg; later blocks are prefetch helpers
   PfDesc pf;
+  // long contexts: the keys are cut into fixed segments of kAttnSeg tokens, one block per (head, row, segment); each
+  // block leaves (max, sum, out[64]) in `part` and k_attn_merge combines a row's segments in order.  nseg == 1: no split.
+  int nseg;
+  float* part;         // [M][n_heads][nseg][66]
 };
 
 constexpr int kAttnWaves = 8;
+constexpr int kAttnSeg = 1024;   // tokens per segment (a multiple of the chunk of either KV type)
 
 // 8 waves; a group of LPT lanes owns one token per pass (16-byte K and V pieces per lane, dot product
 // reduced on the DPP path), UNR passes of loads in flight together (256 tokens per chunk with bf16
@@ -746,7 +751,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
     pf_run(p.pf, (int)blockIdx.x - p.work_blocks, (int)gridDim.x - p.work_blocks, tid, kAttnWaves * 64);
     return;
   }
-  const int head = blockIdx.x % p.n_heads, m = blockIdx.x / p.n_heads;
+  const int head = (blockIdx.x / p.nseg) % p.n_heads, m = blockIdx.x / (p.nseg * p.n_heads), seg = blockIdx.x % p.nseg;
   const int tl = lane / LPT, dl = lane % LPT;
   const int grp = wave * TPW + tl;
   const RowDesc rd = p.rows[m];
@@ -755,7 +760,9 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
   // chunk's loads leave together with it (positions beyond ctx are valid cache memory, masked later)
   const int slot = p.slot_is_row ? m : rd.slot;
   const size_t rowbase = ((size_t)slot * p.n_kv + kvh) * p.max_pos;
-  const int ctx = rd.pos + 1;
+  const int ctx_all = rd.pos + 1;
+  const int ctx = ctx_all < (seg + 1) * kAttnSeg ? ctx_all : (seg + 1) * kAttnSeg;   // this block: keys [seg * kAttnSeg, ctx)
+  if (seg * kAttnSeg >= ctx_all) return;   // block-uniform: this row has no such segment
 
   float qv[DPL];
   {
@@ -767,7 +774,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
 #pragma unroll
   for (int i = 0; i < DPL; ++i) o[i] = 0.f;
 
-  int c0 = 0;
+  int c0 = seg * kAttnSeg;
   do {   // block-uniform trip count; the first chunk never waits for ctx before its loads
     uint4 kr[UNR], vr[UNR];
 #pragma unroll
@@ -857,10 +864,43 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
       const float sc = exp2f((wmax[w] - bm) * LOG2E);   // 0 for a wave that saw no valid token (m_run = NEG)
       O += pw[w][tid] * sc; Ls += pl[w] * sc;
     }
+    if (p.nseg > 1) {   // segment partial at scale exp(-bm); k_attn_merge finishes the row
+      float* pp = p.part + (((size_t)m * p.n_heads + head) * p.nseg + seg) * 66;
+      pp[2 + tid] = O;
+      if (tid == 0) { pp[0] = bm; pp[1] = Ls; }
+      return;
+    }
     uint32_t hi, mi, lo;
     split3(O / Ls, hi, mi, lo);
     const int k = head * kHeadDim + tid;
     const size_t ob = xs_off(k >> 5, 0, (k >> 3) & 3, m, p.M) + (k & 7) * 2;
+    const size_t pl2 = (size_t)4 * p.M * 16;
+    *(uint16_t*)(p.xs_out + ob) = (uint16_t)hi;
+    *(uint16_t*)(p.xs_out + ob + pl2) = (uint16_t)mi;
+    *(uint16_t*)(p.xs_out + ob + 2 * pl2) = (uint16_t)lo;
+  }
+}
+
+// Combines a row's context segments in order (a row with one segment reproduces the unsplit result bit for bit:
+// its scale factor is exp2(0) = 1).  One block per row, one thread per (head, dim).
+__global__ __launch_bounds__(1024) void k_attn_merge(AttnP p) {
+  constexpr float LOG2E = 1.4426950408889634f;
+  const int m = blockIdx.x;
+  const int ns = (p.rows[m].pos + 1 + kAttnSeg - 1) / kAttnSeg;
+  for (int i = threadIdx.x; i < p.n_heads * kHeadDim; i += blockDim.x) {
+    const int head = i / kHeadDim, d = i - head * kHeadDim;
+    const float* pp = p.part + ((size_t)m * p.n_heads + head) * p.nseg * 66;
+    float bm = pp[0];
+    for (int s2 = 1; s2 < ns; ++s2) bm = fmaxf(bm, pp[s2 * 66]);
+    float O = 0.f, Ls = 0.f;
+    for (int s2 = 0; s2 < ns; ++s2) {
+      const float sc = exp2f((pp[s2 * 66] - bm) * LOG2E);
+      O += pp[s2 * 66 + 2 + d] * sc;
+      Ls += pp[s2 * 66 + 1] * sc;
+    }
+    uint32_t hi, mi, lo;
+    split3(O / Ls, hi, mi, lo);
+    const size_t ob = xs_off(i >> 5, 0, (i >> 3) & 3, m, p.M) + (i & 7) * 2;
     const size_t pl2 = (size_t)4 * p.M * 16;
     *(uint16_t*)(p.xs_out + ob) = (uint16_t)hi;
     *(uint16_t*)(p.xs_out + ob + pl2) = (uint16_t)mi;
@@ -1236,6 +1276,8 @@ struct smi_llm {
   int B; int64_t eos; int started;
   // continuous batching (smi_llm_session_*): live rows map to arbitrary KV slots
   int session, identity_slots;
+  int attn_seg;                        // context segments per (head, row) of the attention launches being issued (1 = unsplit)
+  float* apart; size_t apart_floats;   // segment partials [rows][heads][attn_seg][66]
   int slot_busy[32], slot_len[32];      // host: slot in use; prompt length + tokens emitted (cache positions used)
   int max_len, steps_launched;  // host-side bound on cache positions in use
   // sampling state (smi_llm_set_sampling)
@@ -1247,7 +1289,7 @@ struct smi_llm {
   int prefetch;  // same-XCD L2 prefetch by helper blocks (SPARKMI_NO_PREFETCH=1 turns it off)
   int tune2;     // SPARKMI_TUNE2 bit mask (diagnostics)
   int pgemm_min_rows;   // prompt rows from which the prefill GEMM replaces row-grouped decode GEMMs (SPARKMI_PGEMM_MIN_ROWS)
-  hipGraphExec_t graph; int graph_B;
+  hipGraphExec_t graph; int graph_B, graph_seg;
   hipEvent_t ev0, ev1;
   // host staging
   std::vector<RowDesc> host_rows;
@@ -1323,6 +1365,37 @@ void* kv_layer(const smi_llm* L, void* base, int layer) {
 
 enum { KQKV = 0, KATTN, KO, KGU, KD, KLM, KFIN };
 
+int ensure_apart(smi_llm* L, size_t floats) {
+  if (floats <= L->apart_floats) return SMI_OK;
+  if (L->apart) (void)hipFree(L->apart);
+  L->apart = nullptr; L->apart_floats = 0;
+  if (hipMalloc((void**)&L->apart, floats * 4) != hipSuccess) { smi_set_error("hipMalloc(attention partials, %zu floats) failed", floats); return SMI_ENOMEM; }
+  L->apart_floats = floats;
+  return SMI_OK;
+}
+
+int segs_for(int ctx_bound) { return ctx_bound <= kAttnSeg ? 1 : (ctx_bound + kAttnSeg - 1) / kAttnSeg; }
+
+// attention (+ the segment merge when the context bound of the current call exceeds one segment)
+template <int KVF32>
+int launch_attn(smi_llm* L, AttnP a, int helpers_ok, hipStream_t st) {
+  a.nseg = L->attn_seg < 1 ? 1 : L->attn_seg;
+  a.work_blocks = a.n_heads * a.M * a.nseg;
+  if (a.nseg > 1) {
+    int rc = ensure_apart(L, (size_t)a.M * a.n_heads * a.nseg * 66);
+    if (rc) return rc;
+    a.part = L->apart;
+  }
+  const int helpers = (helpers_ok && L->prefetch && a.M <= 8 && a.work_blocks < 232) ? (256 - a.work_blocks) / 8 * 8 : 0;
+  hipLaunchKernelGGL(k_attn<KVF32>, dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
+  SMI_LAUNCH_CHECK();
+  if (a.nseg > 1) {
+    hipLaunchKernelGGL(k_attn_merge, dim3(a.M), dim3(1024), 0, st, a);
+    SMI_LAUNCH_CHECK();
+  }
+  return SMI_OK;
+}
+
 int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, float* logits, hipStream_t st) {
   const smi_llm_cfg& c = L->cfg;
   GemmP p;
@@ -1349,15 +1422,10 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       a.q = L->qbuf; a.kcache = kv_layer(L, L->kcache, layer); a.vcache = kv_layer(L, L->vcache, layer);
       a.rows = rows; a.xs_out = L->xs_attn; a.M = M; a.q_dim = L->Q; a.n_kv = c.num_kv_heads;
       a.group = c.num_heads / c.num_kv_heads; a.max_pos = c.max_positions; a.n_heads = c.num_heads;
-      a.work_blocks = c.num_heads * M;
       a.slot_is_row = rows == L->rows && L->identity_slots;   // the live decode rows are (slot b, ...) in order
       // helpers: second half of this layer's gate_up slices
       a.pf = PfDesc{sec(L, SMI_LLM_WGU, layer), L->KTh * 1024, L->NTgu, (L->NTgu / 8 + 1) / 2, (L->NTgu + 7) / 8};
-      const int helpers = (L->prefetch && M <= 8 && a.work_blocks < 232) ? (256 - a.work_blocks) / 8 * 8 : 0;
-      if (c.kv_dtype) hipLaunchKernelGGL(k_attn<1>, dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
-      else hipLaunchKernelGGL(k_attn<0>, dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
-      SMI_LAUNCH_CHECK();
-      return SMI_OK;
+      return c.kv_dtype ? launch_attn<1>(L, a, 1, st) : launch_attn<0>(L, a, 1, st);
     }
     case KO:   // h += Wo attn; emits the post-attention norm's operand
       p.W = (const uint4*)sec(L, SMI_LLM_WO, layer); p.NT = L->NTh; p.KT = L->KTq;
@@ -1478,10 +1546,8 @@ int launch_layers_big(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
     memset(&a, 0, sizeof(a));
     a.q = L->bq; a.kcache = p.kcache; a.vcache = p.vcache; a.rows = rows; a.xs_out = L->bxs_attn; a.M = M;
     a.q_dim = L->Q; a.n_kv = c.num_kv_heads; a.group = c.num_heads / c.num_kv_heads; a.max_pos = c.max_positions;
-    a.n_heads = c.num_heads; a.work_blocks = c.num_heads * M; a.slot_is_row = 0;
-    if (c.kv_dtype) hipLaunchKernelGGL(k_attn<1>, dim3(a.work_blocks), dim3(kAttnWaves * 64), 0, st, a);
-    else hipLaunchKernelGGL(k_attn<0>, dim3(a.work_blocks), dim3(kAttnWaves * 64), 0, st, a);
-    SMI_LAUNCH_CHECK();
+    a.n_heads = c.num_heads; a.slot_is_row = 0;
+    if ((rc = c.kv_dtype ? launch_attn<1>(L, a, 0, st) : launch_attn<0>(L, a, 0, st))) return rc;
     // o_proj
     GemmP o;
     memset(&o, 0, sizeof(o));
@@ -1611,8 +1677,8 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->prefetch = getenv("SPARKMI_NO_PREFETCH") ? 0 : 1;
   { const char* e = getenv("SPARKMI_TUNE2"); L->tune2 = e ? atoi(e) : 0; }
   { const char* e = getenv("SPARKMI_PGEMM_MIN_ROWS"); L->pgemm_min_rows = e ? atoi(e) : 3072; }
-  L->graph = nullptr; L->graph_B = 0; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->eos = -1;
-  L->session = 0; L->identity_slots = 1; memset(L->slot_busy, 0, sizeof(L->slot_busy)); memset(L->slot_len, 0, sizeof(L->slot_len));
+  L->graph = nullptr; L->graph_B = 0; L->graph_seg = 1; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->eos = -1;
+  L->session = 0; L->identity_slots = 1; L->attn_seg = 1; L->apart = nullptr; L->apart_floats = 0; memset(L->slot_busy, 0, sizeof(L->slot_busy)); memset(L->slot_len, 0, sizeof(L->slot_len));
   const size_t esz = cfg->kv_dtype ? 4 : 2;
   L->kv_layer_elems = (size_t)cfg->max_slots * cfg->num_kv_heads * cfg->max_positions * kHeadDim;
   const size_t kvbytes = L->kv_layer_elems * esz * cfg->num_layers;
@@ -1668,7 +1734,7 @@ int smi_llm_destroy(smi_llm* L) {
   if (!L) return SMI_OK;
   if (L->graph) (void)hipGraphExecDestroy(L->graph);
   void* ptrs[] = {L->h, L->qbuf, L->xs_h, L->xs_attn, L->xs_act, L->sspart, L->rows, L->plan, L->pval, L->pidx, L->hist,
-                  L->count, L->finished, L->step, L->kcache, L->vcache, L->logits, L->tok, L->stamps, L->bh, L->bq, L->bxs_h, L->bxs_attn, L->bxs_act, L->bss};
+                  L->count, L->finished, L->step, L->kcache, L->vcache, L->logits, L->tok, L->stamps, L->bh, L->bq, L->bxs_h, L->bxs_attn, L->bxs_act, L->bss, L->apart};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (L->ev0) (void)hipEventDestroy(L->ev0);
@@ -1704,6 +1770,11 @@ static int prefill_prompts(smi_llm* L, const int64_t* ids, const int32_t* lens, 
       SMI_REQUIRE(id >= 0 && id < L->cfg.vocab_size, "smi_llm_prefill: token id %lld out of range", (long long)id);
     }
     total += lens[b] - 1;
+  }
+  {
+    int longest = 0;
+    for (int b = 0; b < B; ++b) longest = lens[b] > longest ? lens[b] : longest;
+    L->attn_seg = segs_for(longest);
   }
   // plan: every prompt token except each sequence's last, packed 32 rows per chunk; then the
   // B "last prompt token" rows, which run as the first regular step (lm_head + argmax).
@@ -1889,7 +1960,17 @@ int smi_llm_decode(smi_llm* L, int n_steps, void* stream) {
   }
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (L->cfg.use_graph && n_steps > 0 && (!L->graph || L->graph_B != L->B)) {
+  {   // context bound of this call -> attention segments (the partial buffer must exist before a capture starts)
+    int bound = L->max_len + L->steps_launched + n_steps;
+    if (L->session) {
+      bound = 0;
+      for (int sl = 0; sl < kMaxRows; ++sl)
+        if (L->slot_busy[sl] && L->slot_len[sl] + n_steps > bound) bound = L->slot_len[sl] + n_steps;
+    }
+    L->attn_seg = segs_for(bound);
+    if (L->attn_seg > 1 && (rc = ensure_apart(L, (size_t)kMaxRows * L->cfg.num_heads * L->attn_seg * 66))) return rc;
+  }
+  if (L->cfg.use_graph && n_steps > 0 && (!L->graph || L->graph_B != L->B || L->graph_seg != L->attn_seg)) {
     if (L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }
     hipStream_t cs;
     SMI_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
@@ -1905,7 +1986,7 @@ int smi_llm_decode(smi_llm* L, int n_steps, void* stream) {
     }
     (void)hipStreamDestroy(cs);
     (void)hipGetLastError();
-    L->graph_B = L->B;
+    L->graph_B = L->B; L->graph_seg = L->attn_seg;
     if (!L->graph) { smi_set_error("hipGraph capture of the decode step failed"); return SMI_EHIP; }
   }
   for (int s = 0; s < n_steps; ++s) {
@@ -1965,6 +2046,7 @@ int smi_llm_forward_logits(smi_llm* L, const int64_t* ids, int S, float* logits_
   hipStream_t st = (hipStream_t)stream;
   const size_t nchunks = ((size_t)S + kMaxRows - 1) / kMaxRows;
   int rc;
+  L->attn_seg = segs_for(S);
   if ((rc = ensure_plan(L, nchunks * kMaxRows))) return rc;
   L->host_rows.assign(nchunks * kMaxRows, RowDesc{0, 0, 0, 0});
   for (int t = 0; t < S; ++t) {

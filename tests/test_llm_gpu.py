@@ -306,3 +306,11 @@ def test_cache_boundaries_and_long_contexts(tiny):
     got = llm.generate_ids([long_prompt, long_prompt[:77]], 300)               # ctx 250 -> 550 and 77 -> 377
     assert got[0] == ref.generate_greedy(long_prompt, 300)
     assert got[1] == ref.generate_greedy(long_prompt[:77], 300)
+    # beyond 1024 keys the context is cut into segments over several blocks (k_attn_merge): a sequence that crosses the
+    # boundary while a short one runs beside it, and the same long sequence alone
+    vlong = rng.integers(0, cfg.vocab_size, size=1005).tolist()
+    want = ref.generate_greedy(vlong, 40)
+    llm = _llm(cfg, syn, max_slots=2, max_positions=1100)
+    got = llm.generate_ids([vlong, long_prompt[:30]], 40)
+    assert got[0] == want and got[1] == ref.generate_greedy(long_prompt[:30], 40)
+    assert llm.generate_ids([vlong], 40)[0] == want
