@@ -168,6 +168,17 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
         for (int mt = 0; mt < MT; ++mt) bf[u][s][mt] = *(const bf16x8*)(p.XS + xs_off(j, s, k8, mrow[mt], M));
     }
   };
+  // QKV: the epilogue's row descriptors are requested FIRST, so the counted wait for them does not include the weight
+  // stream and the RoPE factors (addressed by the row's position) can be requested while the weights are in flight
+  const int em = lane & 15;
+  RowDesc erd[MT];
+  if (EPI == EPI_QKV && wave < NTB && nt0 + wave < NT) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mbase + mt * 16 + em;
+      erd[mt] = p.rows[m < M ? m : M - 1];
+    }
+  }
 #pragma unroll
   for (int b = 0; b < WB; ++b)
     if (wave + b * NW * U < KT) load_w(w[b], wave + b * NW * U);
@@ -191,9 +202,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
   }
 
   // ---- epilogue operands that do not depend on the GEMM
-  const int em = lane & 15;
-  RowDesc erd[MT];
   float4 epre[MT], egam = make_float4(0.f, 0.f, 0.f, 0.f);
+  float2 erope[MT][2];
   if (wave < NTB && nt0 + wave < NT) {
     const int n = (nt0 + wave) * 16 + 4 * (lane >> 4);
     if (EPI == EPI_RESID) egam = *(const float4*)(p.gamma_next + n);
@@ -201,7 +211,14 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
     for (int mt = 0; mt < MT; ++mt) {
       const int m = mbase + mt * 16 + em;
       if (m < M && ract) {
-        if (EPI == EPI_QKV) { erd[mt] = p.rows[m]; epre[mt] = *(const float4*)(p.bias + n); }
+        if (EPI == EPI_QKV) {
+          epre[mt] = *(const float4*)(p.bias + n);
+          if (n < p.q_dim + p.kv_dim) {
+            const int i0 = (n & 63) >> 1;
+            erope[mt][0] = p.rope[(size_t)erd[mt].pos * 32 + i0];
+            erope[mt][1] = p.rope[(size_t)erd[mt].pos * 32 + i0 + 1];
+          }
+        }
         if (EPI == EPI_RESID) epre[mt] = *(const float4*)(p.Y + (size_t)m * (NT * 16) + n);
       }
     }
@@ -337,8 +354,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
           const RowDesc rd = erd[mt];
           if (n < p.q_dim + p.kv_dim) {
             // rows inside a head are ordered (0,32,1,33,..): (s.x,s.y) and (s.z,s.w) are RoPE pairs
-            const int i0 = (n & 63) >> 1;
-            const float2 c0 = p.rope[(size_t)rd.pos * 32 + i0], c1 = p.rope[(size_t)rd.pos * 32 + i0 + 1];
+            const float2 c0 = erope[mt][0], c1 = erope[mt][1];   // requested in the prologue
             float4 r;
             r.x = __fadd_rn(__fmul_rn(s.x, c0.x), __fmul_rn(-s.y, c0.y));  // x1*cos + (-x2)*sin
             r.y = __fadd_rn(__fmul_rn(s.y, c0.x), __fmul_rn(s.x, c0.y));   // x2*cos + x1*sin
