@@ -87,7 +87,6 @@ struct GemmP {
   PfDesc pf;
   int ldsb;              // few rows: bytes of wave-private LDS for the activation triples (0 = read them from global per tile)
   int lt_shift;          // log2(lanes that fetch one k tile's 12*M pieces)
-  int flags;             // bit 0: keep the staging loads behind the weight loads (diagnostics)
 };
 
 // exact 3-way bf16 split: x == hi + mid + lo (8 + 8 + 8 mantissa bits)
@@ -180,35 +179,17 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
       erd[mt] = p.rows[m < M ? m : M - 1];
     }
   }
+#pragma unroll
+  for (int b = 0; b < WB; ++b)
+    if (wave + b * NW * U < KT) load_w(w[b], wave + b * NW * U);
   // few rows (MT == 1, ldsb > 0): a k tile's 12*M operand pieces are contiguous in XS, so the wave pulls
   // them with full-width loads into its own LDS slice (no block barrier) instead of 3 narrow loads per tile
   const bool vlds = MT == 1 && p.ldsb > 0;
   unsigned char* bw = smem + (size_t)NW * NTB * MT * 1024 + 32 * 4 + NTB * 32 * 8 + (size_t)wave * p.ldsb;
-  const int tw = (KT - wave + NW - 1) / NW;          // this wave's k tiles
-  const int per = vlds ? 64 >> p.lt_shift : 1, pm = 12 * M;
-  const int sr = lane & ((1 << p.lt_shift) - 1);
-  // up to three staging passes (one row: always) are requested AHEAD of the weight stream: loads return in order, so the
-  // LDS copy then completes while the weights are still in flight instead of after them
-  const bool early = vlds && (tw + per - 1) / per <= 3 && !(p.flags & 1);
-  uint4 sv[3];
-  if (early) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int tl = i * per + (lane >> p.lt_shift);
-      sv[i] = (tl < tw && sr < pm) ? *(const uint4*)(p.XS + xs_off(wave + tl * NW, 0, 0, 0, M) + sr * 16) : make_uint4(0u, 0u, 0u, 0u);
-    }
-  }
-#pragma unroll
-  for (int b = 0; b < WB; ++b)
-    if (wave + b * NW * U < KT) load_w(w[b], wave + b * NW * U);
-  if (early) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int tl = i * per + (lane >> p.lt_shift);
-      if (tl < tw && sr < pm) *(uint4*)(bw + ((size_t)tl * pm + sr) * 16) = sv[i];
-    }
-  } else if (vlds) {
-    const int r = sr;
+  if (vlds) {
+    const int tw = (KT - wave + NW - 1) / NW;          // this wave's k tiles
+    const int per = 64 >> p.lt_shift, pm = 12 * M;
+    const int r = lane & ((1 << p.lt_shift) - 1);
     for (int t0 = 0; t0 < tw; t0 += per) {
       const int tl = t0 + (lane >> p.lt_shift);
       if (tl < tw && r < pm) {
@@ -1340,7 +1321,7 @@ int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
   // idle CUs warm the L2 of their own XCD for a later kernel (decode with few rows only)
   const int helpers = (L->prefetch && p.pf.base && p.M <= 8 && work < 232) ? (256 - work) / 8 * 8 : 0;
   size_t lds = (size_t)NW * NTB * MT * 1024 + 32 * 4 + NTB * 32 * 8;
-  p.ldsb = 0; p.lt_shift = 0; p.flags = (L->tune2 & 64) ? 1 : 0;
+  p.ldsb = 0; p.lt_shift = 0;
   if (MT == 1 && p.M <= 5) {
     const int tw = (p.KT + NW - 1) / NW;               // k tiles per wave
     const size_t per_wave = (size_t)tw * 12 * p.M * 16;
