@@ -113,7 +113,9 @@ __device__ __forceinline__ size_t xs_off(int kt, int s, int k8, int m, int M) {
 // H > 1 (RESID only): the 16 rows of a weight tile are split over H blocks (8 or 4 rows each: only those
 // lanes load, the others feed zeros to the MFMA), so a matrix with few n tiles (N = 896: 56) still
 // spreads its HBM stream over 112 / 224 CUs.  Every output element keeps its own summation order.
-template <int MT, int NTB, int NW, int U, int WB, int PRO, int EPI, int KVF32, int H = 1, int OCC = 1>
+// LEAN: the few-row decode instantiation (M <= 5, operands staged through wave-private LDS, no phase stamps): the paths it
+// never takes are compiled out -- these kernels are bound by instruction issue as much as by memory.
+template <int MT, int NTB, int NW, int U, int WB, int PRO, int EPI, int KVF32, int H = 1, int OCC = 1, int LEAN = 0>
 __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
   static_assert(H == 1 || ((H == 2 || H == 4) && NTB == 1 && EPI == EPI_RESID), "row-split tiles: RESID, one tile per block");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
   const int nt0 = (H > 1 ? (int)blockIdx.x % nblk : (int)blockIdx.x) * NTB;
   const bool wact = H == 1 || ((lane & 15) >> (H == 2 ? 3 : 2)) == part;   // this lane's weight row is in the part
   const bool ract = H == 1 || ((lane >> 4) >> (H == 2 ? 1 : 0)) == part;   // this lane's 4 output columns are
-#define SMI_STAMP(i) do { if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SMI_STAMP(i) do { if (!LEAN && p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   SMI_STAMP(0);
   float4* red = (float4*)smem;                                   // [NW][NTB][MT][64]
   float* rarr = (float*)(smem + (size_t)NW * NTB * MT * 1024);  // [32] per-row RMSNorm factor
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
     if (wave + b * NW * U < KT) load_w(w[b], wave + b * NW * U);
   // few rows (MT == 1, ldsb > 0): a k tile's 12*M operand pieces are contiguous in XS, so the wave pulls
   // them with full-width loads into its own LDS slice (no block barrier) instead of 3 narrow loads per tile
-  const bool vlds = MT == 1 && p.ldsb > 0;
+  const bool vlds = LEAN || (MT == 1 && p.ldsb > 0);
   unsigned char* bw = smem + (size_t)NW * NTB * MT * 1024 + 32 * 4 + NTB * 32 * 8 + (size_t)wave * p.ldsb;
   if (vlds) {
     const int tw = (KT - wave + NW - 1) / NW;          // this wave's k tiles
@@ -1343,7 +1345,13 @@ int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
   }
   const int groups = (p.M + MT * 16 - 1) / (MT * 16);   // one block row per MT*16 rows (more than one: prefill, or 17..32 rows as 2 x 16)
   SMI_REQUIRE(groups == 1 || EPI != EPI_LM, "lm_head takes at most 32 rows per launch");
-  if (L->cfg.kv_dtype)
+  constexpr int kLean = (MT == 1 && EPI != EPI_LM) ? 1 : 0;
+  if (kLean && p.ldsb > 0 && !p.stamps && !(L->tune2 & 256)) {
+    if (L->cfg.kv_dtype)
+      hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 1, H, OCC, kLean>), dim3(work + helpers, groups), dim3(NW * 64), lds, st, p);
+    else
+      hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 0, H, OCC, kLean>), dim3(work + helpers, groups), dim3(NW * 64), lds, st, p);
+  } else if (L->cfg.kv_dtype)
     hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 1, H, OCC>), dim3(work + helpers, groups), dim3(NW * 64), lds, st, p);
   else
     hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 0, H, OCC>), dim3(work + helpers, groups), dim3(NW * 64), lds, st, p);
