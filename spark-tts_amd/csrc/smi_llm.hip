@@ -124,8 +124,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
     pf_run(p.pf, (int)blockIdx.x - p.work_blocks, (int)gridDim.x - p.work_blocks, tid, NW * 64);
     return;
   }
-  const int KT = p.KT, M = p.M, NT = p.NT;
-  const int mbase = (int)blockIdx.y * (MT * 16);   // row group (grid.y > 1: a prompt's rows, 32 per block row)
+  const int KT = p.KT, M = LEAN == 2 ? 1 : p.M, NT = p.NT;   // LEAN == 2: exactly one row (batch-1 decode), folded at compile time
+  const int mbase = LEAN == 2 ? 0 : (int)blockIdx.y * (MT * 16);   // row group (grid.y > 1: a prompt's rows, 32 per block row)
   const int nblk = p.work_blocks / H;   // blocks per row part; part r of tile t is block r * nblk + t (same XCD for all r)
   const int part = H > 1 ? (int)blockIdx.x / nblk : 0;
   const int nt0 = (H > 1 ? (int)blockIdx.x % nblk : (int)blockIdx.x) * NTB;
@@ -190,10 +190,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
   unsigned char* bw = smem + (size_t)NW * NTB * MT * 1024 + 32 * 4 + NTB * 32 * 8 + (size_t)wave * p.ldsb;
   if (vlds) {
     const int tw = (KT - wave + NW - 1) / NW;          // this wave's k tiles
-    const int per = 64 >> p.lt_shift, pm = 12 * M;
-    const int r = lane & ((1 << p.lt_shift) - 1);
+    const int lts = LEAN == 2 ? 4 : p.lt_shift;
+    const int per = 64 >> lts, pm = 12 * M;
+    const int r = lane & ((1 << lts) - 1);
     for (int t0 = 0; t0 < tw; t0 += per) {
-      const int tl = t0 + (lane >> p.lt_shift);
+      const int tl = t0 + (lane >> lts);
       if (tl < tw && r < pm) {
         const uint4 v = *(const uint4*)(p.XS + xs_off(wave + tl * NW, 0, 0, 0, M) + r * 16);
         *(uint4*)(bw + ((size_t)tl * pm + r) * 16) = v;
@@ -1346,7 +1347,12 @@ int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
   const int groups = (p.M + MT * 16 - 1) / (MT * 16);   // one block row per MT*16 rows (more than one: prefill, or 17..32 rows as 2 x 16)
   SMI_REQUIRE(groups == 1 || EPI != EPI_LM, "lm_head takes at most 32 rows per launch");
   constexpr int kLean = (MT == 1 && EPI != EPI_LM) ? 1 : 0;
-  if (kLean && p.ldsb > 0 && !p.stamps && !(L->tune2 & 256)) {
+  if (kLean && p.ldsb > 0 && !p.stamps && p.M == 1 && p.lt_shift == 4) {
+    if (L->cfg.kv_dtype)
+      hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 1, H, OCC, 2 * kLean>), dim3(work + helpers, groups), dim3(NW * 64), lds, st, p);
+    else
+      hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 0, H, OCC, 2 * kLean>), dim3(work + helpers, groups), dim3(NW * 64), lds, st, p);
+  } else if (kLean && p.ldsb > 0 && !p.stamps) {
     if (L->cfg.kv_dtype)
       hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 1, H, OCC, kLean>), dim3(work + helpers, groups), dim3(NW * 64), lds, st, p);
     else
