@@ -752,7 +752,8 @@ constexpr int kAttnSeg = 1024;   // tokens per segment (a multiple of the chunk 
 // so every lane accumulates at the same scale; the final merge is a plain sum: inside the wave through
 // its private LDS slice, across waves through one more barrier.  Little redundant work per thread:
 // with one block per head the kernel is bound by instruction issue of its own waves.
-template <int KVF32>
+// ONE: exactly one live row in KV slot 0 and one context segment (batch-1 decode): index arithmetic folded at compile time
+template <int KVF32, int ONE = 0>
 __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
   constexpr int LPT = KVF32 ? 16 : 8;   // lanes per token row (each lane 16 bytes)
   constexpr int DPL = kHeadDim / LPT;   // dims per lane
@@ -770,14 +771,16 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
     pf_run(p.pf, (int)blockIdx.x - p.work_blocks, (int)gridDim.x - p.work_blocks, tid, kAttnWaves * 64);
     return;
   }
-  const int head = (blockIdx.x / p.nseg) % p.n_heads, m = blockIdx.x / (p.nseg * p.n_heads), seg = blockIdx.x % p.nseg;
+  const int head = ONE ? (int)blockIdx.x : (int)(blockIdx.x / p.nseg) % p.n_heads, m = ONE ? 0 : (int)blockIdx.x / (p.nseg * p.n_heads),
+            seg = ONE ? 0 : (int)blockIdx.x % p.nseg;
   const int tl = lane / LPT, dl = lane % LPT;
   const int grp = wave * TPW + tl;
   const RowDesc rd = p.rows[m];
   const int kvh = head / p.group;
   // decode rows use slot == row, so the K/V addresses do not depend on the descriptor and the first
   // chunk's loads leave together with it (positions beyond ctx are valid cache memory, masked later)
-  const int slot = p.slot_is_row ? m : rd.slot;
+  const bool sir = ONE || p.slot_is_row;
+  const int slot = sir ? m : rd.slot;
   const size_t rowbase = ((size_t)slot * p.n_kv + kvh) * p.max_pos;
   const int ctx_all = rd.pos + 1;
   const int ctx = ctx_all < (seg + 1) * kAttnSeg ? ctx_all : (seg + 1) * kAttnSeg;   // this block: keys [seg * kAttnSeg, ctx)
@@ -799,7 +802,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int t = c0 + u * NGRP + grp;
-      const int tc = p.slot_is_row ? (t < p.max_pos ? t : p.max_pos - 1) : (t < ctx ? t : ctx - 1);
+      const int tc = sir ? (t < p.max_pos ? t : p.max_pos - 1) : (t < ctx ? t : ctx - 1);
       const size_t off = (rowbase + tc) * kHeadDim + dl * DPL;
       if (KVF32) {
         kr[u] = *(const uint4*)((const float*)p.kcache + off);
@@ -883,7 +886,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
       const float sc = exp2f((wmax[w] - bm) * LOG2E);   // 0 for a wave that saw no valid token (m_run = NEG)
       O += pw[w][tid] * sc; Ls += pl[w] * sc;
     }
-    if (p.nseg > 1) {   // segment partial at scale exp(-bm); k_attn_merge finishes the row
+    if (!ONE && p.nseg > 1) {   // segment partial at scale exp(-bm); k_attn_merge finishes the row
       float* pp = p.part + (((size_t)m * p.n_heads + head) * p.nseg + seg) * 66;
       pp[2 + tid] = O;
       if (tid == 0) { pp[0] = bm; pp[1] = Ls; }
@@ -892,8 +895,9 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
     uint32_t hi, mi, lo;
     split3(O / Ls, hi, mi, lo);
     const int k = head * kHeadDim + tid;
-    const size_t ob = xs_off(k >> 5, 0, (k >> 3) & 3, m, p.M) + (k & 7) * 2;
-    const size_t pl2 = (size_t)4 * p.M * 16;
+    const int Mx = ONE ? 1 : p.M;
+    const size_t ob = xs_off(k >> 5, 0, (k >> 3) & 3, m, Mx) + (k & 7) * 2;
+    const size_t pl2 = (size_t)4 * Mx * 16;
     *(uint16_t*)(p.xs_out + ob) = (uint16_t)hi;
     *(uint16_t*)(p.xs_out + ob + pl2) = (uint16_t)mi;
     *(uint16_t*)(p.xs_out + ob + 2 * pl2) = (uint16_t)lo;
@@ -1417,7 +1421,10 @@ int launch_attn(smi_llm* L, AttnP a, int helpers_ok, hipStream_t st) {
     a.part = L->apart;
   }
   const int helpers = (helpers_ok && L->prefetch && a.M <= 8 && a.work_blocks < 232) ? (256 - a.work_blocks) / 8 * 8 : 0;
-  hipLaunchKernelGGL(k_attn<KVF32>, dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
+  if (a.M == 1 && a.nseg == 1 && a.slot_is_row)
+    hipLaunchKernelGGL((k_attn<KVF32, 1>), dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
+  else
+    hipLaunchKernelGGL((k_attn<KVF32, 0>), dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
   SMI_LAUNCH_CHECK();
   if (a.nseg > 1) {
     hipLaunchKernelGGL(k_attn_merge, dim3(a.M), dim3(1024), 0, st, a);
