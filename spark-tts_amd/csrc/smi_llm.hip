@@ -480,30 +480,45 @@ __global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
     for (int b = 0; b < MTB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   stage_store(0);
   __syncthreads();
+  // weight tiles run two k tiles ahead of the MFMAs (HBM / L2 latency hidden behind 96 MFMAs per wave)
+  uint4 wA[NTW], wB[NTW], wC[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    wA[i] = p.W[((size_t)nts[i] * KT + 0) * 64 + lane];
+    wB[i] = p.W[((size_t)nts[i] * KT + (1 < KT ? 1 : KT - 1)) * 64 + lane];
+  }
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
-    uint4 wA[NTW];
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) wA[i] = p.W[((size_t)nts[i] * KT + kt) * 64 + lane];
+    for (int i = 0; i < NTW; ++i) wC[i] = p.W[((size_t)nts[i] * KT + (kt + 2 < KT ? kt + 2 : KT - 1)) * 64 + lane];
     if (kt + 1 < KT) stage_load(kt + 1);                 // in flight during this tile's MFMAs
     const uint4* Bb = Bs + buf * PIECES;
+    // operand pieces of m-tile mt + 1 are read from LDS while the six MFMAs of m-tile mt run
+    uint4 bq[2][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) bq[0][s] = Bb[(s * 4 + k8) * ROWS + em];
 #pragma unroll
     for (int mt = 0; mt < MTB; ++mt) {
-      bf16x8 b[3];
+      if (mt + 1 < MTB) {
 #pragma unroll
-      for (int s = 0; s < 3; ++s) b[s] = __builtin_bit_cast(bf16x8, Bb[(s * 4 + k8) * ROWS + mt * 16 + em]);
+        for (int s = 0; s < 3; ++s) bq[(mt + 1) & 1][s] = Bb[(s * 4 + k8) * ROWS + (mt + 1) * 16 + em];
+      }
+      const bf16x8 b0 = __builtin_bit_cast(bf16x8, bq[mt & 1][0]), b1 = __builtin_bit_cast(bf16x8, bq[mt & 1][1]),
+                   b2 = __builtin_bit_cast(bf16x8, bq[mt & 1][2]);
 #pragma unroll
       for (int i = 0; i < NTW; ++i) {
         const bf16x8 a = __builtin_bit_cast(bf16x8, wA[i]);
-        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[2], acc[i][mt], 0, 0, 0);
-        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[1], acc[i][mt], 0, 0, 0);
-        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[0], acc[i][mt], 0, 0, 0);
+        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2, acc[i][mt], 0, 0, 0);
+        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[i][mt], 0, 0, 0);
+        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[i][mt], 0, 0, 0);
       }
     }
     if (kt + 1 < KT) {
       stage_store(buf ^ 1);                              // the other buffer was last read two barriers ago
       __syncthreads();
     }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) { wA[i] = wB[i]; wB[i] = wC[i]; }
   }
   // ---- epilogue (same arithmetic as k_gemm's)
   const int N = NT * 16;
