@@ -434,9 +434,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
 // 128 rows and an operand piece once per 128 output columns.  One accumulator per (tile, m-tile),
 // terms in the order lo, mid, hi per k tile: a row's result does not depend on M or on the batch.
 // ------------------------------------------------------------------------------------------
-template <int PRO, int EPI, int KVF32>
+template <int PRO, int EPI, int KVF32, int NTW = 2>
 __global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
-  constexpr int NTW = 2, MTB = 8, ROWS = MTB * 16, PIECES = 3 * 4 * ROWS;   // 1536 16-byte pieces per k tile
+  constexpr int MTB = 8, ROWS = MTB * 16, PIECES = 3 * 4 * ROWS;   // 1536 16-byte pieces per k tile; NTW weight tiles per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* Bs = (uint4*)smem;                              // [2][PIECES]
   float* rarr = (float*)(smem + (size_t)2 * PIECES * 16);  // [ROWS]
@@ -1563,12 +1563,12 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
 }
 
 // One prefill GEMM over M rows (any M) with k_pgemm; `which` as in launch_one (GEMM kernels only).
-template <int PRO, int EPI>
+template <int PRO, int EPI, int NTW = 2>
 int launch_pgemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
-  const dim3 grid((p.NT + 7) / 8, (p.M + 127) / 128);
+  const dim3 grid((p.NT + 4 * NTW - 1) / (4 * NTW), (p.M + 127) / 128);
   const size_t lds = (size_t)2 * 1536 * 16 + 128 * 4;
-  if (L->cfg.kv_dtype) hipLaunchKernelGGL((k_pgemm<PRO, EPI, 1>), grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((k_pgemm<PRO, EPI, 0>), grid, dim3(256), lds, st, p);
+  if (L->cfg.kv_dtype) hipLaunchKernelGGL((k_pgemm<PRO, EPI, 1, NTW>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((k_pgemm<PRO, EPI, 0, NTW>), grid, dim3(256), lds, st, p);
   SMI_LAUNCH_CHECK();
   return SMI_OK;
 }
@@ -1612,7 +1612,7 @@ int launch_layers_big(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
     memset(&g, 0, sizeof(g));
     g.M = M; g.rows = rows; g.eps = c.rms_eps; g.sspart = L->bss; g.npart = npart;
     g.W = (const uint4*)sec(L, SMI_LLM_WGU, l); g.NT = L->NTgu; g.KT = L->KTh; g.XS = L->bxs_h; g.XSout = L->bxs_act;
-    if ((rc = grouped ? launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_SWIGLU, 1, 2>(L, g, st) : launch_pgemm<PRO_NORM, EPI_SWIGLU>(L, g, st))) return rc;
+    if ((rc = grouped ? launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_SWIGLU, 1, 2>(L, g, st) : ((L->tune2 & 512) ? launch_pgemm<PRO_NORM, EPI_SWIGLU>(L, g, st) : launch_pgemm<PRO_NORM, EPI_SWIGLU, 4>(L, g, st)))) return rc;
     // down
     GemmP d;
     memset(&d, 0, sizeof(d));
