@@ -38,7 +38,7 @@ extern "C" {
 #define SMI_ESTATE (-4)   /* call sequence violated (e.g. decode before prefill) */
 
 #define SMI_ABI_VERSION 1
-#define SMI_MAX_ROWS 32   /* rows (= concurrent sequences, or prompt tokens per prefill chunk) per step */
+#define SMI_MAX_ROWS 64   /* rows (= concurrent sequences, or prompt tokens per prefill chunk) per step */
 
 int smi_version(void);
 const char* smi_last_error(void);

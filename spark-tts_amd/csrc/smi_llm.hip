@@ -66,7 +66,7 @@ struct GemmP {
   int NT, KT, M;         // n tiles, k tiles, rows
   const RowDesc* rows;
   const unsigned char* XS;   // operand: exact bf16 triples [KT][3][4][M][16 B] in MFMA B-operand order
-  const float* sspart;   // PRO_NORM: [32][npart] partial sums of squares of the operand's fp32 source row
+  const float* sspart;   // PRO_NORM: [rows][npart] partial sums of squares of the operand's fp32 source row
   int npart;
   float eps;
   float* Y;              // RESID: h [M][N]; QKV: q [M][q_dim]; LM: logits [M][V] or null
@@ -76,12 +76,12 @@ struct GemmP {
   void* vcache;
   int q_dim, kv_dim, n_kv, max_pos;
   int V;                 // LM: true vocab size
-  float* pval;           // LM: [32][work_blocks] per-block best logit
+  float* pval;           // LM: [rows][work_blocks] per-block best logit
   int* pidx;
   // producer side: the next consumer's operand, written by the epilogue
   unsigned char* XSout;  // RESID: triples of gamma_next * h_new, [N/32][3][4][M][16]; SWIGLU: triples of act
   const float* gamma_next;  // RESID: [N] RMSNorm weight of the NEXT norm
-  float* ssout;          // RESID: [32][NT * 4] partial sums of squares of h_new, one per 4 columns (k_pgemm: [rows][NT])
+  float* ssout;          // RESID: [rows][NT * 4] partial sums of squares of h_new, one per 4 columns (k_pgemm: [rows][NT])
   unsigned long long* stamps;
   int work_blocks;       // blocks >= work_blocks are prefetch helpers (pf)
   PfDesc pf;
@@ -1000,7 +1000,7 @@ struct SampleP {
   float inv_temp, top_p;
   unsigned long long seed;
   const int32_t* step;
-  int* tok;             // [32] sampled token per row
+  int* tok;             // [kMaxRows] sampled token per row
   const float* pval;    // [M][nblk] the lm_head blocks' best logits (a bound for the top-k threshold) or null
   int nblk;
 };
@@ -1169,9 +1169,9 @@ struct FinP {
   const int* pidx;
   int nblk, M, KT;
   RowDesc* rows;
-  int64_t* hist;      // [max_steps][32]
-  int32_t* count;     // [32] tokens counted per sequence
-  int32_t* finished;  // [32]
+  int64_t* hist;      // [max_steps][kMaxRows]
+  int32_t* count;     // [kMaxRows] tokens counted per sequence
+  int32_t* finished;  // [kMaxRows]
   int32_t* step;      // [1]
   int64_t eos;
   const uint16_t* Wlm;
@@ -1229,7 +1229,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinP p) {
     RowDesc rd = p.rows[m];
     const int step = rd.flags;                 // tokens this row has emitted so far
     const int sl = rd.slot;                    // history / counters live per KV slot (== m outside sessions)
-    if (step < p.max_steps) p.hist[(size_t)step * 32 + sl] = bi;
+    if (step < p.max_steps) p.hist[(size_t)step * kMaxRows + sl] = bi;
     if (!p.finished[sl]) {
       p.count[sl] = step + 1;
       if ((int64_t)bi == p.eos) p.finished[sl] = 1;
@@ -1302,10 +1302,10 @@ struct smi_llm {
   // device scratch
   float *h, *qbuf;
   unsigned char *xs_h, *xs_attn, *xs_act;   // GEMM operands as exact bf16 triples ([K/32][3][4][M][16 B])
-  float* sspart;       // [32][NTh * 4] partial sums of squares of h (RMSNorm), one per 4 columns
+  float* sspart;       // [kMaxRows][NTh * 4] partial sums of squares of h (RMSNorm), one per 4 columns
   // prefill workspace for up to big_rows rows at once (allocated at the first multi-chunk prefill)
   float *bh, *bq; unsigned char *bxs_h, *bxs_attn, *bxs_act; float* bss; int big_rows;
-  RowDesc* rows;       // live decode rows [32]
+  RowDesc* rows;       // live decode rows [kMaxRows]
   RowDesc* plan;       // prefill plan
   size_t plan_cap;     // rows
   float* pval; int* pidx; int lm_blocks, lm_cap;
@@ -1316,7 +1316,7 @@ struct smi_llm {
   int session, identity_slots;
   int attn_seg;                        // context segments per (head, row) of the attention launches being issued (1 = unsplit)
   float* apart; size_t apart_floats;   // segment partials [rows][heads][attn_seg][66]
-  int slot_busy[32], slot_len[32];      // host: slot in use; prompt length + tokens emitted (cache positions used)
+  int slot_busy[kMaxRows], slot_len[kMaxRows];      // host: slot in use; prompt length + tokens emitted (cache positions used)
   int max_len, steps_launched;  // host-side bound on cache positions in use
   // sampling state (smi_llm_set_sampling)
   int do_sample, top_k; float temperature, top_p; unsigned long long seed;
@@ -1747,14 +1747,14 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   SMI_ALLOC(L->xs_act, (size_t)kMaxRows * L->I * 6);
   SMI_ALLOC(L->sspart, (size_t)kMaxRows * L->NTh * 4 * 4);
   SMI_ALLOC(L->rows, kMaxRows * sizeof(RowDesc));
-  SMI_ALLOC(L->pval, (size_t)L->lm_cap * 32 * 4);
-  SMI_ALLOC(L->pidx, (size_t)L->lm_cap * 32 * 4);
-  SMI_ALLOC(L->hist, (size_t)L->max_steps * 32 * 8);
-  SMI_ALLOC(L->count, 32 * 4);
-  SMI_ALLOC(L->finished, 32 * 4);
+  SMI_ALLOC(L->pval, (size_t)L->lm_cap * kMaxRows * 4);
+  SMI_ALLOC(L->pidx, (size_t)L->lm_cap * kMaxRows * 4);
+  SMI_ALLOC(L->hist, (size_t)L->max_steps * kMaxRows * 8);
+  SMI_ALLOC(L->count, kMaxRows * 4);
+  SMI_ALLOC(L->finished, kMaxRows * 4);
   SMI_ALLOC(L->step, 4);
   SMI_ALLOC(L->logits, (size_t)kMaxRows * cfg->vocab_size * 4);
-  SMI_ALLOC(L->tok, 32 * 4);
+  SMI_ALLOC(L->tok, kMaxRows * 4);
   SMI_ALLOC(L->stamps, (size_t)4096 * 8 * 8);
   SMI_ALLOC(L->kcache, kvbytes);
   SMI_ALLOC(L->vcache, kvbytes);
@@ -1767,7 +1767,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
       hipMemset(L->sspart, 0, (size_t)kMaxRows * L->NTh * 4 * 4) != hipSuccess ||
       hipMemset(L->qbuf, 0, (size_t)kMaxRows * L->Q * 4) != hipSuccess ||
       hipMemset(L->rows, 0, kMaxRows * sizeof(RowDesc)) != hipSuccess ||
-      hipMemset(L->count, 0, 128) != hipSuccess || hipMemset(L->finished, 0, 128) != hipSuccess ||
+      hipMemset(L->count, 0, kMaxRows * 4) != hipSuccess || hipMemset(L->finished, 0, kMaxRows * 4) != hipSuccess ||
       hipMemset(L->step, 0, 4) != hipSuccess) {
     smi_set_error("hipMemset of scratch failed");
     smi_llm_destroy(L);
@@ -1872,8 +1872,8 @@ int smi_llm_prefill(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, 
   hipStream_t st = (hipStream_t)stream;
   int32_t slots[kMaxRows];
   for (int b = 0; b < kMaxRows; ++b) slots[b] = b;
-  SMI_HIP(hipMemsetAsync(L->count, 0, 128, st));
-  SMI_HIP(hipMemsetAsync(L->finished, 0, 128, st));
+  SMI_HIP(hipMemsetAsync(L->count, 0, kMaxRows * 4, st));
+  SMI_HIP(hipMemsetAsync(L->finished, 0, kMaxRows * 4, st));
   SMI_HIP(hipMemsetAsync(L->step, 0, 4, st));
   L->B = B; L->eos = eos_id; L->started = 1; L->session = 0; L->identity_slots = 1;
   L->max_len = 0;
@@ -1892,8 +1892,8 @@ int smi_llm_prefill(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, 
 int smi_llm_session_begin(smi_llm* L, int64_t eos_id, void* stream) {
   SMI_REQUIRE(L, "smi_llm_session_begin: null handle");
   hipStream_t st = (hipStream_t)stream;
-  SMI_HIP(hipMemsetAsync(L->count, 0, 128, st));
-  SMI_HIP(hipMemsetAsync(L->finished, 0, 128, st));
+  SMI_HIP(hipMemsetAsync(L->count, 0, kMaxRows * 4, st));
+  SMI_HIP(hipMemsetAsync(L->finished, 0, kMaxRows * 4, st));
   SMI_HIP(hipMemsetAsync(L->step, 0, 4, st));
   L->B = 0; L->eos = eos_id; L->started = 1; L->session = 1; L->identity_slots = 1;
   L->max_len = 0; L->steps_launched = 0;
@@ -1989,7 +1989,7 @@ int smi_llm_slot_tokens(smi_llm* L, int slot, int64_t* out, int cap, int32_t* n_
   SMI_HIP(hipStreamSynchronize(st));
   int n = cnt < cap ? cnt : cap;
   if (n > L->max_steps) n = L->max_steps;
-  if (n > 0) SMI_HIP(hipMemcpy2D(out, 8, L->hist + slot, 32 * 8, 8, (size_t)n, hipMemcpyDeviceToHost));
+  if (n > 0) SMI_HIP(hipMemcpy2D(out, 8, L->hist + slot, kMaxRows * 8, 8, (size_t)n, hipMemcpyDeviceToHost));
   *n_out = n;
   *finished = fin;
   return SMI_OK;
@@ -2057,7 +2057,7 @@ int smi_llm_decode(smi_llm* L, int n_steps, void* stream) {
 
 int smi_llm_all_done(smi_llm* L, int* all_done, void* stream) {
   SMI_REQUIRE(L && all_done, "smi_llm_all_done: null argument");
-  int32_t fin[32];
+  int32_t fin[kMaxRows];
   SMI_HIP(hipMemcpyAsync(fin, L->finished, sizeof(fin), hipMemcpyDeviceToHost, (hipStream_t)stream));
   SMI_HIP(hipStreamSynchronize((hipStream_t)stream));
   int d = 1;
@@ -2076,18 +2076,18 @@ int smi_llm_steps(smi_llm* L) {
 int smi_llm_get_tokens(smi_llm* L, int64_t* out, int32_t* lens, int cap, void* stream) {
   SMI_REQUIRE(L && out && lens && cap >= 0, "smi_llm_get_tokens: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  int32_t cnt[32], step = 0;
+  int32_t cnt[kMaxRows], step = 0;
   SMI_HIP(hipMemcpyAsync(cnt, L->count, sizeof(cnt), hipMemcpyDeviceToHost, st));
   SMI_HIP(hipMemcpyAsync(&step, L->step, 4, hipMemcpyDeviceToHost, st));
   SMI_HIP(hipStreamSynchronize(st));
   if (step > L->max_steps) step = L->max_steps;
-  std::vector<int64_t> hist((size_t)step * 32);
+  std::vector<int64_t> hist((size_t)step * kMaxRows);
   if (step) SMI_HIP(hipMemcpy(hist.data(), L->hist, hist.size() * 8, hipMemcpyDeviceToHost));
   for (int b = 0; b < L->B; ++b) {
     int n = cnt[b] < cap ? cnt[b] : cap;
     if (n > step) n = step;
     lens[b] = n;
-    for (int s = 0; s < n; ++s) out[(size_t)b * cap + s] = hist[(size_t)s * 32 + b];
+    for (int s = 0; s < n; ++s) out[(size_t)b * cap + s] = hist[(size_t)s * kMaxRows + b];
   }
   return SMI_OK;
 }

@@ -12,7 +12,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["SPARKMI_LIB"]) if os.environ.get("SPARKMI_LIB") else _HERE / "libsparkmi.so"
 
-SMI_MAX_ROWS = 32
+SMI_MAX_ROWS = 64
 
 
 class SparkMIError(RuntimeError):

@@ -314,3 +314,19 @@ def test_cache_boundaries_and_long_contexts(tiny):
     got = llm.generate_ids([vlong, long_prompt[:30]], 40)
     assert got[0] == want and got[1] == ref.generate_greedy(long_prompt[:30], 40)
     assert llm.generate_ids([vlong], 40)[0] == want
+
+
+def test_sixty_four_concurrent_sequences_equal_single_runs(tiny):
+    """SMI_MAX_ROWS = 64 live sequences per step (four 16-row block rows in the few-tile GEMVs, two 32-row ones in
+    gate_up, four lm_head passes): every sequence still equals its own B = 1 run."""
+    cfg, syn = tiny
+    rng = np.random.Generator(np.random.PCG64(64))
+    B = 64
+    prompts = [rng.integers(0, cfg.vocab_size, size=int(rng.integers(1, 30))).tolist() for _ in range(B)]
+    batched = _llm(cfg, syn, max_slots=B, max_positions=64).generate_ids(prompts, 20)
+    single = _llm(cfg, syn, max_slots=1, max_positions=64)
+    for b in (0, 15, 16, 31, 32, 47, 48, 63):
+        assert single.generate_ids([prompts[b]], 20)[0] == batched[b], f"sequence {b}"
+    from sparkmi._lib import SparkMIError
+    with pytest.raises(SparkMIError):
+        _llm(cfg, syn, max_slots=65, max_positions=64)
