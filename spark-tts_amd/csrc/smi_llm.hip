@@ -615,26 +615,33 @@ __global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
 // a running arg-max per row.  Same k-tile -> wave map, accumulator chains and reduction order as
 // k_gemm<EPI_LM>, so the logits are bit-identical to the two-m-tile path.
 // ------------------------------------------------------------------------------------------
-template <int KVF32_UNUSED>
-__global__ __launch_bounds__(256) void k_lm(GemmP p, int ngroups, int m0) {
+// HV = 2: two groups of four waves share a block and the weight stream (the second group's tile loads hit L2); group h
+// owns rows m0 + 16 h .. and does exactly what the HV = 1 kernel does for 16 rows, so the logits are the same bits.
+template <int HV>
+__global__ __launch_bounds__(256 * HV) void k_lm(GemmP p, int ngroups, int m0_launch) {
   constexpr int NTB = 2, NW = 4, U = 8, MT = 1;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr size_t kHalfBytes = (size_t)NW * NTB * MT * 1024 + 32 * 4 + NTB * 32 * 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  const int half = HV == 2 ? (int)threadIdx.x >> 8 : 0;
+  unsigned char* smem = smem_all + half * kHalfBytes;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int KT = p.KT, NT = p.NT;
-  const int M = p.M - m0 < 16 ? p.M - m0 : 16;   // this launch: rows m0 .. m0 + M - 1 of the p.M live ones
+  const int m0 = m0_launch + 16 * half;
+  const int M = p.M - m0 < 16 ? (p.M - m0 > 0 ? p.M - m0 : 0) : 16;   // this wave group: rows m0 .. m0 + M - 1 (none: it only keeps the barriers)
   float4* red = (float4*)smem;                                   // [NW][NTB][64]
   float* rarr = (float*)(smem + (size_t)NW * NTB * MT * 1024);
   float* bestv = rarr + 32;                                      // [NTB][32] running best of this block
   int* besti = (int*)(bestv + NTB * 32);
   const int k8 = lane >> 4, em = lane & 15;
-  const int mrow = em < M ? em : M - 1;
+  const int mrow = em < M ? em : (M > 0 ? M - 1 : 0);
+  const int xrow = m0 + mrow < p.M ? m0 + mrow : p.M - 1;
   bf16x8 bf[U][3];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     int j = wave + u * NW;
     j = j < KT ? j : KT - 1;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) bf[u][s] = *(const bf16x8*)(p.XS + xs_off(j, s, k8, m0 + mrow, p.M));
+    for (int s = 0; s < 3; ++s) bf[u][s] = *(const bf16x8*)(p.XS + xs_off(j, s, k8, xrow, p.M));
   }
   uint4 w[U][NTB];
   auto load_w = [&](int g) {
@@ -1423,6 +1430,12 @@ int ensure_apart(smi_llm* L, size_t floats) {
   return SMI_OK;
 }
 
+// lm_head partial columns (= persistent blocks) finalize / the sampler read for M live rows
+int lm_blocks_for(const smi_llm* L, int M) {
+  if (L->KTh > 32) return L->lm_cap;
+  return M <= 16 ? L->lm_blocks : (L->lm_blocks < 256 ? L->lm_blocks : 256);
+}
+
 int segs_for(int ctx_bound) { return ctx_bound <= kAttnSeg ? 1 : (ctx_bound + kAttnSeg - 1) / kAttnSeg; }
 
 // attention (+ the segment merge when the context bound of the current call exceeds one segment)
@@ -1525,12 +1538,17 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       p.XS = L->xs_h;
       p.Y = logits ? logits : (L->do_sample ? L->logits : nullptr);
       p.V = c.vocab_size; p.pval = L->pval; p.pidx = L->pidx;
-      if (L->KTh <= 32) {   // persistent path (16 rows' operand resident in registers); 17..32 rows: two passes
+      if (L->KTh <= 32) {   // persistent path: 16 rows' operand resident in the registers of a 4-wave group
         const int ngroups = (L->NTlm + 1) / 2;
         const size_t lds = (size_t)4 * 2 * 1024 + 32 * 4 + 2 * 32 * 8;
-        for (int m0 = 0; m0 < M; m0 += 16) {
-          hipLaunchKernelGGL(k_lm<0>, dim3(L->lm_blocks), dim3(256), lds, st, p, ngroups, m0);
+        if (M <= 16) {
+          hipLaunchKernelGGL(k_lm<1>, dim3(L->lm_blocks), dim3(256), lds, st, p, ngroups, 0);
           SMI_LAUNCH_CHECK();
+        } else {              // two groups per block (32 rows per pass), one 8-wave block per CU
+          for (int m0 = 0; m0 < M; m0 += 32) {
+            hipLaunchKernelGGL(k_lm<2>, dim3(lm_blocks_for(L, M)), dim3(512), 2 * lds, st, p, ngroups, m0);
+            SMI_LAUNCH_CHECK();
+          }
         }
         return SMI_OK;
       }
@@ -1543,13 +1561,13 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
         SampleP sp;
         sp.logits = L->logits; sp.V = c.vocab_size; sp.top_k = L->top_k; sp.inv_temp = 1.0f / L->temperature;
         sp.top_p = L->top_p; sp.seed = L->seed; sp.step = L->step; sp.tok = L->tok;
-        sp.pval = L->pval; sp.nblk = L->KTh <= 32 ? L->lm_blocks : L->lm_cap;
+        sp.pval = L->pval; sp.nblk = lm_blocks_for(L, M);
         hipLaunchKernelGGL(k_sample, dim3(M), dim3(1024), 0, st, sp);
         SMI_LAUNCH_CHECK();
         f.tok = L->tok;
       }
       f.pval = L->pval; f.pidx = L->pidx; f.M = M; f.KT = L->KTh;
-      f.nblk = L->KTh <= 32 ? L->lm_blocks : L->lm_cap;
+      f.nblk = lm_blocks_for(L, M);
       f.rows = L->rows; f.hist = L->hist; f.count = L->count; f.finished = L->finished; f.step = L->step;
       f.eos = L->eos; f.Wlm = (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0); f.h = L->h; f.max_steps = L->max_steps;
       f.gamma0 = (const float*)sec(L, SMI_LLM_LN1, 0); f.xs = L->xs_h; f.sspart = L->sspart; f.npart = L->NTh * 4;
