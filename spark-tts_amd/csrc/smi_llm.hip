@@ -2084,6 +2084,16 @@ int smi_llm_all_done(smi_llm* L, int* all_done, void* stream) {
   return SMI_OK;
 }
 
+// Tokens emitted and eos flags of every KV slot in one round trip (continuous-batching drivers poll this every few steps)
+int smi_llm_status(smi_llm* L, int32_t* count_host, int32_t* finished_host, void* stream) {
+  SMI_REQUIRE(L && count_host && finished_host, "smi_llm_status: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  SMI_HIP(hipMemcpyAsync(count_host, L->count, kMaxRows * 4, hipMemcpyDeviceToHost, st));
+  SMI_HIP(hipMemcpyAsync(finished_host, L->finished, kMaxRows * 4, hipMemcpyDeviceToHost, st));
+  SMI_HIP(hipStreamSynchronize(st));
+  return SMI_OK;
+}
+
 int smi_llm_steps(smi_llm* L) {
   if (!L) return SMI_EINVAL;
   int32_t s = 0;

@@ -172,6 +172,14 @@ class SparkLLM:
                                                  C.byref(fin), self._stream()), "smi_llm_slot_tokens")
         return out[: n.value].tolist(), bool(fin.value)
 
+    def status(self):
+        """(tokens emitted, finished flag) per KV slot, as two int32 arrays of SMI_MAX_ROWS -- one device round trip."""
+        cnt = np.zeros(_lib.SMI_MAX_ROWS, dtype=np.int32)
+        fin = np.zeros(_lib.SMI_MAX_ROWS, dtype=np.int32)
+        _lib.check(self._lib.smi_llm_status(self._h, cnt.ctypes.data_as(C.POINTER(C.c_int32)), fin.ctypes.data_as(C.POINTER(C.c_int32)),
+                                            self._stream()), "smi_llm_status")
+        return cnt, fin
+
     def serve(self, requests, max_live: Optional[int] = None, decode_stride: int = 8):
         """In-flight batching driver: ``requests`` yields (key, prompt ids, max_new_tokens, eos id or None -- one eos for
         the session: the first request's); yields (key, new ids) as each sequence finishes.  New requests are admitted
@@ -182,19 +190,23 @@ class SparkLLM:
         pending = next(it, None)
         started = False
         while pending is not None or live:
-            while pending is not None and len(live) < max_live:
-                key, prompt, max_new, eos = pending
-                if not started:
-                    self.session_begin(eos)
-                    started = True
-                (slot,) = self.admit([list(prompt)])
-                live[slot] = (key, int(max_new))
+            batch = []
+            while pending is not None and len(live) + len(batch) < max_live:
+                batch.append(pending)
                 pending = next(it, None)
+            if batch:                      # all free slots are filled by ONE admission (one prefill launch sequence)
+                if not started:
+                    self.session_begin(batch[0][3])
+                    started = True
+                slots = self.admit([list(b[1]) for b in batch])
+                for slot, b in zip(slots, batch):
+                    live[slot] = (b[0], int(b[2]))
             self.decode(decode_stride)
+            cnt, fin = self.status()
             for slot in list(live):
                 key, max_new = live[slot]
-                toks, fin = self.slot_tokens(slot, max_new)
-                if fin or len(toks) >= max_new:
+                if fin[slot] or cnt[slot] >= max_new:
+                    toks, _ = self.slot_tokens(slot, max_new)
                     self.retire(slot)
                     del live[slot]
                     yield key, toks
