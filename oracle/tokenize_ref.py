@@ -10,7 +10,8 @@ this file against them.  NOT pinned: the mel spectrogram -- the reference calls
 ``torchaudio.transforms.MelSpectrogram`` (``bicodec.py:198-211``) and torchaudio is absent from this
 image, so ``mel_spectrogram`` below restates torchaudio's published algorithm (``torch.stft`` +
 slaney mel filterbank) with **parity unpinned** for that one function; everything downstream of the
-mel is pinned.
+mel is pinned.  (The test file also cross-checks it against ``transformers.audio_utils``, an
+independent third-party implementation of the same algorithm: a second opinion, not a pin.)
 
 State dict keys are the reference module tree's (weight-norm folded).
 """
