@@ -54,18 +54,19 @@ __device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erf
 // tile (large C, short T) instead of owning a 32-row output tile each.  CHG: a staged chunk holds
 // 32*CHG input channels (1-tap layers use 128 so a chunk carries enough MFMAs per barrier).  NC:
 // the staged row (tile * input stride + halo) is up to 64 * NC columns wide.
-template <int QB, bool KS, int CHG, int NC>
+template <int QB, bool KS, int CHG, int NC, bool WPF = false>
 __global__ __launch_bounds__(256) void k_conv(ConvP p) {
   constexpr int kCh = kChunk * CHG;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int QT = QB * 32;
-  const int b = blockIdx.z / p.S, phase = blockIdx.z - b * p.S;
-  const int q0 = blockIdx.x * QT;
+  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  const int b = bz / p.S, phase = bz - b * p.S;
+  const int q0 = bx * QT;
   const int len = p.lens[b];
   const int olen = p.olens ? p.olens[b] : len;
   if (q0 >= olen) return;
-  const int ct = KS ? blockIdx.y : blockIdx.y * 4 + wave;
+  const int ct = KS ? by : by * 4 + wave;
   const bool live = ct * 32 < p.Cout;
   const int ntap = p.ntaps[phase];
   const int groups = p.CinP >> 3;
@@ -110,6 +111,45 @@ __global__ __launch_bounds__(256) void k_conv(ConvP p) {
         if (lane + 64 * k < xw) lr[lane + 64 * k] = sreg[r][k];
     }
   };
+  if constexpr (KS && CHG == 4 && WPF) {
+    // One-tap layers with the channels split over the waves, launched with so few blocks that a SIMD holds one wave
+    // (short sequences: encoder FFNs, point-wise convs; with more blocks occupancy hides the latency and the extra
+    // registers only cost).  A
+    // wave's weights for a chunk are CHG float4 per lane; they are requested one chunk ahead together with the
+    // staged rows, so the L2 latency of both hides behind the previous chunk's MFMAs instead of sitting in front of
+    // every group of four.  Channels past CinP multiply zero weights (same accumulation order, same bits).
+    float4 wn[CHG];
+    auto wload = [&](int c0) {
+#pragma unroll
+      for (int g = 0; g < CHG; ++g) {
+        const int gi = (c0 >> 3) + wave * CHG + g;
+        wn[g] = (live && gi < groups) ? Wp[(long long)gi * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    stage_load(0);
+    wload(0);
+    const int col0 = p.halo_l + p.off[phase][0] + (lane & 31) * p.istr;
+    for (int c0 = 0; c0 < p.CinP; c0 += kCh) {
+      if (c0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stage_store();
+      float4 wc[CHG];
+#pragma unroll
+      for (int g = 0; g < CHG; ++g) wc[g] = wn[g];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (c0 + kCh < p.CinP) { stage_load(c0 + kCh); wload(c0 + kCh); }
+#pragma unroll
+      for (int g = 0; g < CHG; ++g) {
+        const float wa[4] = {wc[g].x, wc[g].y, wc[g].z, wc[g].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float* xr = lds + ((wave * CHG + g) * 8 + j * 2 + (lane >> 5)) * xw + col0;
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb)
+            acc[qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], xr[qb * 32 * p.istr], acc[qb], 0, 0, 0);
+        }
+      }
+    }
+  } else {
   stage_load(0);
   for (int c0 = 0; c0 < p.CinP; c0 += kCh) {
     if (c0) { if (KS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads(); }   // previous chunk fully read
@@ -136,6 +176,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvP p) {
     }
   }
 
+  }
   if (KS) {
     // fixed-order reduction of the four waves' partial tiles, then each wave finishes 4 of the 16 rows-groups
     __syncthreads();
@@ -417,7 +458,11 @@ int run_launch(const Launch& L, hipStream_t st) {
         hipLaunchKernelGGL(k_gemv1, L.grid, dim3(256), 0, st, L.cp);
       } else if (L.chg == 4) {      // 1-tap layers: 128-channel chunks, narrow rows
         if (L.ks) {
-          if (L.qb == 1) hipLaunchKernelGGL((k_conv<1, true, 4, 1>), L.grid, dim3(256), L.lds, st, L.cp);
+          // measured (profiles/README.md): pays up to about two blocks per CU, costs beyond (fewer waves fit)
+          const bool wpf = (long long)L.grid.x * L.grid.y * L.grid.z <= 512;
+          if (L.qb == 1 && wpf) hipLaunchKernelGGL((k_conv<1, true, 4, 1, true>), L.grid, dim3(256), L.lds, st, L.cp);
+          else if (L.qb == 1) hipLaunchKernelGGL((k_conv<1, true, 4, 1>), L.grid, dim3(256), L.lds, st, L.cp);
+          else if (wpf) hipLaunchKernelGGL((k_conv<2, true, 4, 1, true>), L.grid, dim3(256), L.lds, st, L.cp);
           else hipLaunchKernelGGL((k_conv<2, true, 4, 1>), L.grid, dim3(256), L.lds, st, L.cp);
         } else {
           if (L.qb == 1) hipLaunchKernelGGL((k_conv<1, false, 4, 1>), L.grid, dim3(256), L.lds, st, L.cp);
