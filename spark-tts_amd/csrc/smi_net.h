@@ -537,7 +537,10 @@ Launch make_conv_w(const std::string& name, const float* W, const float* bias,
   const int qb = (Lmax <= 32 || (blocks64 < 256 && getenv("SPARKMI_QB2") == nullptr)) ? 1 : 2;
   const int qt = qb * 32, nq = (Lmax + qt - 1) / qt;
   const long long blocks_cosplit = (long long)nq * ((cot + 3) / 4) * B * S;
-  L.ks = (blocks_cosplit < 512 || cot % 4 != 0) && Cin >= 8;
+  // (a partial last group of output tiles just idles its spare waves).  The choice depends on the call's shape
+  // (B, longest row): a row is independent of its neighbours and padding bit for bit, and equal to fp32
+  // re-association between calls of different shapes.
+  L.ks = blocks_cosplit < 512 && Cin >= 8;
   L.qb = qb;
   p.halo_l = g.halo_l;
   p.xw = (qt - 1) * istr + 1 + g.halo_l + g.halo_r;

@@ -33,3 +33,6 @@ for n, ms, f in rows:
     g = groups.setdefault(key, [0, 0.0, 0.0]); g[0] += 1; g[1] += ms; g[2] += f
 for k, (c, ms, f) in sorted(groups.items(), key=lambda kv: -kv[1][1])[:24]:
     print(f"{ms:8.3f} ms  x{c:3d}  {f / ms / 1e9 if ms else 0:7.1f} TF/s  {k}")
+if os.environ.get("VOC_PROFILE_ALL"):
+    for n, ms, f in rows:
+        print(f"{ms:8.3f} ms {f / ms / 1e9 if ms else 0:7.1f} TF/s  {n}")
