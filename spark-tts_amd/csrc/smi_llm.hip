@@ -448,20 +448,19 @@ __global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
 #pragma unroll
   for (int i = 0; i < NTW; ++i) { const int nt = ((int)blockIdx.x * 4 + wave) * NTW + i; nts[i] = nt < NT ? nt : NT - 1; }
 
-  uint4 sreg[PIECES / 256];
-  auto stage_load = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < PIECES / 256; ++i) {
-      const int q = tid + 256 * i;                       // [s][k8][row]
-      int row = m0 + (q & (ROWS - 1));
-      row = row < M ? row : M - 1;
-      sreg[i] = *(const uint4*)(p.XS + xs_off(kt, q / (4 * ROWS), (q / ROWS) & 3, row, M));
-    }
+  // The six staged pieces are named registers, not an array: as `uint4 sreg[6]` the compiler left them in scratch
+  // memory (ScratchSize 112), which put a wait for the global loads right behind their issue -- in front of the k
+  // tile's MFMAs instead of behind them.
+  static_assert(PIECES / 256 == 6, "six staged pieces per thread");
+  uint4 sr0, sr1, sr2, sr3, sr4, sr5;
+  auto piece = [&](int kt, int i) -> uint4 {
+    const int q = tid + 256 * i;                         // [s][k8][row]
+    int row = m0 + (q & (ROWS - 1));
+    row = row < M ? row : M - 1;
+    return *(const uint4*)(p.XS + xs_off(kt, q / (4 * ROWS), (q / ROWS) & 3, row, M));
   };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < PIECES / 256; ++i) Bs[buf * PIECES + tid + 256 * i] = sreg[i];
-  };
+#define stage_load(kt_) do { sr0 = piece((kt_), 0); sr1 = piece((kt_), 1); sr2 = piece((kt_), 2); sr3 = piece((kt_), 3); sr4 = piece((kt_), 4); sr5 = piece((kt_), 5); } while (0)
+#define stage_store(buf_) do { uint4* d_ = Bs + (buf_) * PIECES + tid; d_[0] = sr0; d_[256] = sr1; d_[512] = sr2; d_[768] = sr3; d_[1024] = sr4; d_[1280] = sr5; } while (0)
   stage_load(0);
   if (PRO == PRO_NORM) {
     for (int r = wave; r < ROWS; r += 4) {
@@ -480,46 +479,48 @@ __global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
     for (int b = 0; b < MTB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   stage_store(0);
   __syncthreads();
-  // weight tiles run two k tiles ahead of the MFMAs (HBM / L2 latency hidden behind 96 MFMAs per wave)
-  uint4 wA[NTW], wB[NTW], wC[NTW];
-#pragma unroll
-  for (int i = 0; i < NTW; ++i) {
-    wA[i] = p.W[((size_t)nts[i] * KT + 0) * 64 + lane];
-    wB[i] = p.W[((size_t)nts[i] * KT + (1 < KT ? 1 : KT - 1)) * 64 + lane];
+  // Weight tiles run two k tiles ahead of the MFMAs (HBM / L2 latency hidden behind 96 MFMAs per wave).  Three
+  // register sets take the roles (in use, next, in flight) in turn -- the k loop is unrolled by three so that no
+  // set is ever copied: with `wA = wB; wB = wC` at the loop end the compiler waited for the loads it had just issued.
+  uint4 w0[NTW], w1[NTW], w2[NTW];
+#define wload(w_, kt_) do { const int kc_ = (kt_) < KT ? (kt_) : KT - 1; _Pragma("unroll") for (int i = 0; i < NTW; ++i) (w_)[i] = p.W[((size_t)nts[i] * KT + kc_) * 64 + lane]; } while (0)
+#define ktile(kt_, wuse_, wld_) do { \
+    const int kq_ = (kt_); \
+    wload(wld_, kq_ + 2); \
+    if (kq_ + 1 < KT) stage_load(kq_ + 1);               /* in flight during this tile's MFMAs */ \
+    const uint4* Bb = Bs + (kq_ & 1) * PIECES; \
+    /* operand pieces of m-tile mt + 1 are read from LDS while the MFMAs of m-tile mt run */ \
+    uint4 bq[2][3]; \
+    _Pragma("unroll") for (int s = 0; s < 3; ++s) bq[0][s] = Bb[(s * 4 + k8) * ROWS + em]; \
+    _Pragma("unroll") for (int mt = 0; mt < MTB; ++mt) { \
+      if (mt + 1 < MTB) { \
+        _Pragma("unroll") for (int s = 0; s < 3; ++s) bq[(mt + 1) & 1][s] = Bb[(s * 4 + k8) * ROWS + (mt + 1) * 16 + em]; \
+      } \
+      const bf16x8 b0 = __builtin_bit_cast(bf16x8, bq[mt & 1][0]), b1 = __builtin_bit_cast(bf16x8, bq[mt & 1][1]), \
+                   b2 = __builtin_bit_cast(bf16x8, bq[mt & 1][2]); \
+      _Pragma("unroll") for (int i = 0; i < NTW; ++i) { \
+        const bf16x8 a = __builtin_bit_cast(bf16x8, (wuse_)[i]); \
+        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2, acc[i][mt], 0, 0, 0); \
+        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[i][mt], 0, 0, 0); \
+        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[i][mt], 0, 0, 0); \
+      } \
+    } \
+    if (kq_ + 1 < KT) { \
+      stage_store((kq_ & 1) ^ 1);                        /* the other buffer was last read two barriers ago */ \
+      __syncthreads(); \
+    } \
+  } while (0)
+  wload(w0, 0);
+  wload(w1, 1);
+  for (int kt = 0; kt < KT; kt += 3) {
+    ktile(kt, w0, w2);
+    if (kt + 1 < KT) ktile(kt + 1, w1, w0);
+    if (kt + 2 < KT) ktile(kt + 2, w2, w1);
   }
-  for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) wC[i] = p.W[((size_t)nts[i] * KT + (kt + 2 < KT ? kt + 2 : KT - 1)) * 64 + lane];
-    if (kt + 1 < KT) stage_load(kt + 1);                 // in flight during this tile's MFMAs
-    const uint4* Bb = Bs + buf * PIECES;
-    // operand pieces of m-tile mt + 1 are read from LDS while the six MFMAs of m-tile mt run
-    uint4 bq[2][3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) bq[0][s] = Bb[(s * 4 + k8) * ROWS + em];
-#pragma unroll
-    for (int mt = 0; mt < MTB; ++mt) {
-      if (mt + 1 < MTB) {
-#pragma unroll
-        for (int s = 0; s < 3; ++s) bq[(mt + 1) & 1][s] = Bb[(s * 4 + k8) * ROWS + (mt + 1) * 16 + em];
-      }
-      const bf16x8 b0 = __builtin_bit_cast(bf16x8, bq[mt & 1][0]), b1 = __builtin_bit_cast(bf16x8, bq[mt & 1][1]),
-                   b2 = __builtin_bit_cast(bf16x8, bq[mt & 1][2]);
-#pragma unroll
-      for (int i = 0; i < NTW; ++i) {
-        const bf16x8 a = __builtin_bit_cast(bf16x8, wA[i]);
-        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2, acc[i][mt], 0, 0, 0);
-        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[i][mt], 0, 0, 0);
-        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[i][mt], 0, 0, 0);
-      }
-    }
-    if (kt + 1 < KT) {
-      stage_store(buf ^ 1);                              // the other buffer was last read two barriers ago
-      __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) { wA[i] = wB[i]; wB[i] = wC[i]; }
-  }
+#undef ktile
+#undef wload
+#undef stage_load
+#undef stage_store
   // ---- epilogue (same arithmetic as k_gemm's)
   const int N = NT * 16;
 #pragma unroll
@@ -924,6 +925,118 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
     *(uint16_t*)(p.xs_out + ob + pl2) = (uint16_t)mi;
     *(uint16_t*)(p.xs_out + ob + 2 * pl2) = (uint16_t)lo;
   }
+}
+
+// Prompt rows (prefill of more than one chunk): one WAVE per (row, head), eight consecutive rows of one head per
+// block.  A prompt row's context is short on average (half the prompt) and thousands of rows arrive together, so the
+// decode kernel's shape -- eight waves and two barriers around one 256-token chunk -- is mostly idle lanes and merge
+// overhead there (199 us per layer for 32 x 127 rows).  Here a wave walks its row's keys 32 (bf16 KV) at a time
+// with the same per-token arithmetic, keeps its own running max, and merges its token streams through a private LDS
+// slice; nothing is shared between waves, so there is no barrier and no context segmentation.  Neighbouring rows of
+// a sequence read the same K/V lines out of L1/L2.
+template <int KVF32>
+__global__ __launch_bounds__(kAttnWaves * 64) void k_attn_pf(AttnP p) {
+  constexpr int LPT = KVF32 ? 16 : 8;
+  constexpr int DPL = kHeadDim / LPT;
+  constexpr int TPW = 64 / LPT;
+  constexpr int UNR = 4;
+  constexpr float NEG = -1e30f;
+  constexpr float LOG2E = 1.4426950408889634f;
+  __shared__ __attribute__((aligned(16))) float so[kAttnWaves][TPW][kHeadDim];
+  __shared__ float sl[kAttnWaves][TPW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int head = blockIdx.y, m = (int)blockIdx.x * kAttnWaves + wave;
+  if (m >= p.M) return;   // wave-uniform; the kernel has no barrier
+  const int tl = lane / LPT, dl = lane % LPT;
+  const RowDesc rd = p.rows[m];
+  const int kvh = head / p.group;
+  const size_t rowbase = ((size_t)rd.slot * p.n_kv + kvh) * p.max_pos;
+  const int ctx = rd.pos + 1;
+  float qv[DPL];
+  {
+    const float* qp = p.q + (size_t)m * p.q_dim + head * kHeadDim + dl * DPL;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) qv[i] = qp[i] * 0.125f;  // head_dim^-0.5, exact
+  }
+  float m_run = NEG, lrun = 0.f, o[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) o[i] = 0.f;
+  for (int c0 = 0; c0 < ctx; c0 += TPW * UNR) {
+    uint4 kr[UNR], vr[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int t = c0 + u * TPW + tl;
+      const size_t off = (rowbase + (t < ctx ? t : ctx - 1)) * kHeadDim + dl * DPL;
+      if (KVF32) {
+        kr[u] = *(const uint4*)((const float*)p.kcache + off);
+        vr[u] = *(const uint4*)((const float*)p.vcache + off);
+      } else {
+        kr[u] = *(const uint4*)((const uint16_t*)p.kcache + off);
+        vr[u] = *(const uint4*)((const uint16_t*)p.vcache + off);
+      }
+    }
+    float sc[UNR];
+    float lmax = NEG;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const uint32_t ku[4] = {kr[u].x, kr[u].y, kr[u].z, kr[u].w};
+      float d = 0.f;
+      if (KVF32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d += qv[i % DPL] * __uint_as_float(ku[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          d += qv[(2 * i) % DPL] * __uint_as_float(ku[i] << 16);
+          d += qv[(2 * i + 1) % DPL] * __uint_as_float(ku[i] & 0xffff0000u);
+        }
+      }
+      d = KVF32 ? smi_sum16(d) : smi_sum8(d);
+      sc[u] = (c0 + u * TPW + tl < ctx) ? d : NEG;
+      lmax = fmaxf(lmax, sc[u]);
+    }
+    lmax = fmaxf(lmax, smi_dpp<0x128>(lmax));   // row_ror:8
+    const float wm = fmaxf(fmaxf(smi_readlane(lmax, 0), smi_readlane(lmax, 16)), fmaxf(smi_readlane(lmax, 32), smi_readlane(lmax, 48)));
+    const float mn = fmaxf(m_run, wm);
+    const float a = exp2f((m_run - mn) * LOG2E);
+    lrun *= a;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) o[i] *= a;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const float e = sc[u] > 0.5f * NEG ? exp2f((sc[u] - mn) * LOG2E) : 0.f;
+      const uint32_t vu[4] = {vr[u].x, vr[u].y, vr[u].z, vr[u].w};
+      lrun += e;
+      if (KVF32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i % DPL] += e * __uint_as_float(vu[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o[(2 * i) % DPL] += e * __uint_as_float(vu[i] << 16);
+          o[(2 * i + 1) % DPL] += e * __uint_as_float(vu[i] & 0xffff0000u);
+        }
+      }
+    }
+    m_run = mn;
+  }
+  // the wave's token streams are all at scale exp(-m_run): plain sums in fixed order
+#pragma unroll
+  for (int i = 0; i < DPL; i += 4)
+    *(float4*)&so[wave][tl][dl * DPL + i] = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
+  if (dl == 0) sl[wave][tl] = lrun;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes have landed
+  float O = 0.f, Ls = 0.f;
+#pragma unroll
+  for (int g = 0; g < TPW; ++g) { O += so[wave][g][lane]; Ls += sl[wave][g]; }
+  uint32_t hi, mi, lo;
+  split3(O / Ls, hi, mi, lo);
+  const int k = head * kHeadDim + lane;
+  const size_t ob = xs_off(k >> 5, 0, (k >> 3) & 3, m, p.M) + (k & 7) * 2;
+  const size_t pl2 = (size_t)4 * p.M * 16;
+  *(uint16_t*)(p.xs_out + ob) = (uint16_t)hi;
+  *(uint16_t*)(p.xs_out + ob + pl2) = (uint16_t)mi;
+  *(uint16_t*)(p.xs_out + ob + 2 * pl2) = (uint16_t)lo;
 }
 
 // Combines a row's context segments in order (a row with one segment reproduces the unsplit result bit for bit:
@@ -1617,7 +1730,14 @@ int launch_layers_big(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
     a.q = L->bq; a.kcache = p.kcache; a.vcache = p.vcache; a.rows = rows; a.xs_out = L->bxs_attn; a.M = M;
     a.q_dim = L->Q; a.n_kv = c.num_kv_heads; a.group = c.num_heads / c.num_kv_heads; a.max_pos = c.max_positions;
     a.n_heads = c.num_heads; a.slot_is_row = 0;
-    if ((rc = c.kv_dtype ? launch_attn<1>(L, a, 0, st) : launch_attn<0>(L, a, 0, st))) return rc;
+    if (L->tune2 & 1024) {   // SPARKMI_TUNE2 bit 1024: the decode attention kernel per prompt row (the path before k_attn_pf)
+      if ((rc = c.kv_dtype ? launch_attn<1>(L, a, 0, st) : launch_attn<0>(L, a, 0, st))) return rc;
+    } else {
+      const dim3 ag((unsigned)((M + kAttnWaves - 1) / kAttnWaves), (unsigned)c.num_heads);
+      if (c.kv_dtype) hipLaunchKernelGGL((k_attn_pf<1>), ag, dim3(kAttnWaves * 64), 0, st, a);
+      else hipLaunchKernelGGL((k_attn_pf<0>), ag, dim3(kAttnWaves * 64), 0, st, a);
+      SMI_LAUNCH_CHECK();
+    }
     // o_proj
     GemmP o;
     memset(&o, 0, sizeof(o));
