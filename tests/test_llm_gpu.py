@@ -314,6 +314,11 @@ def test_cache_boundaries_and_long_contexts(tiny):
     got = llm.generate_ids([vlong, long_prompt[:30]], 40)
     assert got[0] == want and got[1] == ref.generate_greedy(long_prompt[:30], 40)
     assert llm.generate_ids([vlong], 40)[0] == want
+    # a prompt that is itself longer than a segment: the prefill attention (one wave per row and head, k_attn_pf)
+    # walks the whole context in one loop, and decode then starts on a two-segment context
+    xlong = rng.integers(0, cfg.vocab_size, size=1300).tolist()
+    llm = _llm(cfg, syn, max_slots=1, max_positions=1320)
+    assert llm.generate_ids([xlong], 12)[0] == ref.generate_greedy(xlong, 12)
 
 
 def test_sixty_four_concurrent_sequences_equal_single_runs(tiny):
