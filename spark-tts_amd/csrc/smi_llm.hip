@@ -1194,13 +1194,26 @@ __global__ __launch_bounds__(1024) void k_sample(SampleP p) {
   if (tid == 0) { s_cnt = 0; s_thr = -INFINITY; }
   __syncthreads();
   if (p.pval && p.nblk <= kCandCap && p.nblk >= p.top_k) {
-    const float mine = tid < p.nblk ? p.pval[(size_t)m * p.nblk + tid] : -INFINITY;
-    cv[tid] = mine;
-    __syncthreads();
-    if (tid < p.nblk) {
-      int r = 0;
-      for (int j = 0; j < p.nblk; ++j) r += (cv[j] > mine) || (cv[j] == mine && j < tid);
-      if (r == p.top_k - 1) s_thr = mine;
+    // top_k-th largest block maximum, by ONE wave: each lane holds up to 16 of the (<= 1024) maxima as order-preserving
+    // keys and the answer is built bit by bit from ballots (K = max{x : #{keys >= x} >= top_k}) -- no LDS, no barrier.
+    // (An all-pairs rank count over the block took 10 us of this kernel: 512 x 512 compares on one CU.)
+    if (tid < 64) {
+      uint32_t key[kCandCap / 64];
+#pragma unroll
+      for (int i = 0; i < kCandCap / 64; ++i) {
+        const int j = tid + 64 * i;
+        key[i] = j < p.nblk ? sortable(p.pval[(size_t)m * p.nblk + j]) : 0u;   // 0 sorts below every float
+      }
+      uint32_t K = 0;
+      for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t t = K | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < kCandCap / 64; ++i)
+          if (i * 64 < p.nblk) c += __popcll(__ballot(key[i] >= t));   // uniform: slots beyond nblk hold no key
+        if (c >= p.top_k) K = t;   // wave-uniform
+      }
+      if (tid == 0) s_thr = __uint_as_float((K & 0x80000000u) ? (K ^ 0x80000000u) : ~K);
     }
     __syncthreads();
   }
@@ -1209,16 +1222,29 @@ __global__ __launch_bounds__(1024) void k_sample(SampleP p) {
   if (thr0 > -INFINITY) {
     const bool vec = (p.V & 3) == 0;
     if (vec) {
+      // eight 16-byte loads per thread in flight together: with one load per trip the pass over the row (41 trips) was a
+      // chain of 41 memory round trips, ~33 us of the kernel's 38
       const float4* l4 = (const float4*)lg;
-      for (int i = tid; i < p.V / 4; i += 1024) {
-        const float4 v = l4[i];
-        const float a[4] = {v.x, v.y, v.z, v.w};
+      const int n4 = p.V / 4;
+      constexpr int UL = 8;
+      for (int base = 0; base < n4; base += 1024 * UL) {
+        float4 v[UL];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (a[e] >= thr0) {
-            const unsigned pos = atomicAdd(&s_cnt, 1u);
-            if (pos < kCandCap) { cv[pos] = a[e]; ci[pos] = 4 * i + e; }
-          }
+        for (int u = 0; u < UL; ++u) {
+          const int i = base + u * 1024 + tid;
+          v[u] = i < n4 ? l4[i] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        }
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+          const int i = base + u * 1024 + tid;
+          const float a[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (a[e] >= thr0) {
+              const unsigned pos = atomicAdd(&s_cnt, 1u);
+              if (pos < kCandCap) { cv[pos] = a[e]; ci[pos] = 4 * i + e; }
+            }
+        }
       }
     } else {
       for (int i = tid; i < p.V; i += 1024) {
@@ -1256,12 +1282,19 @@ __global__ __launch_bounds__(1024) void k_sample(SampleP p) {
     if (r < kSampleCap) { sv[r] = v; si[r] = ix; }
   }
   __syncthreads();
+  {   // softmax numerators of the top-k of logits / T (fp32, like the warpers), one per thread
+    const int k = n < p.top_k ? n : p.top_k;
+    float e = 0.f;
+    if (tid < k) e = expf(sv[tid] * p.inv_temp - sv[0] * p.inv_temp);
+    __syncthreads();   // cv (the candidates) has been read by the rank sort
+    if (tid < k) cv[tid] = e;
+    __syncthreads();
+  }
   if (tid == 0) {
     const int k = n < p.top_k ? n : p.top_k;
-    // softmax over the top-k of logits / T (fp32, like the warpers), then the nucleus cut
-    const float mx = sv[0] * p.inv_temp;
+    // their sum in index order, then the nucleus cut
     float sum = 0.f;
-    for (int i = 0; i < k; ++i) { cv[i] = expf(sv[i] * p.inv_temp - mx); sum += cv[i]; }
+    for (int i = 0; i < k; ++i) sum += cv[i];
     float tail = 0.f;
     int keep = 1;
     // ascending cumulative probability: token i is dropped when sum_{j>=i} p_j <= 1 - top_p

@@ -4,7 +4,8 @@ reference calls it (``cli/SparkTTS.py:197-204``), running on the HIP kernels of 
 ``generate`` keeps the HF call shape (``input_ids`` (B, P), ``attention_mask``,
 ``max_new_tokens``, ``do_sample``, ``eos_token_id``, ``pad_token_id``) and returns (B, P + N)
 ids, prompt included, exactly like the reference expects when it slices the prompt off at
-``cli/SparkTTS.py:207-210``.  Greedy (``do_sample=False``) only in this round.
+``cli/SparkTTS.py:207-210``.  Greedy by default; ``do_sample=True`` runs the reference's temperature → top-k →
+top-p → multinomial chain on the device (``k_sample``).
 """
 from __future__ import annotations
 
