@@ -1123,6 +1123,8 @@ struct SampleP {
   int* tok;             // [kMaxRows] sampled token per row
   const float* pval;    // [M][nblk] the lm_head blocks' best logits (a bound for the top-k threshold) or null
   int nblk;
+  // candidates at or above the bound, collected by k_sample_scan: [kMaxRows][kCandCap] values / indices, [kMaxRows] counts
+  float* cand_v; int* cand_i; unsigned int* cand_n;
 };
 
 __device__ __forceinline__ uint32_t sortable(float f) {
@@ -1179,10 +1181,74 @@ __device__ uint32_t radix_kth_key(const float* lg, int V, int top_k, unsigned in
   return *s_prefix;
 }
 
-// One block per row.  The top_k-th largest of the lm_head blocks' maxima is a lower bound of the top_k-th
-// largest logit (those maxima are top_k distinct logits at or above it), so ONE pass over the row collects a
-// short candidate list that contains the whole top-k; the candidates are rank-sorted exactly (value descending,
-// index ascending on ties), then temperature -> top-k -> top-p -> multinomial on one thread.
+constexpr int kScanBlocks = 16;  // blocks per row in k_sample_scan
+
+// The top_k-th largest of the lm_head blocks' maxima is a lower bound of the top_k-th largest logit (those maxima are
+// top_k distinct logits at or above it), so ONE pass over the row collects a short candidate list that contains the
+// whole top-k.  kScanBlocks blocks per row share that pass (one CU pulls a 664 KB row at ~150 GB/s: 25 us for a
+// single block); each finds the bound itself and appends its candidates to the row's global list.  The list order
+// depends on the race, the result does not: k_sample rank-sorts the list by (value, index).
+__global__ __launch_bounds__(256) void k_sample_scan(SampleP p) {
+  __shared__ float s_thr;
+  const int m = blockIdx.y, tid = threadIdx.x;
+  if (!(p.pval && p.nblk <= kCandCap && p.nblk >= p.top_k)) return;   // no usable bound: k_sample selects by radix
+  // the bound, by ONE wave: each lane holds up to 16 of the (<= 1024) maxima as order-preserving keys and the answer is
+  // built bit by bit from ballots (K = max{x : #{keys >= x} >= top_k}) -- no LDS, no barrier
+  if (tid < 64) {
+    uint32_t key[kCandCap / 64];
+#pragma unroll
+    for (int i = 0; i < kCandCap / 64; ++i) {
+      const int j = tid + 64 * i;
+      key[i] = j < p.nblk ? sortable(p.pval[(size_t)m * p.nblk + j]) : 0u;   // 0 sorts below every float
+    }
+    uint32_t K = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+      const uint32_t t = K | (1u << bit);
+      int c = 0;
+#pragma unroll
+      for (int i = 0; i < kCandCap / 64; ++i)
+        if (i * 64 < p.nblk) c += __popcll(__ballot(key[i] >= t));   // uniform: slots beyond nblk hold no key
+      if (c >= p.top_k) K = t;   // wave-uniform
+    }
+    if (tid == 0) s_thr = __uint_as_float((K & 0x80000000u) ? (K ^ 0x80000000u) : ~K);
+  }
+  __syncthreads();
+  const float thr = s_thr;
+  const float* lg = p.logits + (size_t)m * p.V;
+  auto take = [&](float v, int idx) {
+    if (v >= thr) {
+      const unsigned pos = atomicAdd(&p.cand_n[m], 1u);
+      if (pos < (unsigned)kCandCap) { p.cand_v[(size_t)m * kCandCap + pos] = v; p.cand_i[(size_t)m * kCandCap + pos] = idx; }
+    }
+  };
+  if ((p.V & 3) == 0) {
+    const float4* l4 = (const float4*)lg;
+    const int n4 = p.V / 4, per = (n4 + kScanBlocks - 1) / kScanBlocks;
+    const int lo = (int)blockIdx.x * per, hi = lo + per < n4 ? lo + per : n4;
+    constexpr int UL = 4;   // loads in flight per thread
+    for (int base = lo; base < hi; base += 256 * UL) {
+      float4 v[UL];
+#pragma unroll
+      for (int u = 0; u < UL; ++u) {
+        const int i = base + u * 256 + tid;
+        v[u] = i < hi ? l4[i] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      }
+#pragma unroll
+      for (int u = 0; u < UL; ++u) {
+        const int i = base + u * 256 + tid;
+        take(v[u].x, 4 * i); take(v[u].y, 4 * i + 1); take(v[u].z, 4 * i + 2); take(v[u].w, 4 * i + 3);
+      }
+    }
+  } else {
+    const int per = (p.V + kScanBlocks - 1) / kScanBlocks;
+    const int lo = (int)blockIdx.x * per, hi = lo + per < p.V ? lo + per : p.V;
+    for (int i = lo + tid; i < hi; i += 256) take(lg[i], i);
+  }
+}
+
+// One block per row: takes the candidates k_sample_scan collected (without a usable bound, or with more than kCandCap of
+// them, it selects the top_k-th key exactly by radix and walks the row itself); the candidates are rank-sorted exactly
+// (value descending, index ascending on ties), then temperature -> top-k -> top-p -> multinomial.
 __global__ __launch_bounds__(1024) void k_sample(SampleP p) {
   __shared__ unsigned int hist[256];
   __shared__ unsigned int s_prefix, s_need, s_cnt;
@@ -1193,70 +1259,18 @@ __global__ __launch_bounds__(1024) void k_sample(SampleP p) {
   const float* lg = p.logits + (size_t)m * p.V;
   if (tid == 0) { s_cnt = 0; s_thr = -INFINITY; }
   __syncthreads();
-  if (p.pval && p.nblk <= kCandCap && p.nblk >= p.top_k) {
-    // top_k-th largest block maximum, by ONE wave: each lane holds up to 16 of the (<= 1024) maxima as order-preserving
-    // keys and the answer is built bit by bit from ballots (K = max{x : #{keys >= x} >= top_k}) -- no LDS, no barrier.
-    // (An all-pairs rank count over the block took 10 us of this kernel: 512 x 512 compares on one CU.)
-    if (tid < 64) {
-      uint32_t key[kCandCap / 64];
-#pragma unroll
-      for (int i = 0; i < kCandCap / 64; ++i) {
-        const int j = tid + 64 * i;
-        key[i] = j < p.nblk ? sortable(p.pval[(size_t)m * p.nblk + j]) : 0u;   // 0 sorts below every float
-      }
-      uint32_t K = 0;
-      for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t t = K | (1u << bit);
-        int c = 0;
-#pragma unroll
-        for (int i = 0; i < kCandCap / 64; ++i)
-          if (i * 64 < p.nblk) c += __popcll(__ballot(key[i] >= t));   // uniform: slots beyond nblk hold no key
-        if (c >= p.top_k) K = t;   // wave-uniform
-      }
-      if (tid == 0) s_thr = __uint_as_float((K & 0x80000000u) ? (K ^ 0x80000000u) : ~K);
+  const bool bound_ok = p.pval && p.nblk <= kCandCap && p.nblk >= p.top_k;   // the condition k_sample_scan ran under
+  if (bound_ok) {
+    if (tid == 0) { s_cnt = p.cand_n[m]; p.cand_n[m] = 0; s_thr = 0.f; }   // the counter is left at zero for the next step
+    __syncthreads();
+    const unsigned ng = s_cnt;
+    if (ng <= (unsigned)kCandCap && tid < (int)ng) {
+      cv[tid] = p.cand_v[(size_t)m * kCandCap + tid];
+      ci[tid] = p.cand_i[(size_t)m * kCandCap + tid];
     }
     __syncthreads();
   }
   const float thr0 = s_thr;
-  __syncthreads();   // cv is reused for the candidates
-  if (thr0 > -INFINITY) {
-    const bool vec = (p.V & 3) == 0;
-    if (vec) {
-      // eight 16-byte loads per thread in flight together: with one load per trip the pass over the row (41 trips) was a
-      // chain of 41 memory round trips, ~33 us of the kernel's 38
-      const float4* l4 = (const float4*)lg;
-      const int n4 = p.V / 4;
-      constexpr int UL = 8;
-      for (int base = 0; base < n4; base += 1024 * UL) {
-        float4 v[UL];
-#pragma unroll
-        for (int u = 0; u < UL; ++u) {
-          const int i = base + u * 1024 + tid;
-          v[u] = i < n4 ? l4[i] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        }
-#pragma unroll
-        for (int u = 0; u < UL; ++u) {
-          const int i = base + u * 1024 + tid;
-          const float a[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (a[e] >= thr0) {
-              const unsigned pos = atomicAdd(&s_cnt, 1u);
-              if (pos < kCandCap) { cv[pos] = a[e]; ci[pos] = 4 * i + e; }
-            }
-        }
-      }
-    } else {
-      for (int i = tid; i < p.V; i += 1024) {
-        const float v = lg[i];
-        if (v >= thr0) {
-          const unsigned pos = atomicAdd(&s_cnt, 1u);
-          if (pos < kCandCap) { cv[pos] = v; ci[pos] = i; }
-        }
-      }
-    }
-    __syncthreads();
-  }
   if (thr0 == -INFINITY || s_cnt > (unsigned)kCandCap) {
     // no usable bound (or a pathological row with > 1024 logits above it): exact radix selection of the k-th key
     __syncthreads();
@@ -1290,29 +1304,61 @@ __global__ __launch_bounds__(1024) void k_sample(SampleP p) {
     if (tid < k) cv[tid] = e;
     __syncthreads();
   }
-  if (tid == 0) {
+  // Nucleus cut and multinomial draw on ONE wave, four consecutive ranks per lane (top_k <= kSampleCap = 256): sums, suffix
+  // sums and prefix sums come from shuffles instead of four serial loops with a division each on one thread (15 us).
+  if (tid < 64) {
+    static_assert(kSampleCap == 256, "four ranks per lane");
     const int k = n < p.top_k ? n : p.top_k;
-    // their sum in index order, then the nucleus cut
-    float sum = 0.f;
-    for (int i = 0; i < k; ++i) sum += cv[i];
-    float tail = 0.f;
-    int keep = 1;
-    // ascending cumulative probability: token i is dropped when sum_{j>=i} p_j <= 1 - top_p
-    for (int i = k - 1; i >= 1; --i) {
-      tail += cv[i] / sum;
-      if (tail > 1.0f - p.top_p) { keep = i + 1; break; }
+    const int i0 = tid * 4;
+    float c[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c[e] = i0 + e < k ? cv[i0 + e] : 0.f;
+    const float sum = smi_wave_sum((c[0] + c[1]) + (c[2] + c[3]));
+    // token i is dropped when the probability mass from rank i on, sum_{j >= i} p_j, is <= 1 - top_p
+    float sfx[4];
+    sfx[3] = c[3] / sum;
+    sfx[2] = c[2] / sum + sfx[3];
+    sfx[1] = c[1] / sum + sfx[2];
+    sfx[0] = c[0] / sum + sfx[1];
+    float t = sfx[0];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const float v = __shfl_down(t, d, 64);
+      if (tid + d < 64) t += v;
     }
-    float ksum = 0.f;
-    for (int i = 0; i < keep; ++i) ksum += cv[i];
+    float above = __shfl_down(t, 1, 64);   // mass of the lanes after this one
+    if (tid == 63) above = 0.f;
+    int best = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (i0 + e >= 1 && i0 + e < k && sfx[e] + above > 1.0f - p.top_p) best = i0 + e;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_xor(best, d, 64); best = v > best ? v : best; }
+    const int keep = best + 1;   // rank 0 always stays
+    // inverse-CDF draw over the kept ranks
+    float pre[4];
+    pre[0] = i0 < keep ? c[0] : 0.f;
+    pre[1] = pre[0] + (i0 + 1 < keep ? c[1] : 0.f);
+    pre[2] = pre[1] + (i0 + 2 < keep ? c[2] : 0.f);
+    pre[3] = pre[2] + (i0 + 3 < keep ? c[3] : 0.f);
+    float q = pre[3];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const float v = __shfl_up(q, d, 64);
+      if (tid >= d) q += v;
+    }
+    const float ksum = __shfl(q, 63, 64);
+    float before = __shfl_up(q, 1, 64);
+    if (tid == 0) before = 0.f;
     const uint32_t r = philox_u32(p.seed, (uint32_t)*p.step, (uint32_t)m);
     const float u = (float)(r >> 8) * (1.0f / 16777216.0f) * ksum;
-    float acc = 0.f;
     int pick = keep - 1;
-    for (int i = 0; i < keep; ++i) {
-      acc += cv[i];
-      if (u < acc) { pick = i; break; }
-    }
-    p.tok[m] = si[pick];
+#pragma unroll
+    for (int e = 3; e >= 0; --e)
+      if (i0 + e < keep && u < before + pre[e]) pick = i0 + e;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_xor(pick, d, 64); pick = v < pick ? v : pick; }
+    if (tid == 0) p.tok[m] = si[pick];
   }
 }
 
@@ -1474,6 +1520,7 @@ struct smi_llm {
   // sampling state (smi_llm_set_sampling)
   int do_sample, top_k; float temperature, top_p; unsigned long long seed;
   float* logits; int* tok;
+  float* cand_v; int* cand_i; unsigned int* cand_n;   // sampler candidate lists
   unsigned long long* stamps; int stamps_on;
   int max_steps;
   int tune[4];   // SPARKMI_TUNE block-shape selectors (diagnostics)
@@ -1708,6 +1755,9 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
         sp.logits = L->logits; sp.V = c.vocab_size; sp.top_k = L->top_k; sp.inv_temp = 1.0f / L->temperature;
         sp.top_p = L->top_p; sp.seed = L->seed; sp.step = L->step; sp.tok = L->tok;
         sp.pval = L->pval; sp.nblk = lm_blocks_for(L, M);
+        sp.cand_v = L->cand_v; sp.cand_i = L->cand_i; sp.cand_n = L->cand_n;
+        hipLaunchKernelGGL(k_sample_scan, dim3(kScanBlocks, M), dim3(256), 0, st, sp);
+        SMI_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_sample, dim3(M), dim3(1024), 0, st, sp);
         SMI_LAUNCH_CHECK();
         f.tok = L->tok;
@@ -1894,7 +1944,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->lm_cap = (L->NTlm + 3) / 4;                       // partial-argmax slots (two-m-tile path: one per block)
   L->lm_blocks = L->lm_cap < 512 ? L->lm_cap : 512;    // persistent path: 2 resident blocks per CU
   L->max_steps = cfg->max_positions;
-  L->do_sample = 0; L->top_k = 50; L->temperature = 0.8f; L->top_p = 0.95f; L->seed = 0; L->logits = nullptr; L->tok = nullptr; L->stamps = nullptr; L->stamps_on = 0;
+  L->do_sample = 0; L->top_k = 50; L->temperature = 0.8f; L->top_p = 0.95f; L->seed = 0; L->logits = nullptr; L->tok = nullptr; L->cand_v = nullptr; L->cand_i = nullptr; L->cand_n = nullptr; L->stamps = nullptr; L->stamps_on = 0;
   { L->tune[0] = L->tune[1] = L->tune[2] = L->tune[3] = 0; const char* e = getenv("SPARKMI_TUNE"); if (e) sscanf(e, "%d,%d,%d,%d", &L->tune[0], &L->tune[1], &L->tune[2], &L->tune[3]); }
   L->bh = L->bq = nullptr; L->bxs_h = L->bxs_attn = L->bxs_act = nullptr; L->bss = nullptr; L->big_rows = 0;
   L->prefetch = getenv("SPARKMI_NO_PREFETCH") ? 0 : 1;
@@ -1926,6 +1976,10 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   SMI_ALLOC(L->step, 4);
   SMI_ALLOC(L->logits, (size_t)kMaxRows * cfg->vocab_size * 4);
   SMI_ALLOC(L->tok, kMaxRows * 4);
+  SMI_ALLOC(L->cand_v, (size_t)kMaxRows * kCandCap * 4);
+  SMI_ALLOC(L->cand_i, (size_t)kMaxRows * kCandCap * 4);
+  SMI_ALLOC(L->cand_n, kMaxRows * 4);
+  SMI_HIP(hipMemset(L->cand_n, 0, kMaxRows * 4));
   SMI_ALLOC(L->stamps, (size_t)4096 * 8 * 8);
   SMI_ALLOC(L->kcache, kvbytes);
   SMI_ALLOC(L->vcache, kvbytes);
@@ -1957,7 +2011,7 @@ int smi_llm_destroy(smi_llm* L) {
   if (!L) return SMI_OK;
   if (L->graph) (void)hipGraphExecDestroy(L->graph);
   void* ptrs[] = {L->h, L->qbuf, L->xs_h, L->xs_attn, L->xs_act, L->sspart, L->rows, L->plan, L->pval, L->pidx, L->hist,
-                  L->count, L->finished, L->step, L->kcache, L->vcache, L->logits, L->tok, L->stamps, L->bh, L->bq, L->bxs_h, L->bxs_attn, L->bxs_act, L->bss, L->apart};
+                  L->count, L->finished, L->step, L->kcache, L->vcache, L->logits, L->tok, L->cand_v, L->cand_i, L->cand_n, L->stamps, L->bh, L->bq, L->bxs_h, L->bxs_attn, L->bxs_act, L->bss, L->apart};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (L->ev0) (void)hipEventDestroy(L->ev0);
