@@ -53,10 +53,13 @@ __device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erf
 // QB: 32-wide time sub-tiles per wave.  KS: waves split the input channels of ONE 32-row output
 // tile (large C, short T) instead of owning a 32-row output tile each.  CHG: a staged chunk holds
 // 32*CHG input channels (1-tap layers use 128 so a chunk carries enough MFMAs per barrier).  NC:
-// the staged row (tile * input stride + halo) is up to 64 * NC columns wide.
-template <int QB, bool KS, int CHG, int NC, bool WPF = false>
+// the staged row (tile * input stride + halo) is up to 64 * NC columns wide.  NWV: waves per block (3 when the number of
+// 32-row output tiles is a multiple of 3 but not of 4 -- C = 96, 192: with four waves a quarter of every block, and so one
+// SIMD of every CU, would idle).
+template <int QB, bool KS, int CHG, int NC, bool WPF = false, int NWV = 4>
 __global__ __launch_bounds__(256) void k_conv(ConvP p) {
-  constexpr int kCh = kChunk * CHG;
+  static_assert(NWV == 4 || !KS, "the channel-split mode reduces over four waves");
+  constexpr int kCh = 8 * NWV * CHG;   // channels per staged chunk: eight rows per wave and CHG
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int QT = QB * 32;
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvP p) {
   const int len = p.lens[b];
   const int olen = p.olens ? p.olens[b] : len;
   if (q0 >= olen) return;
-  const int ct = KS ? by : by * 4 + wave;
+  const int ct = KS ? by : by * NWV + wave;
   const bool live = ct * 32 < p.Cout;
   const int ntap = p.ntaps[phase];
   const int groups = p.CinP >> 3;
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvP p) {
     if (KS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads();
     if (c0 + kCh < p.CinP) stage_load(c0 + kCh);
     if (live) {
-      const int g0 = KS ? wave * CHG : 0, g1 = KS ? (wave + 1) * CHG : 4 * CHG;
+      const int g0 = KS ? wave * CHG : 0, g1 = KS ? (wave + 1) * CHG : NWV * CHG;
       for (int tap = 0; tap < ntap; ++tap) {
         const int col0 = p.halo_l + p.off[phase][tap] + (lane & 31) * p.istr;
         for (int g = g0; g < g1; ++g) {
@@ -442,7 +445,7 @@ struct Launch {
   std::function<void(hipStream_t)> fn;
   std::string name;
   double flops;
-  ConvP cp; int qb; bool ks; int chg; bool gemv; dim3 grid; size_t lds;
+  ConvP cp; int qb; bool ks; int chg; int nwv = 4; bool gemv; dim3 grid; size_t lds;
   LnP lp; int cpt;
   // small kernels keep their args here
   const int64_t* sem; int semstride; const float* cb; int D, cbsize; float* Z; int zstride; long long zb;
@@ -467,6 +470,14 @@ int run_launch(const Launch& L, hipStream_t st) {
         } else {
           if (L.qb == 1) hipLaunchKernelGGL((k_conv<1, false, 4, 1>), L.grid, dim3(256), L.lds, st, L.cp);
           else hipLaunchKernelGGL((k_conv<2, false, 4, 1>), L.grid, dim3(256), L.lds, st, L.cp);
+        }
+      } else if (L.nwv == 3) {      // three output tiles per block (never channel-split)
+        if (L.cp.xw > 128) {
+          if (L.qb == 1) hipLaunchKernelGGL((k_conv<1, false, 1, 3, false, 3>), L.grid, dim3(192), L.lds, st, L.cp);
+          else hipLaunchKernelGGL((k_conv<2, false, 1, 3, false, 3>), L.grid, dim3(192), L.lds, st, L.cp);
+        } else {
+          if (L.qb == 1) hipLaunchKernelGGL((k_conv<1, false, 1, 2, false, 3>), L.grid, dim3(192), L.lds, st, L.cp);
+          else hipLaunchKernelGGL((k_conv<2, false, 1, 2, false, 3>), L.grid, dim3(192), L.lds, st, L.cp);
         }
       } else if (L.cp.xw > 128) {   // strided convs: up to 192 staged columns
         if (L.ks) {
@@ -544,10 +555,13 @@ Launch make_conv_w(const std::string& name, const float* W, const float* bias,
   L.qb = qb;
   p.halo_l = g.halo_l;
   p.xw = (qt - 1) * istr + 1 + g.halo_l + g.halo_r;
-  L.grid = dim3(nq, L.ks ? cot : (cot + 3) / 4, B * S);
+  // three-wave blocks where four would leave a wave (and so a SIMD of each CU) without an output tile; measured at
+  // 150 frames: 75.0 -> 73.2 ms at B = 32, 21.0 -> 20.5 at B = 8, but 4.66 -> 4.72 at B = 1, hence the grid-size condition
+  L.nwv = (!L.ks && cot % 3 == 0 && cot % 4 != 0 && blocks_cosplit >= 2048) ? 3 : 4;
+  L.grid = dim3(nq, L.ks ? cot : (cot + L.nwv - 1) / L.nwv, B * S);
   L.chg = (S == 1 && K == 1 && Cin >= 128 && L.ks) ? 4 : 1;   // K-split 1-tap layers stage 128 channels per chunk
   L.gemv = false;   // set by the caller for the per-utterance vector projections (use_gemv)
-  size_t lds = (size_t)kChunk * L.chg * p.xw * 4;
+  size_t lds = (size_t)8 * L.nwv * L.chg * p.xw * 4;
   const size_t red = L.ks ? (size_t)4 * qb * 16 * 64 * 4 : 0;
   L.lds = lds > red ? lds : red;
   double taps = 0;
