@@ -193,11 +193,31 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
     const int lts = LEAN == 2 ? 4 : p.lt_shift;
     const int per = 64 >> lts, pm = 12 * M;
     const int r = lane & ((1 << lts) - 1);
-    for (int t0 = 0; t0 < tw; t0 += per) {
-      const int tl = t0 + (lane >> lts);
-      if (tl < tw && r < pm) {
-        const uint4 v = *(const uint4*)(p.XS + xs_off(wave + tl * NW, 0, 0, 0, M) + r * 16);
-        *(uint4*)(bw + ((size_t)tl * pm + r) * 16) = v;
+    // one row, many k tiles per wave (down_proj: 152 tiles over 16 waves = 3 rounds of 4 tiles): all rounds' loads leave
+    // before the first LDS write -- one at a time each round was a full L2 round trip behind the weight stream
+    constexpr int RIF = (LEAN == 2 && WB >= 4) ? 3 : 1;   // rounds in flight
+    if constexpr (RIF > 1) {
+      // (named registers and unconditional loads from clamped addresses: a conditionally written `uint4 v[3]` stays in
+      // scratch memory, and `ok ? *p : zero` becomes a flat load through a select between p and a stack slot)
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const int rc = r < pm ? r : pm - 1;
+      for (int t0 = 0; t0 < tw; t0 += per * 3) {
+        const int ta = t0 + (lane >> lts), tb = ta + per, tc = tb + per;
+        u32x4 va = *(const u32x4*)(p.XS + xs_off(wave + (ta < tw ? ta : tw - 1) * NW, 0, 0, 0, M) + rc * 16);
+        u32x4 vb = *(const u32x4*)(p.XS + xs_off(wave + (tb < tw ? tb : tw - 1) * NW, 0, 0, 0, M) + rc * 16);
+        u32x4 vc = *(const u32x4*)(p.XS + xs_off(wave + (tc < tw ? tc : tw - 1) * NW, 0, 0, 0, M) + rc * 16);
+        asm volatile("" : "+v"(va), "+v"(vb), "+v"(vc));   // all three loads are issued here, not sunk into the branches below
+        if (ta < tw && r < pm) *(u32x4*)(bw + ((size_t)ta * pm + r) * 16) = va;
+        if (tb < tw && r < pm) *(u32x4*)(bw + ((size_t)tb * pm + r) * 16) = vb;
+        if (tc < tw && r < pm) *(u32x4*)(bw + ((size_t)tc * pm + r) * 16) = vc;
+      }
+    } else {
+      for (int t0 = 0; t0 < tw; t0 += per) {
+        const int tl = t0 + (lane >> lts);
+        if (tl < tw && r < pm) {
+          const uint4 v = *(const uint4*)(p.XS + xs_off(wave + tl * NW, 0, 0, 0, M) + r * 16);
+          *(uint4*)(bw + ((size_t)tl * pm + r) * 16) = v;
+        }
       }
     }
   } else if (wave < KT) {
