@@ -115,6 +115,23 @@ __device__ __forceinline__ size_t xs_off(int kt, int s, int k8, int m, int M) {
 // spreads its HBM stream over 112 / 224 CUs.  Every output element keeps its own summation order.
 // LEAN: the few-row decode instantiation (M <= 5, operands staged through wave-private LDS, no phase stamps): the paths it
 // never takes are compiled out -- these kernels are bound by instruction issue as much as by memory.
+// Sum of a row's RMSNorm partials for one lane (index order lane, lane + 64, ...; the caller adds the lanes with
+// smi_wave_sum).  Four loads are issued together from clamped addresses and masked by value: written as a plain loop
+// the compiler emits load -> wait -> add per trip, i.e. one L2 round trip per 64 partials behind the weight stream.
+__device__ __forceinline__ float smi_ss_lane_sum(const float* sp, int npart, int lane) {
+  float v = 0.f;
+  for (int i0 = lane; i0 < npart; i0 += 256) {   // block-uniform trip count is not required: lanes past npart add zeros
+    const int i1 = i0 + 64, i2 = i0 + 128, i3 = i0 + 192, last = npart - 1;
+    float a0 = sp[i0 < npart ? i0 : last], a1 = sp[i1 < npart ? i1 : last], a2 = sp[i2 < npart ? i2 : last], a3 = sp[i3 < npart ? i3 : last];
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+    v += a0;                         // i0 < npart by the loop condition
+    v += i1 < npart ? a1 : 0.f;
+    v += i2 < npart ? a2 : 0.f;
+    v += i3 < npart ? a3 : 0.f;
+  }
+  return v;
+}
+
 template <int MT, int NTB, int NW, int U, int WB, int PRO, int EPI, int KVF32, int H = 1, int OCC = 1, int LEAN = 0>
 __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
   static_assert(H == 1 || ((H == 2 || H == 4) && NTB == 1 && EPI == EPI_RESID), "row-split tiles: RESID, one tile per block");
@@ -249,8 +266,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
   // ---- RMSNorm factor per row from the producer's partial sums (fixed order: DPP tree over partials)
   if (PRO == PRO_NORM) {
     for (int ml = wave; ml < MT * 16 && mbase + ml < M; ml += NW) {
-      float v = 0.f;
-      for (int i = lane; i < p.npart; i += 64) v += p.sspart[(size_t)(mbase + ml) * p.npart + i];
+      float v = smi_ss_lane_sum(p.sspart + (size_t)(mbase + ml) * p.npart, p.npart, lane);
       v = smi_wave_sum(v);
       if (lane == 0) rarr[ml] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
     }
@@ -486,8 +502,7 @@ __global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
     for (int r = wave; r < ROWS; r += 4) {
       int m = m0 + r;
       m = m < M ? m : M - 1;
-      float v = 0.f;
-      for (int i = lane; i < p.npart; i += 64) v += p.sspart[(size_t)m * p.npart + i];
+      float v = smi_ss_lane_sum(p.sspart + (size_t)m * p.npart, p.npart, lane);
       v = smi_wave_sum(v);
       if (lane == 0) rarr[r] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
     }
@@ -681,8 +696,7 @@ __global__ __launch_bounds__(256 * HV) void k_lm(GemmP p, int ngroups, int m0_la
   int g = blockIdx.x;
   if (g < ngroups) load_w(g);
   for (int m = wave; m < M; m += NW) {
-    float v = 0.f;
-    for (int i = lane; i < p.npart; i += 64) v += p.sspart[(size_t)(m0 + m) * p.npart + i];
+    float v = smi_ss_lane_sum(p.sspart + (size_t)(m0 + m) * p.npart, p.npart, lane);
     v = smi_wave_sum(v);
     if (lane == 0) rarr[m] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
   }
