@@ -204,6 +204,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
   // few rows (MT == 1, ldsb > 0): a k tile's 12*M operand pieces are contiguous in XS, so the wave pulls
   // them with full-width loads into its own LDS slice (no block barrier) instead of 3 narrow loads per tile
   const bool vlds = LEAN || (MT == 1 && p.ldsb > 0);
+  // LEAN PRO_NORM kernels: the partial sums of squares of the row this wave owns (row `wave` of the group) are requested
+  // together with its first staging round
+  float ss0 = 0.f, ss1 = 0.f, ss2 = 0.f, ss3 = 0.f;
+  const bool ss_pre = LEAN >= 1 && PRO == PRO_NORM && p.npart <= 256 && wave < MT * 16 && mbase + wave < M;
   unsigned char* bw = smem + (size_t)NW * NTB * MT * 1024 + 32 * 4 + NTB * 32 * 8 + (size_t)wave * p.ldsb;
   if (vlds) {
     const int tw = (KT - wave + NW - 1) / NW;          // this wave's k tiles
@@ -229,7 +233,25 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
         if (tc < tw && r < pm) *(u32x4*)(bw + ((size_t)tc * pm + r) * 16) = vc;
       }
     } else {
-      for (int t0 = 0; t0 < tw; t0 += per) {
+      int t0 = 0;
+      if constexpr (LEAN >= 1 && PRO == PRO_NORM) {
+        // first staging round and this wave's RMSNorm partials (if it owns a row) behind ONE wait: two round trips -> one
+        if (tw > 0) {
+          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+          const int tl = lane >> lts;
+          u32x4 v0 = *(const u32x4*)(p.XS + xs_off(wave + (tl < tw ? tl : tw - 1) * NW, 0, 0, 0, M) + (r < pm ? r : pm - 1) * 16);
+          if (ss_pre) {
+            const float* sp = p.sspart + (size_t)(mbase + wave) * p.npart;
+            const int last = p.npart - 1;
+            ss0 = sp[lane < last ? lane : last]; ss1 = sp[lane + 64 < last ? lane + 64 : last];
+            ss2 = sp[lane + 128 < last ? lane + 128 : last]; ss3 = sp[lane + 192 < last ? lane + 192 : last];
+          }
+          asm volatile("" : "+v"(v0), "+v"(ss0), "+v"(ss1), "+v"(ss2), "+v"(ss3));
+          if (tl < tw && r < pm) *(u32x4*)(bw + ((size_t)tl * pm + r) * 16) = v0;
+          t0 = per;
+        }
+      }
+      for (; t0 < tw; t0 += per) {
         const int tl = t0 + (lane >> lts);
         if (tl < tw && r < pm) {
           const uint4 v = *(const uint4*)(p.XS + xs_off(wave + tl * NW, 0, 0, 0, M) + r * 16);
@@ -266,7 +288,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
   // ---- RMSNorm factor per row from the producer's partial sums (fixed order: DPP tree over partials)
   if (PRO == PRO_NORM) {
     for (int ml = wave; ml < MT * 16 && mbase + ml < M; ml += NW) {
-      float v = smi_ss_lane_sum(p.sspart + (size_t)(mbase + ml) * p.npart, p.npart, lane);
+      float v;
+      if (ss_pre && ml == wave) {   // same order as smi_ss_lane_sum
+        v = lane < p.npart ? ss0 : 0.f;
+        v += lane + 64 < p.npart ? ss1 : 0.f;
+        v += lane + 128 < p.npart ? ss2 : 0.f;
+        v += lane + 192 < p.npart ? ss3 : 0.f;
+      } else {
+        v = smi_ss_lane_sum(p.sspart + (size_t)(mbase + ml) * p.npart, p.npart, lane);
+      }
       v = smi_wave_sum(v);
       if (lane == 0) rarr[ml] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
     }
