@@ -195,12 +195,46 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int m = mbase + mt * 16 + em;
-      erd[mt] = p.rows[m < M ? m : M - 1];
+      if (LEAN != 2) erd[mt] = p.rows[m < M ? m : M - 1];
     }
   }
 #pragma unroll
   for (int b = 0; b < WB; ++b)
     if (wave + b * NW * U < KT) load_w(w[b], wave + b * NW * U);
+  if constexpr (LEAN == 2 && EPI == EPI_QKV) {
+    // one row: its descriptor sits at a uniform address, so it comes through the SCALAR cache -- not counted by vmcnt,
+    // hence the RoPE load that needs the position no longer waits for the weight tiles issued above (the compiler's
+    // counted wait for a vector load of the descriptor was vmcnt(1): descriptor AND weights)
+    if (wave < NTB && nt0 + wave < NT) {
+      unsigned long long sp;
+      asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sp) : "s"(p.rows) : "memory");
+      erd[0].slot = (int32_t)(uint32_t)sp;
+      erd[0].pos = (int32_t)(uint32_t)(sp >> 32);
+    }
+  }
+  // ---- epilogue operands that do not depend on the GEMM: requested BEFORE the operand staging below, so that the
+  // staging wait covers them too (behind it, the first MFMA waited one more L2 round trip for the bias / residual row)
+  float4 epre[MT], egam = make_float4(0.f, 0.f, 0.f, 0.f);
+  float2 erope[MT][2];
+  if (wave < NTB && nt0 + wave < NT) {
+    const int n = (nt0 + wave) * 16 + 4 * (lane >> 4);
+    if (EPI == EPI_RESID) egam = *(const float4*)(p.gamma_next + n);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mbase + mt * 16 + em;
+      if (m < M && ract) {
+        if (EPI == EPI_QKV) {
+          epre[mt] = *(const float4*)(p.bias + n);
+          if (n < p.q_dim + p.kv_dim) {
+            const int i0 = (n & 63) >> 1;
+            erope[mt][0] = p.rope[(size_t)erd[mt].pos * 32 + i0];
+            erope[mt][1] = p.rope[(size_t)erd[mt].pos * 32 + i0 + 1];
+          }
+        }
+        if (EPI == EPI_RESID) epre[mt] = *(const float4*)(p.Y + (size_t)m * (NT * 16) + n);
+      }
+    }
+  }
   // few rows (MT == 1, ldsb > 0): a k tile's 12*M operand pieces are contiguous in XS, so the wave pulls
   // them with full-width loads into its own LDS slice (no block barrier) instead of 3 narrow loads per tile
   const bool vlds = LEAN || (MT == 1 && p.ldsb > 0);
@@ -263,28 +297,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
     load_bf(wave);
   }
 
-  // ---- epilogue operands that do not depend on the GEMM
-  float4 epre[MT], egam = make_float4(0.f, 0.f, 0.f, 0.f);
-  float2 erope[MT][2];
-  if (wave < NTB && nt0 + wave < NT) {
-    const int n = (nt0 + wave) * 16 + 4 * (lane >> 4);
-    if (EPI == EPI_RESID) egam = *(const float4*)(p.gamma_next + n);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = mbase + mt * 16 + em;
-      if (m < M && ract) {
-        if (EPI == EPI_QKV) {
-          epre[mt] = *(const float4*)(p.bias + n);
-          if (n < p.q_dim + p.kv_dim) {
-            const int i0 = (n & 63) >> 1;
-            erope[mt][0] = p.rope[(size_t)erd[mt].pos * 32 + i0];
-            erope[mt][1] = p.rope[(size_t)erd[mt].pos * 32 + i0 + 1];
-          }
-        }
-        if (EPI == EPI_RESID) epre[mt] = *(const float4*)(p.Y + (size_t)m * (NT * 16) + n);
-      }
-    }
-  }
   // ---- RMSNorm factor per row from the producer's partial sums (fixed order: DPP tree over partials)
   if (PRO == PRO_NORM) {
     for (int ml = wave; ml < MT * 16 && mbase + ml < M; ml += NW) {
