@@ -882,14 +882,17 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
   const int slot = sir ? m : rd.slot;
   const size_t rowbase = ((size_t)slot * p.n_kv + kvh) * p.max_pos;
   const int ctx_all = rd.pos + 1;
-  const int ctx = ctx_all < (seg + 1) * kAttnSeg ? ctx_all : (seg + 1) * kAttnSeg;   // this block: keys [seg * kAttnSeg, ctx)
-  if (seg * kAttnSeg >= ctx_all) return;   // block-uniform: this row has no such segment
+  int ctx = ctx_all < (seg + 1) * kAttnSeg ? ctx_all : (seg + 1) * kAttnSeg;   // this block: keys [seg * kAttnSeg, ctx)
+  if (!ONE && seg * kAttnSeg >= ctx_all) return;   // block-uniform: this row has no such segment (ONE: a single segment -- and no wait for the descriptor before the q / K / V loads are requested)
 
-  float qv[DPL];
+  // q is requested here but first USED after the chunk's K/V loads have been requested (the scaling sits in the loop behind
+  // an opaque asm so that it is not hoisted back): descriptor, q and the first K/V chunk share one memory round trip
+  // instead of queueing up as descriptor -> q -> K/V
+  float qraw[DPL];
   {
     const float* qp = p.q + (size_t)m * p.q_dim + head * kHeadDim + dl * DPL;
 #pragma unroll
-    for (int i = 0; i < DPL; ++i) qv[i] = qp[i] * 0.125f;  // head_dim^-0.5, exact
+    for (int i = 0; i < DPL; ++i) qraw[i] = qp[i];
   }
   float m_run = NEG, lrun = 0.f, o[DPL];
 #pragma unroll
@@ -910,6 +913,18 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
         kr[u] = *(const uint4*)((const uint16_t*)p.kcache + off);
         vr[u] = *(const uint4*)((const uint16_t*)p.vcache + off);
       }
+    }
+    if (ONE) {   // the descriptor is first looked at here, behind the loads above (same opaque-asm device as for q below)
+      int pr = rd.pos;
+      asm volatile("" : "+v"(pr));
+      ctx = pr + 1 < kAttnSeg ? pr + 1 : kAttnSeg;
+    }
+    float qv[DPL];
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+      float t = qraw[i];
+      asm volatile("" : "+v"(t));
+      qv[i] = t * 0.125f;  // head_dim^-0.5, exact
     }
     float sc[UNR];
     float lmax = NEG;
