@@ -851,7 +851,9 @@ constexpr int kAttnSeg = 1024;   // tokens per segment (a multiple of the chunk 
 // so every lane accumulates at the same scale; the final merge is a plain sum: inside the wave through
 // its private LDS slice, across waves through one more barrier.  Little redundant work per thread:
 // with one block per head the kernel is bound by instruction issue of its own waves.
-// ONE: exactly one live row in KV slot 0 and one context segment (batch-1 decode): index arithmetic folded at compile time
+// ONE == 1: exactly one live row in KV slot 0 and one context segment (batch-1 decode): index arithmetic folded at compile
+// time.  ONE == 2: several rows, row m in KV slot m, one context segment (plain batched decode): the K/V addresses do not
+// depend on the row descriptor, so descriptor, q and the first K/V chunk travel together as in the one-row kernel.
 template <int KVF32, int ONE = 0>
 __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
   constexpr int LPT = KVF32 ? 16 : 8;   // lanes per token row (each lane 16 bytes)
@@ -870,7 +872,8 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
     pf_run(p.pf, (int)blockIdx.x - p.work_blocks, (int)gridDim.x - p.work_blocks, tid, kAttnWaves * 64);
     return;
   }
-  const int head = ONE ? (int)blockIdx.x : (int)(blockIdx.x / p.nseg) % p.n_heads, m = ONE ? 0 : (int)blockIdx.x / (p.nseg * p.n_heads),
+  const int head = ONE == 1 ? (int)blockIdx.x : ONE == 2 ? (int)blockIdx.x % p.n_heads : (int)(blockIdx.x / p.nseg) % p.n_heads,
+            m = ONE == 1 ? 0 : ONE == 2 ? (int)blockIdx.x / p.n_heads : (int)blockIdx.x / (p.nseg * p.n_heads),
             seg = ONE ? 0 : (int)blockIdx.x % p.nseg;
   const int tl = lane / LPT, dl = lane % LPT;
   const int grp = wave * TPW + tl;
@@ -1009,7 +1012,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
     uint32_t hi, mi, lo;
     split3(O / Ls, hi, mi, lo);
     const int k = head * kHeadDim + tid;
-    const int Mx = ONE ? 1 : p.M;
+    const int Mx = ONE == 1 ? 1 : p.M;
     const size_t ob = xs_off(k >> 5, 0, (k >> 3) & 3, m, Mx) + (k & 7) * 2;
     const size_t pl2 = (size_t)4 * Mx * 16;
     *(uint16_t*)(p.xs_out + ob) = (uint16_t)hi;
@@ -1735,6 +1738,8 @@ int launch_attn(smi_llm* L, AttnP a, int helpers_ok, hipStream_t st) {
   const int helpers = (helpers_ok && L->prefetch && a.M <= 8 && a.work_blocks < 232) ? (256 - a.work_blocks) / 8 * 8 : 0;
   if (a.M == 1 && a.nseg == 1 && a.slot_is_row)
     hipLaunchKernelGGL((k_attn<KVF32, 1>), dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
+  else if (a.nseg == 1 && a.slot_is_row)
+    hipLaunchKernelGGL((k_attn<KVF32, 2>), dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
   else
     hipLaunchKernelGGL((k_attn<KVF32, 0>), dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
   SMI_LAUNCH_CHECK();
