@@ -872,9 +872,17 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
     pf_run(p.pf, (int)blockIdx.x - p.work_blocks, (int)gridDim.x - p.work_blocks, tid, kAttnWaves * 64);
     return;
   }
-  const int head = ONE == 1 ? (int)blockIdx.x : ONE == 2 ? (int)blockIdx.x % p.n_heads : (int)(blockIdx.x / p.nseg) % p.n_heads,
-            m = ONE == 1 ? 0 : ONE == 2 ? (int)blockIdx.x / p.n_heads : (int)blockIdx.x / (p.nseg * p.n_heads),
-            seg = ONE ? 0 : (int)blockIdx.x % p.nseg;
+  // Several rows: the query heads of one KV group (and a row's segments) are neighbours in the natural block order, but
+  // consecutive block ids go to the 8 XCDs round-robin, so each of a group's 7 heads would pull the same K/V rows into a
+  // different L2.  Re-number: XCD x works through the x-th contiguous eighth of the natural order.
+  unsigned bid = blockIdx.x;
+  if (ONE != 1) {
+    const unsigned total = (unsigned)p.work_blocks, xcd = bid & 7u, slot = bid >> 3, q8 = total >> 3, r8 = total & 7u;
+    bid = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
+  }
+  const int head = ONE == 1 ? (int)bid : ONE == 2 ? (int)bid % p.n_heads : (int)(bid / p.nseg) % p.n_heads,
+            m = ONE == 1 ? 0 : ONE == 2 ? (int)bid / p.n_heads : (int)bid / (p.nseg * p.n_heads),
+            seg = ONE ? 0 : (int)bid % p.nseg;
   const int tl = lane / LPT, dl = lane % LPT;
   const int grp = wave * TPW + tl;
   const RowDesc rd = p.rows[m];
@@ -1039,7 +1047,10 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn_pf(AttnP p) {
   __shared__ __attribute__((aligned(16))) float so[kAttnWaves][TPW][kHeadDim];
   __shared__ float sl[kAttnWaves][TPW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int head = blockIdx.y, m = (int)blockIdx.x * kAttnWaves + wave;
+  // natural order: the 14 heads of a row tile are neighbours; XCD x takes the x-th contiguous eighth of it (see k_attn)
+  const unsigned total = gridDim.x * gridDim.y, pb = blockIdx.x + gridDim.x * blockIdx.y;
+  const unsigned lb = (pb & 7u) * (total >> 3) + ((pb & 7u) < (total & 7u) ? (pb & 7u) : (total & 7u)) + (pb >> 3);
+  const int head = (int)(lb % gridDim.y), m = (int)(lb / gridDim.y) * kAttnWaves + wave;
   if (m >= p.M) return;   // wave-uniform; the kernel has no barrier
   const int tl = lane / LPT, dl = lane % LPT;
   const RowDesc rd = p.rows[m];
