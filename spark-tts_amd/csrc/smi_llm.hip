@@ -1701,7 +1701,7 @@ int launch_gemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
     if constexpr (N2 > 1) return launch_gemm_kv<2, NTB * N2, NW, 2, 1, PRO, EPI>(L, p, st);   // two k tiles in flight: 13.9 -> 13.6 us at 32 rows, 18.5 -> 17.5 at 64
     // few n tiles (N = 896 / 1152): 16-row blocks in two block rows put twice the CUs to work and halve the operand
     // bytes per CU (measured at M = 32; SPARKMI_TUNE2 bit 0 keeps 32-row blocks)
-    if constexpr (N2 == 0) { if (!(L->tune2 & 1)) return launch_gemm_kv<1, NTB, NW, U, 1, PRO, EPI>(L, p, st); }
+    if constexpr (N2 == 0) { if (!(L->tune2 & 1)) return launch_gemm_kv<1, NTB, NW, U, 1, PRO, EPI, H>(L, p, st); }
     return launch_gemm_kv<2, NTB, NW, (NW >= 16 || NTB >= 4 ? 2 : (U > 4 ? 4 : U)), 1, PRO, EPI>(L, p, st);
   }
   return launch_gemm_kv<1, NTB, NW, U, WB, PRO, EPI, H, OCC>(L, p, st);
@@ -1832,7 +1832,12 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
         case 5: return launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID, 2>(L, p, st);
         case 6: return launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID>(L, p, st);
         default:   // few rows: 4-row parts (224 blocks, -0.7 us); same bits either way, the zero-fed MFMAs cost at M > 8
-          return M <= 8 ? launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID, 4>(L, p, st) : launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID, 1, 0>(L, p, st);
+          // row parts (H blocks per weight tile) while the operand re-reads they cost stay small: measured step at
+          // 16 / 32 / 64 rows with H = 1 | 2 | 4: 930 | 915 | 900, 1064 | 1055 | 1161, 1318 | 1443 | 1671 us
+          if (M <= 8) return launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID, 4>(L, p, st);
+          if (M <= 16) return launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID, 4, 0>(L, p, st);
+          if (M <= 32) return launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID, 2, 0>(L, p, st);
+          return launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID, 1, 0>(L, p, st);
       }
     case KLM:
       p.W = (const uint4*)sec(L, SMI_LLM_LM_HEAD, 0); p.NT = L->NTlm; p.KT = L->KTh;
