@@ -564,7 +564,8 @@ __global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
 #define ktile(kt_, wuse_, wld_) do { \
     const int kq_ = (kt_); \
     wload(wld_, kq_ + 2); \
-    if (kq_ + 1 < KT) stage_load(kq_ + 1);               /* in flight during this tile's MFMAs */ \
+    stage_load(kq_ + 1 < KT ? kq_ + 1 : KT - 1);         /* in flight during this tile's MFMAs: unconditional (behind a branch the compiler waited for them in front of the MFMAs) and fenced (without the fence it sinks them below the MFMAs) */ \
+    __builtin_amdgcn_sched_barrier(0); \
     const uint4* Bb = Bs + (kq_ & 1) * PIECES; \
     /* operand pieces of m-tile mt + 1 are read from LDS while the MFMAs of m-tile mt run */ \
     uint4 bq[2][3]; \
