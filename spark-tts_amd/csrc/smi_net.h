@@ -160,21 +160,33 @@ __global__ __launch_bounds__(256) void k_conv(ConvP p) {
     if (KS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads();
     if (c0 + kCh < p.CinP) stage_load(c0 + kCh);
     if (live) {
-      const int g0 = KS ? wave * CHG : 0, g1 = KS ? (wave + 1) * CHG : NWV * CHG;
-      for (int tap = 0; tap < ntap; ++tap) {
+      // (tap, 8-channel group) steps in order over this wave's groups of the chunk (all of them, or with KS its own CHG),
+      // the NEXT step's packed weights requested before this step's MFMAs and fenced there (the plain loop loads a float4,
+      // waits an L2 round trip, issues 4 * QB MFMAs, and leaves hiding that latency to the other waves of the SIMD)
+      typedef float f32x4v __attribute__((ext_vector_type(4)));
+      const int gbase = KS ? wave * CHG : 0, gcap = KS ? CHG : NWV * CHG;
+      int gl = (p.CinP - c0 + 7) / 8 - gbase;   // live groups of this chunk from gbase on
+      gl = gl < gcap ? gl : gcap;
+      const int nstep = gl > 0 ? ntap * gl : 0;
+      const f32x4v* Wq = (const f32x4v*)Wp + ((long long)(c0 >> 3) + gbase) * 64 + lane;
+      int tap = 0, g = 0;
+      f32x4v wv = *(gl > 0 ? Wq : (const f32x4v*)Wp + lane);   // (no live group: any valid address of this tile's weights, unused)
+      for (int st = 0; st < nstep; ++st) {
+        int gn = g + 1, tn = tap;
+        if (gn == gl) { gn = 0; ++tn; }
+        if (tn == ntap) { tn = tap; gn = g; }   // last step: re-request the current weights (no branch around the load)
+        const f32x4v wn = Wq[((long long)tn * groups + gn) * 64];
+        __builtin_amdgcn_sched_barrier(0);
         const int col0 = p.halo_l + p.off[phase][tap] + (lane & 31) * p.istr;
-        for (int g = g0; g < g1; ++g) {
-          if (c0 + g * 8 >= p.CinP) break;
-          const float4 wv = Wp[((long long)tap * groups + (c0 >> 3) + g) * 64 + lane];
-          const float wa[4] = {wv.x, wv.y, wv.z, wv.w};
+        const float wa[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float* xr = lds + (g * 8 + j * 2 + (lane >> 5)) * xw + col0;
+        for (int j = 0; j < 4; ++j) {
+          const float* xr = lds + ((gbase + g) * 8 + j * 2 + (lane >> 5)) * xw + col0;
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
-              acc[qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], xr[qb * 32 * p.istr], acc[qb], 0, 0, 0);
-          }
+          for (int qb = 0; qb < QB; ++qb)
+            acc[qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], xr[qb * 32 * p.istr], acc[qb], 0, 0, 0);
         }
+        wv = wn; g = gn; tap = tn;
       }
     }
   }
