@@ -204,7 +204,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
   if constexpr (LEAN == 2 && EPI == EPI_QKV) {
     // one row: its descriptor sits at a uniform address, so it comes through the SCALAR cache -- not counted by vmcnt,
     // hence the RoPE load that needs the position no longer waits for the weight tiles issued above (the compiler's
-    // counted wait for a vector load of the descriptor was vmcnt(1): descriptor AND weights)
+    // counted wait for a vector load of the descriptor was vmcnt(1): descriptor AND weights).  The descriptor is rewritten
+    // by k_finalize every step; like every compiler-scalarised load of data an earlier kernel wrote, this relies on the
+    // scalar-cache invalidate of the dispatch's acquire fence (with `glc` the load is 1.3 us slower: 630 -> 662 us per step).
     if (wave < NTB && nt0 + wave < NT) {
       unsigned long long sp;
       asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sp) : "s"(p.rows) : "memory");
