@@ -37,7 +37,8 @@ extern "C" {
 #define SMI_ENOMEM (-3)   /* device allocation failed */
 #define SMI_ESTATE (-4)   /* call sequence violated (e.g. decode before prefill) */
 
-#define SMI_ABI_VERSION 1
+#define SMI_ABI_VERSION 2   /* 2: eos id LISTS (generation_config.json holds several), per-sequence sampler streams */
+#define SMI_MAX_EOS 4      /* eos ids per generation (HF stops on ANY id of generation_config.eos_token_id) */
 #define SMI_MAX_ROWS 64   /* rows (= concurrent sequences, or prompt tokens per prefill chunk) per step */
 
 int smi_version(void);
@@ -89,14 +90,16 @@ int smi_llm_destroy(smi_llm* h);
 /* Start B sequences (slots 0..B-1): run the prompts through the model (KV cache filled) and emit
  * each sequence's first new token (generate()'s prefill forward + argmax).
  *   ids_host:  [B][P_max] int64 prompt ids, right-padded;  lens_host: [B] prompt lengths (>= 1).
- *   eos_id:    a sequence stops counting tokens after emitting it; pass -1 to never stop.       */
+ *   eos_ids_host / n_eos: a sequence stops counting tokens after emitting ANY of these ids, as HF generate()
+ *              does with every id of generation_config.json's eos_token_id (cli/SparkTTS.py:197-204 passes none
+ *              itself); 0 <= n_eos <= SMI_MAX_EOS, n_eos = 0: never stop.                          */
 int smi_llm_prefill(smi_llm* h, const int64_t* ids_host, const int32_t* lens_host, int B, int P_max,
-                    int64_t eos_id, void* stream);
+                    const int64_t* eos_ids_host, int n_eos, void* stream);
 /* Token selection for the following prefill/decode calls.  do_sample = 0: greedy argmax (lowest id
  * on ties, like torch.argmax).  do_sample = 1: the reference's default at cli/SparkTTS.py:197-204 --
  * temperature, then top-k (1..256), then nucleus top-p, one multinomial draw per step from a
- * Philox stream keyed by (seed, step, row): reproducible per seed, statistically (not bitwise)
- * equivalent to transformers' sampler. */
+ * Philox stream keyed by (seed; the sequence's admission number, its own token index): reproducible per
+ * seed whatever else is in the batch, statistically (not bitwise) equivalent to transformers' sampler. */
 int smi_llm_set_sampling(smi_llm* h, int do_sample, float temperature, int top_k, float top_p, uint64_t seed);
 /* Run n_steps more decode steps for all B sequences (finished ones keep stepping; their
  * tokens are not counted).  Asynchronous. */
@@ -113,7 +116,7 @@ int smi_llm_get_tokens(smi_llm* h, int64_t* out_host, int32_t* lens_host, int ca
  * touching the live sequences; smi_llm_decode then steps every live sequence; smi_llm_slot_tokens reads one
  * sequence's tokens so far and whether it has produced eos; smi_llm_retire frees its slot.  A sequence's
  * tokens do not depend on what else is live (rows are independent in every kernel). */
-int smi_llm_session_begin(smi_llm* h, int64_t eos_id, void* stream);
+int smi_llm_session_begin(smi_llm* h, const int64_t* eos_ids_host, int n_eos, void* stream);
 int smi_llm_admit(smi_llm* h, const int64_t* ids_host, const int32_t* lens_host, int n, int P_max, int32_t* slots_out, void* stream);
 int smi_llm_retire(smi_llm* h, int slot, void* stream);
 int smi_llm_slot_tokens(smi_llm* h, int slot, int64_t* out_host, int cap, int32_t* n_out, int32_t* finished, void* stream);
@@ -131,6 +134,10 @@ int smi_llm_steps(smi_llm* h);
  * 16 + k (k = 0..4): layer kernel k timed in sequence -- (iters whole layers) minus (the same layers
  * without k) -- so that it finds the L2 state its producers leave, as inside the decode graph. */
 int smi_llm_time_kernel(smi_llm* h, int kernel, int layer, int iters, float* ms_avg, void* stream);
+/* Diagnostics: one launch of a decode-step GEMM kernel (ids as above, GEMM kernels only) with in-kernel
+ * s_memrealtime phase stamps; out[0..7) = mean over blocks of (stamp i - earliest stamp 0) in microseconds,
+ * out[7] = shader clock in MHz (tools/stamps.py).  Needs a started generation. */
+int smi_llm_debug_stamps(smi_llm* h, int kernel, int layer, double* out);
 
 /* ------------------------------------------------------------------------------------------
  * Vocoder: BiCodec.detokenize (codebook lookup, d-vector, ConvNeXt prenet, WaveGenerator).

@@ -1,7 +1,7 @@
-// smi_ubench.hip -- launch-floor microbenchmarks (diagnostics only; not part of the product path).
+// diag_ubench.hip -- launch-floor microbenchmarks (diagnostics only; not part of the product path).
 // Times hipGraph replays of a chain of N dependent kernels of one kind, to price the fixed cost of a
 // kernel boundary on this machine separately from the work inside the kernels.
-#include "smi_common.h"
+#include "../smi_common.h"
 #include <vector>
 
 namespace {

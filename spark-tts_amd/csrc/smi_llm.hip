@@ -27,6 +27,7 @@
 #include "smi_common.h"
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -36,6 +37,15 @@ constexpr int kHeadDim = 64;
 
 struct RowDesc {  // 16 bytes, lives in device memory
   int32_t slot, pos, token, flags;
+};
+
+// Generation controls in device memory (written at prefill / session_begin / admit; read by k_finalize and the sampler),
+// so that nothing of them is baked into the captured decode graph: the graph survives from one utterance to the next.
+struct Ctl {
+  long long eos[SMI_MAX_EOS];     // a sequence stops counting after emitting any of the first n_eos ids
+  int32_t n_eos, pad;
+  unsigned long long seed;        // sampler stream key
+  int32_t seqid[SMI_MAX_ROWS];    // per KV slot: admission number of the sequence living there (sampler stream key)
 };
 
 enum { PRO_PLAIN = 0, PRO_NORM = 1 };
@@ -1220,14 +1230,15 @@ __global__ __launch_bounds__(256) void k_embed(const uint16_t* Wlm, int KT, cons
 // cli/SparkTTS.py:166-168,197-204).  Restates the HF warper chain: logits / T -> keep top k ->
 // nucleus (drop the low tail whose cumulative probability <= 1 - top_p, keep >= 1) -> softmax ->
 // one multinomial draw.  The draw uses a counter-based Philox4x32-10 stream keyed by
-// (seed; step, row), so a run is reproducible but not bit-identical to torch.multinomial.
+// (seed; the sequence's own token index, its admission number), so a run is reproducible but not
+// bit-identical to torch.multinomial.
 // ------------------------------------------------------------------------------------------
 struct SampleP {
   const float* logits;  // [M][V]
   int V, top_k;
   float inv_temp, top_p;
-  unsigned long long seed;
-  const int32_t* step;
+  const Ctl* ctl;        // seed and the per-slot admission numbers
+  const RowDesc* rows;   // the live rows: (slot, ..., flags = tokens this sequence has emitted so far)
   int* tok;             // [kMaxRows] sampled token per row
   const float* pval;    // [M][nblk] the lm_head blocks' best logits (a bound for the top-k threshold) or null
   int nblk;
@@ -1458,7 +1469,10 @@ __global__ __launch_bounds__(1024) void k_sample(SampleP p) {
     const float ksum = __shfl(q, 63, 64);
     float before = __shfl_up(q, 1, 64);
     if (tid == 0) before = 0.f;
-    const uint32_t r = philox_u32(p.seed, (uint32_t)*p.step, (uint32_t)m);
+    // one stream per SEQUENCE: (its admission number, its own token index) -- a request's draws do not depend on which
+    // row it occupies, on what else is live or on when its neighbours were admitted
+    const RowDesc rd = p.rows[m];
+    const uint32_t r = philox_u32(p.ctl->seed, (uint32_t)rd.flags, (uint32_t)p.ctl->seqid[rd.slot]);
     const float u = (float)(r >> 8) * (1.0f / 16777216.0f) * ksum;
     int pick = keep - 1;
 #pragma unroll
@@ -1480,7 +1494,7 @@ struct FinP {
   int32_t* count;     // [kMaxRows] tokens counted per sequence
   int32_t* finished;  // [kMaxRows]
   int32_t* step;      // [1]
-  int64_t eos;
+  const Ctl* ctl;     // eos ids
   const uint16_t* Wlm;
   float* h;
   int max_steps;
@@ -1539,7 +1553,10 @@ __global__ __launch_bounds__(256) void k_finalize(FinP p) {
     if (step < p.max_steps) p.hist[(size_t)step * kMaxRows + sl] = bi;
     if (!p.finished[sl]) {
       p.count[sl] = step + 1;
-      if ((int64_t)bi == p.eos) p.finished[sl] = 1;
+      bool stop = false;   // HF generate(): any id of generation_config.eos_token_id ends the sequence
+#pragma unroll
+      for (int e = 0; e < SMI_MAX_EOS; ++e) stop |= e < p.ctl->n_eos && (long long)bi == p.ctl->eos[e];
+      if (stop) p.finished[sl] = 1;
     }
     rd.token = bi;
     rd.pos += 1;
@@ -1618,7 +1635,9 @@ struct smi_llm {
   float* pval; int* pidx; int lm_blocks, lm_cap;
   int64_t* hist; int32_t *count, *finished, *step;
   void *kcache, *vcache; size_t kv_layer_elems;
-  int B; int64_t eos; int started;
+  int B; int started;
+  Ctl hctl; Ctl* ctl;   // host copy / device block of the generation controls
+  int admit_seq;        // sequences admitted so far in this generation / session (sampler stream ids)
   // continuous batching (smi_llm_session_*): live rows map to arbitrary KV slots
   int session, identity_slots;
   int attn_seg;                        // context segments per (head, row) of the attention launches being issued (1 = unsplit)
@@ -1635,7 +1654,7 @@ struct smi_llm {
   int prefetch;  // same-XCD L2 prefetch by helper blocks (SPARKMI_NO_PREFETCH=1 turns it off)
   int tune2;     // SPARKMI_TUNE2 bit mask (diagnostics)
   int pgemm_min_rows;   // prompt rows from which the prefill GEMM replaces row-grouped decode GEMMs (SPARKMI_PGEMM_MIN_ROWS)
-  hipGraphExec_t graph; int graph_B, graph_seg;
+  hipGraphExec_t graph; int graph_B, graph_seg, graph_ident;
   hipEvent_t ev0, ev1;
   // host staging
   std::vector<RowDesc> host_rows;
@@ -1663,12 +1682,17 @@ int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
       lds += per_wave * NW;
     }
   }
-  if (lds > 64 * 1024) {   // more than the default dynamic LDS window: opt in once per instantiation
-    static bool done = false;
-    if (!done) {
+  if (lds > 64 * 1024) {   // more than the default dynamic LDS window: opt in once per instantiation AND device
+    // (the attribute belongs to the function on one device; several handles / host threads may get here together)
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    SMI_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev >= 0 && dev < 64 && !done[dev]) {
       SMI_HIP(hipFuncSetAttribute((const void*)k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 1, H, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       SMI_HIP(hipFuncSetAttribute((const void*)k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 0, H, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      done = true;
+      done[dev] = true;
     }
   }
   const int groups = (p.M + MT * 16 - 1) / (MT * 16);   // one block row per MT*16 rows (more than one: prefill, or 17..32 rows as 2 x 16)
@@ -1869,7 +1893,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       if (L->do_sample) {
         SampleP sp;
         sp.logits = L->logits; sp.V = c.vocab_size; sp.top_k = L->top_k; sp.inv_temp = 1.0f / L->temperature;
-        sp.top_p = L->top_p; sp.seed = L->seed; sp.step = L->step; sp.tok = L->tok;
+        sp.top_p = L->top_p; sp.ctl = L->ctl; sp.rows = L->rows; sp.tok = L->tok;
         sp.pval = L->pval; sp.nblk = lm_blocks_for(L, M);
         sp.cand_v = L->cand_v; sp.cand_i = L->cand_i; sp.cand_n = L->cand_n;
         hipLaunchKernelGGL(k_sample_scan, dim3(kScanBlocks, M), dim3(256), 0, st, sp);
@@ -1881,7 +1905,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       f.pval = L->pval; f.pidx = L->pidx; f.M = M; f.KT = L->KTh;
       f.nblk = lm_blocks_for(L, M);
       f.rows = L->rows; f.hist = L->hist; f.count = L->count; f.finished = L->finished; f.step = L->step;
-      f.eos = L->eos; f.Wlm = (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0); f.h = L->h; f.max_steps = L->max_steps;
+      f.ctl = L->ctl; f.Wlm = (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0); f.h = L->h; f.max_steps = L->max_steps;
       f.gamma0 = (const float*)sec(L, SMI_LLM_LN1, 0); f.xs = L->xs_h; f.sspart = L->sspart; f.npart = L->NTh * 4;
       hipLaunchKernelGGL(k_finalize, dim3(M), dim3(256), 0, st, f);
       SMI_LAUNCH_CHECK();
@@ -2066,7 +2090,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->prefetch = getenv("SPARKMI_NO_PREFETCH") ? 0 : 1;
   { const char* e = getenv("SPARKMI_TUNE2"); L->tune2 = e ? atoi(e) : 0; }
   { const char* e = getenv("SPARKMI_PGEMM_MIN_ROWS"); L->pgemm_min_rows = e ? atoi(e) : 3072; }
-  L->graph = nullptr; L->graph_B = 0; L->graph_seg = 1; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->eos = -1;
+  L->graph = nullptr; L->graph_B = 0; L->graph_seg = 1; L->graph_ident = 1; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->ctl = nullptr; L->admit_seq = 0; memset(&L->hctl, 0, sizeof(L->hctl));
   L->session = 0; L->identity_slots = 1; L->attn_seg = 1; L->apart = nullptr; L->apart_floats = 0; memset(L->slot_busy, 0, sizeof(L->slot_busy)); memset(L->slot_len, 0, sizeof(L->slot_len));
   const size_t esz = cfg->kv_dtype ? 4 : 2;
   L->kv_layer_elems = (size_t)cfg->max_slots * cfg->num_kv_heads * cfg->max_positions * kHeadDim;
@@ -2090,6 +2114,8 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   SMI_ALLOC(L->count, kMaxRows * 4);
   SMI_ALLOC(L->finished, kMaxRows * 4);
   SMI_ALLOC(L->step, 4);
+  SMI_ALLOC(L->ctl, sizeof(Ctl));
+  SMI_HIP(hipMemset(L->ctl, 0, sizeof(Ctl)));
   SMI_ALLOC(L->logits, (size_t)kMaxRows * cfg->vocab_size * 4);
   SMI_ALLOC(L->tok, kMaxRows * 4);
   SMI_ALLOC(L->cand_v, (size_t)kMaxRows * kCandCap * 4);
@@ -2127,7 +2153,7 @@ int smi_llm_destroy(smi_llm* L) {
   if (!L) return SMI_OK;
   if (L->graph) (void)hipGraphExecDestroy(L->graph);
   void* ptrs[] = {L->h, L->qbuf, L->xs_h, L->xs_attn, L->xs_act, L->sspart, L->rows, L->plan, L->pval, L->pidx, L->hist,
-                  L->count, L->finished, L->step, L->kcache, L->vcache, L->logits, L->tok, L->cand_v, L->cand_i, L->cand_n, L->stamps, L->bh, L->bq, L->bxs_h, L->bxs_attn, L->bxs_act, L->bss, L->apart};
+                  L->count, L->finished, L->step, L->ctl, L->kcache, L->vcache, L->logits, L->tok, L->cand_v, L->cand_i, L->cand_n, L->stamps, L->bh, L->bq, L->bxs_h, L->bxs_attn, L->bxs_act, L->bss, L->apart};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (L->ev0) (void)hipEventDestroy(L->ev0);
@@ -2144,9 +2170,14 @@ int smi_llm_set_sampling(smi_llm* L, int do_sample, float temperature, int top_k
     SMI_REQUIRE(top_p > 0.f && top_p <= 1.f, "smi_llm_set_sampling: top_p must be in (0, 1]");
     if (top_k > L->cfg.vocab_size) top_k = L->cfg.vocab_size;
   }
+  // mode, temperature, top-k and top-p are kernel parameters of the captured step; the seed lives in device memory (Ctl)
+  const bool changed = L->do_sample != (do_sample ? 1 : 0) ||
+                       (do_sample && (L->temperature != temperature || L->top_k != top_k || L->top_p != top_p));
   L->do_sample = do_sample ? 1 : 0;
   L->temperature = temperature; L->top_k = top_k; L->top_p = top_p; L->seed = seed;
-  if (L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }   // parameters are baked into the graph
+  L->hctl.seed = seed;   // uploaded with the next prefill / session_begin too
+  SMI_HIP(hipMemcpy(&L->ctl->seed, &seed, sizeof(seed), hipMemcpyHostToDevice));
+  if (changed && L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }
   return SMI_OK;
 }
 
@@ -2207,20 +2238,35 @@ static int prefill_prompts(smi_llm* L, const int64_t* ids, const int32_t* lens, 
   return SMI_OK;
 }
 
-int smi_llm_prefill(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, int P_max, int64_t eos_id, void* stream) {
+// eos ids + seed + the slots' sequence numbers -> device (before anything of the generation is enqueued)
+static int upload_ctl(smi_llm* L, const int64_t* eos_ids, int n_eos, hipStream_t st) {
+  SMI_REQUIRE(n_eos >= 0 && n_eos <= SMI_MAX_EOS && (n_eos == 0 || eos_ids), "eos list: 0..%d ids", SMI_MAX_EOS);
+  for (int e = 0; e < SMI_MAX_EOS; ++e) L->hctl.eos[e] = e < n_eos ? (long long)eos_ids[e] : -1;
+  L->hctl.n_eos = n_eos;
+  L->hctl.seed = L->seed;
+  SMI_HIP(hipMemcpyAsync(L->ctl, &L->hctl, sizeof(Ctl), hipMemcpyHostToDevice, st));
+  return SMI_OK;
+}
+
+int smi_llm_prefill(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, int P_max, const int64_t* eos_ids, int n_eos,
+                    void* stream) {
   SMI_REQUIRE(L && ids && lens, "smi_llm_prefill: null argument");
   SMI_REQUIRE(B >= 1 && B <= L->cfg.max_slots, "smi_llm_prefill: B=%d outside 1..%d", B, L->cfg.max_slots);
   hipStream_t st = (hipStream_t)stream;
+  for (int b = 0; b < kMaxRows; ++b) L->hctl.seqid[b] = b;
+  L->admit_seq = B;
+  { int rc0 = upload_ctl(L, eos_ids, n_eos, st); if (rc0) return rc0; }
   int32_t slots[kMaxRows];
   for (int b = 0; b < kMaxRows; ++b) slots[b] = b;
   SMI_HIP(hipMemsetAsync(L->count, 0, kMaxRows * 4, st));
   SMI_HIP(hipMemsetAsync(L->finished, 0, kMaxRows * 4, st));
   SMI_HIP(hipMemsetAsync(L->step, 0, 4, st));
-  L->B = B; L->eos = eos_id; L->started = 1; L->session = 0; L->identity_slots = 1;
+  L->B = B; L->started = 1; L->session = 0; L->identity_slots = 1;
   L->max_len = 0;
   for (int b = 0; b < B; ++b) L->max_len = lens[b] > L->max_len ? lens[b] : L->max_len;
   L->steps_launched = 1;
-  if (L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }  // eos / B are baked into the graph
+  // the captured decode step is kept across utterances: eos ids and the seed live in device memory (Ctl); smi_llm_decode
+  // re-captures only when the row count, the context-segment count or the slot mapping differ from the captured ones
   size_t tail = 0;
   int rc;
   if ((rc = prefill_prompts(L, ids, lens, B, P_max, slots, &tail, st))) { L->started = 0; return rc; }
@@ -2230,13 +2276,16 @@ int smi_llm_prefill(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, 
 }
 
 // ---- continuous batching: sequences join (admit) and leave (retire) between decode steps ----
-int smi_llm_session_begin(smi_llm* L, int64_t eos_id, void* stream) {
+int smi_llm_session_begin(smi_llm* L, const int64_t* eos_ids, int n_eos, void* stream) {
   SMI_REQUIRE(L, "smi_llm_session_begin: null handle");
   hipStream_t st = (hipStream_t)stream;
+  memset(L->hctl.seqid, 0, sizeof(L->hctl.seqid));
+  L->admit_seq = 0;
+  { int rc0 = upload_ctl(L, eos_ids, n_eos, st); if (rc0) return rc0; }
   SMI_HIP(hipMemsetAsync(L->count, 0, kMaxRows * 4, st));
   SMI_HIP(hipMemsetAsync(L->finished, 0, kMaxRows * 4, st));
   SMI_HIP(hipMemsetAsync(L->step, 0, 4, st));
-  L->B = 0; L->eos = eos_id; L->started = 1; L->session = 1; L->identity_slots = 1;
+  L->B = 0; L->started = 1; L->session = 1; L->identity_slots = 1;
   L->max_len = 0; L->steps_launched = 0;
   memset(L->slot_busy, 0, sizeof(L->slot_busy));
   memset(L->slot_len, 0, sizeof(L->slot_len));
@@ -2279,6 +2328,8 @@ int smi_llm_admit(smi_llm* L, const int64_t* ids, const int32_t* lens, int n, in
   for (int sl = 0; sl < L->cfg.max_slots && k < n; ++sl)
     if (!L->slot_busy[sl]) slots[k++] = sl;
   SMI_REQUIRE(k == n, "smi_llm_admit: no free KV slot");
+  for (int b = 0; b < n; ++b) L->hctl.seqid[slots[b]] = L->admit_seq++;
+  SMI_HIP(hipMemcpyAsync(L->ctl, &L->hctl, sizeof(Ctl), hipMemcpyHostToDevice, st));
   size_t tail = 0;
   if ((rc = prefill_prompts(L, ids, lens, n, P_max, slots, &tail, st))) return rc;
   // first token of the new sequences: one step over the new rows alone
@@ -2363,7 +2414,7 @@ int smi_llm_decode(smi_llm* L, int n_steps, void* stream) {
     L->attn_seg = segs_for(bound);
     if (L->attn_seg > 1 && (rc = ensure_apart(L, (size_t)kMaxRows * L->cfg.num_heads * L->attn_seg * 66))) return rc;
   }
-  if (L->cfg.use_graph && n_steps > 0 && (!L->graph || L->graph_B != L->B || L->graph_seg != L->attn_seg)) {
+  if (L->cfg.use_graph && n_steps > 0 && (!L->graph || L->graph_B != L->B || L->graph_seg != L->attn_seg || L->graph_ident != L->identity_slots)) {
     if (L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }
     hipStream_t cs;
     SMI_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
@@ -2379,7 +2430,7 @@ int smi_llm_decode(smi_llm* L, int n_steps, void* stream) {
     }
     (void)hipStreamDestroy(cs);
     (void)hipGetLastError();
-    L->graph_B = L->B; L->graph_seg = L->attn_seg;
+    L->graph_B = L->B; L->graph_seg = L->attn_seg; L->graph_ident = L->identity_slots;
     if (!L->graph) { smi_set_error("hipGraph capture of the decode step failed"); return SMI_EHIP; }
   }
   for (int s = 0; s < n_steps; ++s) {

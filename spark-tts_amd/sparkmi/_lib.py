@@ -13,6 +13,8 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["SPARKMI_LIB"]) if os.environ.get("SPARKMI_LIB") else _HERE / "libsparkmi.so"
 
 SMI_MAX_ROWS = 64
+SMI_MAX_EOS = 4
+ABI_VERSION = 2
 
 
 class SparkMIError(RuntimeError):
@@ -63,12 +65,12 @@ SYMBOLS = {
     "smi_llm_arena_section": (_I, [_P(LLMCfg), _I, _I, _P(_SZ), _P(_SZ)]),
     "smi_llm_create": (_I, [_P(LLMCfg), _VP, _SZ, _P(_VP)]),
     "smi_llm_destroy": (_I, [_VP]),
-    "smi_llm_prefill": (_I, [_VP, _P(C.c_int64), _P(C.c_int32), _I, _I, C.c_int64, _VP]),
+    "smi_llm_prefill": (_I, [_VP, _P(C.c_int64), _P(C.c_int32), _I, _I, _P(C.c_int64), _I, _VP]),
     "smi_llm_set_sampling": (_I, [_VP, _I, C.c_float, _I, C.c_float, C.c_uint64]),
     "smi_llm_decode": (_I, [_VP, _I, _VP]),
     "smi_llm_all_done": (_I, [_VP, _P(_I), _VP]),
     "smi_llm_get_tokens": (_I, [_VP, _P(C.c_int64), _P(C.c_int32), _I, _VP]),
-    "smi_llm_session_begin": (_I, [_VP, C.c_int64, _VP]),
+    "smi_llm_session_begin": (_I, [_VP, _P(C.c_int64), _I, _VP]),
     "smi_llm_admit": (_I, [_VP, _P(C.c_int64), _P(C.c_int32), _I, _I, _P(C.c_int32), _VP]),
     "smi_llm_retire": (_I, [_VP, _I, _VP]),
     "smi_llm_slot_tokens": (_I, [_VP, _I, _P(C.c_int64), _I, _P(C.c_int32), _P(C.c_int32), _VP]),
@@ -76,6 +78,7 @@ SYMBOLS = {
     "smi_llm_forward_logits": (_I, [_VP, _P(C.c_int64), _I, _VP, _VP]),
     "smi_llm_steps": (_I, [_VP]),
     "smi_llm_time_kernel": (_I, [_VP, _I, _I, _I, _P(C.c_float), _VP]),
+    "smi_llm_debug_stamps": (_I, [_VP, _I, _I, _P(C.c_double)]),
     "smi_voc_arena_count": (_I, [_P(VocCfg)]),
     "smi_voc_arena_entry": (_I, [_P(VocCfg), _I, C.c_char_p, _I, _P(_SZ), _P(_SZ), _P(C.c_int32)]),
     "smi_voc_arena_bytes": (_SZ, [_P(VocCfg)]),
@@ -117,8 +120,8 @@ def lib() -> C.CDLL:
                 continue            # A/B runs against an older build (diagnostics only)
             fn = getattr(l, name)   # AttributeError here = header/library mismatch
             fn.restype, fn.argtypes = res, args
-        if l.smi_version() != 1:
-            raise SparkMIError(f"libsparkmi ABI version {l.smi_version()} != 1")
+        if l.smi_version() != ABI_VERSION:
+            raise SparkMIError(f"libsparkmi ABI version {l.smi_version()} != {ABI_VERSION}")
         _lib = l
     return _lib
 

@@ -15,16 +15,40 @@ import numpy as np
 
 from . import _lib
 from .config import LLMConfig
-from .weights import f32_to_bf16_bits
+from .weights import bf16_bits_to_f32, f32_to_bf16_bits
 
 
-def pack_tiles(w: np.ndarray) -> np.ndarray:
+class Bf16RoundingReport:
+    """What packing a checkpoint into the bf16 arena changed.  north_star fixes the LLM arithmetic at bf16 weights
+    with fp32 accumulation; a checkpoint saved in bf16 packs exactly (``max_rel == 0``), one saved in fp32 is ROUNDED
+    here, and its logits then differ from the reference's fp32 CPU run by that rounding (``tests/test_llm_gpu.py::
+    test_fp32_checkpoint_is_rounded_and_reported`` measures the effect on a synthetic fp32 model)."""
+
+    def __init__(self):
+        self.max_rel = 0.0          # max over matrices of max|w - bf16(w)| / max|w|
+        self.inexact = 0            # matrices with at least one rounded element
+        self.worst = ""
+
+    def add(self, name: str, w: np.ndarray, bits: np.ndarray) -> None:
+        scale = float(np.abs(w).max())
+        if scale == 0.0:
+            return
+        err = float(np.abs(bf16_bits_to_f32(bits).reshape(w.shape) - w).max()) / scale
+        if err > 0.0:
+            self.inexact += 1
+            if err > self.max_rel:
+                self.max_rel, self.worst = err, name
+
+
+def pack_tiles(w: np.ndarray, report: "Bf16RoundingReport" = None, name: str = "") -> np.ndarray:
     """[N, K] fp32 -> uint16 bf16 bits in MFMA A-operand tile order; N padded to 16 with zeros."""
     n, k = w.shape
     if k % 32:
         raise ValueError(f"K={k} must be a multiple of 32")
     npad = (n + 15) // 16 * 16
     bits = f32_to_bf16_bits(w).reshape(n, k)
+    if report is not None:
+        report.add(name, w, bits)
     if npad != n:
         bits = np.concatenate([bits, np.zeros((npad - n, k), np.uint16)], axis=0)
     t = bits.reshape(npad // 16, 16, k // 32, 4, 8).transpose(0, 2, 3, 1, 4)
@@ -59,9 +83,13 @@ def llm_cfg_struct(cfg: LLMConfig, max_slots: int, max_positions: int, kv_dtype:
         kv_dtype={"bf16": 0, "f32": 1}[kv_dtype], use_graph=int(use_graph), rms_eps=cfg.rms_norm_eps)
 
 
-def pack_llm_arena(cfg: LLMConfig, weights: Mapping[str, np.ndarray], cs: _lib.LLMCfg) -> np.ndarray:
-    """Host uint8 image of the whole LLM arena (caller uploads it to the GPU)."""
+def pack_llm_arena(cfg: LLMConfig, weights: Mapping[str, np.ndarray], cs: _lib.LLMCfg,
+                   strict_bf16: bool = False, report: "Bf16RoundingReport" = None) -> np.ndarray:
+    """Host uint8 image of the whole LLM arena (caller uploads it to the GPU).  A checkpoint whose matrices are not
+    bf16-representable (an fp32 save) is rounded: that is reported with a warning, or refused with ``strict_bf16``."""
+    import warnings
     lib = _lib.lib()
+    rep = report if report is not None else Bf16RoundingReport()
     total = lib.smi_llm_arena_bytes(C.byref(cs))
     if total == 0:
         raise _lib.SparkMIError("smi_llm_arena_bytes: config outside the kernel contract")
@@ -84,19 +112,26 @@ def pack_llm_arena(cfg: LLMConfig, weights: Mapping[str, np.ndarray], cs: _lib.L
         wq, wk, wv = (f32(weights[p + f"self_attn.{n}_proj.weight"]) for n in "qkv")
         bq, bk, bv = (f32(weights[p + f"self_attn.{n}_proj.bias"]) for n in "qkv")
         put(_lib.LLM_LN1, i, f32(weights[p + "input_layernorm.weight"]))
-        put(_lib.LLM_WQKV, i, pack_tiles(np.concatenate([wq[pq], wk[pk], wv], axis=0)))
+        put(_lib.LLM_WQKV, i, pack_tiles(np.concatenate([wq[pq], wk[pk], wv], axis=0), rep, p + "self_attn.qkv"))
         put(_lib.LLM_BQKV, i, np.concatenate([bq[pq], bk[pk], bv]))
-        put(_lib.LLM_WO, i, pack_tiles(f32(weights[p + "self_attn.o_proj.weight"])))
+        put(_lib.LLM_WO, i, pack_tiles(f32(weights[p + "self_attn.o_proj.weight"]), rep, p + "self_attn.o_proj"))
         put(_lib.LLM_LN2, i, f32(weights[p + "post_attention_layernorm.weight"]))
         g, u = f32(weights[p + "mlp.gate_proj.weight"]), f32(weights[p + "mlp.up_proj.weight"])
         gu = np.empty((2 * g.shape[0], g.shape[1]), np.float32)
         gu[0::2], gu[1::2] = g, u
-        put(_lib.LLM_WGU, i, pack_tiles(gu))
-        put(_lib.LLM_WD, i, pack_tiles(f32(weights[p + "mlp.down_proj.weight"])))
+        put(_lib.LLM_WGU, i, pack_tiles(gu, rep, p + "mlp.gate_up"))
+        put(_lib.LLM_WD, i, pack_tiles(f32(weights[p + "mlp.down_proj.weight"]), rep, p + "mlp.down_proj"))
     put(_lib.LLM_FINAL_NORM, 0, f32(weights["model.norm.weight"]))
     head = "model.embed_tokens.weight" if cfg.tie_word_embeddings else "lm_head.weight"
     if not cfg.tie_word_embeddings:
         raise NotImplementedError("untied lm_head: the kernels gather embeddings from the lm_head tiles")
-    put(_lib.LLM_LM_HEAD, 0, pack_tiles(f32(weights[head])))
+    put(_lib.LLM_LM_HEAD, 0, pack_tiles(f32(weights[head]), rep, head))
     put(_lib.LLM_ROPE, 0, rope_table(cfg, cs.max_positions))
+    if rep.inexact:
+        msg = (f"{rep.inexact} LLM matrices are not bf16-representable (an fp32 checkpoint?): rounded to bf16 for the "
+               f"weight arena, max |w - bf16(w)| / max|w| = {rep.max_rel:.2e} at {rep.worst}; outputs will differ from an "
+               f"fp32 CPU run of the same checkpoint by that rounding")
+        if strict_bf16:
+            raise ValueError(msg)
+        warnings.warn(msg, stacklevel=2)
     return arena

@@ -10,7 +10,10 @@ top-p → multinomial chain on the device (``k_sample``).
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Mapping, Optional, Sequence, Union
+import json
+import warnings
+from pathlib import Path
+from typing import Iterable, List, Mapping, Optional, Sequence, Union
 
 import numpy as np
 import torch
@@ -20,13 +23,37 @@ from .arena import llm_cfg_struct, pack_llm_arena
 from .config import LLMConfig
 
 
+EosLike = Union[None, int, Iterable[int]]
+
+
+def eos_ids_from_generation_config(model_dir: Union[str, Path], cfg: Optional[LLMConfig] = None) -> List[int]:
+    """The ids HF ``generate()`` stops on when the caller passes no ``eos_token_id`` -- which is how the reference
+    calls it (``cli/SparkTTS.py:197-204``): every id of ``generation_config.json``'s ``eos_token_id`` (an int or a
+    list), else ``config.json``'s."""
+    ids: List[int] = []
+    g = Path(model_dir) / "generation_config.json"
+    if g.exists():
+        e = json.loads(g.read_text()).get("eos_token_id")
+        if e is not None:
+            ids = [int(x) for x in (e if isinstance(e, (list, tuple)) else [e])]
+    if not ids and cfg is not None and cfg.eos_token_id is not None:
+        e = cfg.eos_token_id
+        ids = [int(x) for x in (e if isinstance(e, (list, tuple)) else [e])]
+    return ids
+
+
 class SparkLLM:
     def __init__(self, cfg: LLMConfig, weights: Mapping[str, np.ndarray],
                  device: Union[str, torch.device] = "cuda:0", max_slots: int = 1,
                  max_positions: int = 4096, kv_dtype: str = "bf16", use_graph: bool = True,
-                 arena: Optional[torch.Tensor] = None):
+                 arena: Optional[torch.Tensor] = None, eos_token_ids: EosLike = None):
+        """``eos_token_ids``: the model's default stop ids (``generation_config.json``; see
+        ``eos_ids_from_generation_config``).  ``generate()`` falls back to them when the caller passes none, like HF."""
         cfg.validate()
         self.cfg = cfg
+        if eos_token_ids is None and cfg.eos_token_id is not None:
+            eos_token_ids = cfg.eos_token_id
+        self.default_eos = self._eos_list(eos_token_ids)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.SparkMIError("SparkLLM runs on an MI355X only (device must be cuda:N); there is no CPU path")
@@ -58,17 +85,42 @@ class SparkLLM:
         except Exception:
             pass
 
+    @classmethod
+    def from_pretrained(cls, llm_dir: Union[str, Path], device: Union[str, torch.device] = "cuda:0", **kw) -> "SparkLLM":
+        """Stands where ``AutoModelForCausalLM.from_pretrained(f"{model_dir}/LLM")`` stands (``cli/SparkTTS.py:49``):
+        config.json, safetensors and generation_config.json (stop ids) of a checkpoint directory."""
+        from .weights import load_llm_state
+        llm_dir = Path(llm_dir)
+        cfg = LLMConfig.from_json(llm_dir / "config.json")
+        return cls(cfg, load_llm_state(llm_dir), device, eos_token_ids=eos_ids_from_generation_config(llm_dir, cfg), **kw)
+
+    @staticmethod
+    def _eos_list(eos: EosLike) -> List[int]:
+        if eos is None:
+            return []
+        ids = [int(eos)] if isinstance(eos, (int, np.integer)) else [int(e) for e in eos]
+        if len(ids) > _lib.SMI_MAX_EOS:
+            raise ValueError(f"{len(ids)} eos ids; the step kernel checks at most {_lib.SMI_MAX_EOS}")
+        return ids
+
+    def _eos_args(self, eos: EosLike):
+        ids = self._eos_list(eos)
+        arr = (C.c_int64 * max(len(ids), 1))(*ids)
+        return arr, len(ids)
+
     # ------------------------------------------------------------------ generation
-    def prefill(self, prompts: Sequence[Sequence[int]], eos_token_id: Optional[int] = None) -> None:
+    def prefill(self, prompts: Sequence[Sequence[int]], eos_token_id: EosLike = None) -> None:
+        """``eos_token_id``: an id, a list of ids (any of them stops the sequence) or None (never stop)."""
         B = len(prompts)
         lens = np.array([len(p) for p in prompts], dtype=np.int32)
         pmax = int(lens.max())
         ids = np.zeros((B, pmax), dtype=np.int64)
         for b, p in enumerate(prompts):
             ids[b, : len(p)] = np.asarray(p, dtype=np.int64)
+        eos_arr, n_eos = self._eos_args(eos_token_id)
         _lib.check(self._lib.smi_llm_prefill(
             self._h, ids.ctypes.data_as(C.POINTER(C.c_int64)), lens.ctypes.data_as(C.POINTER(C.c_int32)),
-            B, pmax, -1 if eos_token_id is None else int(eos_token_id), self._stream()), "smi_llm_prefill")
+            B, pmax, eos_arr, n_eos, self._stream()), "smi_llm_prefill")
         self._B, self._lens = B, lens
 
     def decode(self, n_steps: int) -> None:
@@ -95,7 +147,7 @@ class SparkLLM:
                                                   float(top_p), int(seed) & (2 ** 64 - 1)), "smi_llm_set_sampling")
 
     def generate_ids(self, prompts: Sequence[Sequence[int]], max_new_tokens: int,
-                     eos_token_id: Optional[int] = None, check_every: int = 32, do_sample: bool = False,
+                     eos_token_id: EosLike = None, check_every: int = 32, do_sample: bool = False,
                      temperature: float = 0.8, top_k: int = 50, top_p: float = 0.95,
                      seed: Optional[int] = None) -> List[List[int]]:
         """Generation for B ragged prompts; returns only the new ids per sequence (eos included
@@ -110,7 +162,7 @@ class SparkLLM:
                              f"max_positions ({self.max_positions})")
         self.prefill(prompts, eos_token_id)
         remaining = max_new_tokens - 1
-        if eos_token_id is None:
+        if not self._eos_list(eos_token_id):
             self.decode(remaining)
         else:
             while remaining > 0 and not self.all_done():
@@ -121,10 +173,14 @@ class SparkLLM:
 
     @torch.no_grad()
     def generate(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
-                 max_new_tokens: int = 3000, do_sample: bool = False, eos_token_id: Optional[int] = None,
+                 max_new_tokens: int = 3000, do_sample: bool = False, eos_token_id: EosLike = None,
                  pad_token_id: Optional[int] = None, temperature: float = 1.0, top_k: int = 50,
                  top_p: float = 1.0, seed: Optional[int] = None, **unused) -> torch.Tensor:
-        """HF-shaped entry.  ``attention_mask`` marks real tokens of right- or left-padded rows."""
+        """HF-shaped entry.  ``attention_mask`` marks real tokens of right- or left-padded rows.  Like HF's
+        ``generate``: with no ``eos_token_id`` the model's own stop ids apply (``generation_config.json``, given at
+        construction) -- the reference's call at ``cli/SparkTTS.py:197-204`` relies on exactly that -- and generation
+        ends at the context limit when ``max_new_tokens`` would pass it (HF's limit is the model's 32k positions; here it
+        is ``max_positions``, so a long clone prompt shortens the budget instead of failing)."""
         ids = input_ids.detach().cpu().numpy().astype(np.int64)
         if ids.ndim == 1:
             ids = ids[None]
@@ -133,9 +189,13 @@ class SparkLLM:
             prompts = [ids[b][msk[b]].tolist() for b in range(ids.shape[0])]
         else:
             prompts = [ids[b].tolist() for b in range(ids.shape[0])]
-        new = self.generate_ids(prompts, max_new_tokens, eos_token_id, do_sample=do_sample, temperature=temperature,
+        eos = self._eos_list(eos_token_id) or self.default_eos
+        room = self.max_positions - max(len(p) for p in prompts)
+        if room < 1:
+            raise ValueError(f"prompt of {max(len(p) for p in prompts)} tokens leaves no room in max_positions={self.max_positions}")
+        new = self.generate_ids(prompts, min(int(max_new_tokens), room), eos, do_sample=do_sample, temperature=temperature,
                                 top_k=top_k, top_p=top_p, seed=seed)
-        pad = pad_token_id if pad_token_id is not None else (eos_token_id if eos_token_id is not None else 0)
+        pad = pad_token_id if pad_token_id is not None else (eos[0] if eos else 0)
         n = max(len(t) for t in new)
         out = np.full((ids.shape[0], ids.shape[1] + n), pad, dtype=np.int64)
         out[:, : ids.shape[1]] = ids
@@ -144,10 +204,10 @@ class SparkLLM:
         return torch.from_numpy(out).to(input_ids.device)
 
     # ------------------------------------------------------------------ continuous batching
-    def session_begin(self, eos_token_id: Optional[int] = None) -> None:
+    def session_begin(self, eos_token_id: EosLike = None) -> None:
         """Empty in-flight-batching session: sequences are admitted and retired between decode steps."""
-        _lib.check(self._lib.smi_llm_session_begin(self._h, -1 if eos_token_id is None else int(eos_token_id), self._stream()),
-                   "smi_llm_session_begin")
+        eos_arr, n_eos = self._eos_args(eos_token_id)
+        _lib.check(self._lib.smi_llm_session_begin(self._h, eos_arr, n_eos, self._stream()), "smi_llm_session_begin")
 
     def admit(self, prompts: Sequence[Sequence[int]]) -> List[int]:
         """Prefill new prompts into free KV slots (first token emitted); returns their slot ids."""

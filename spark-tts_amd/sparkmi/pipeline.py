@@ -19,7 +19,7 @@ import torch
 from . import _lib
 from .bicodec import BiCodecTokenizer
 from .config import LLMConfig, TopConfig
-from .llm import SparkLLM
+from .llm import SparkLLM, eos_ids_from_generation_config
 from .pipeline_text import (GENDER_MAP, LEVELS_MAP, TASK_TOKEN_MAP, build_clone_prompt,
                             build_control_prompt, parse_global, parse_semantic)
 from .streaming import ChunkScheduler
@@ -79,16 +79,13 @@ class SparkTTS:
         llm_dir = Path(self.model_dir) / "LLM"
         self.tokenizer = AutoTokenizer.from_pretrained(str(llm_dir))
         cfg = LLMConfig.from_json(llm_dir / "config.json")
-        gen_cfg = llm_dir / "generation_config.json"
-        self._eos = cfg.eos_token_id
-        if gen_cfg.exists():
-            import json
-            e = json.loads(gen_cfg.read_text()).get("eos_token_id", self._eos)
-            self._eos = e[0] if isinstance(e, list) else e
-        if self._eos is None:
-            self._eos = self.tokenizer.eos_token_id
+        # HF generate() as the reference calls it (no eos argument, cli/SparkTTS.py:197-204) stops on EVERY id of
+        # generation_config.json's eos_token_id; all of them go down to the step kernel
+        self._eos = eos_ids_from_generation_config(llm_dir, cfg)
+        if not self._eos and self.tokenizer.eos_token_id is not None:
+            self._eos = [int(self.tokenizer.eos_token_id)]
         self.model = SparkLLM(cfg, load_llm_state(llm_dir), self.device, max_slots=self._max_batch,
-                              max_positions=self._max_positions, kv_dtype=self._kv_dtype)
+                              max_positions=self._max_positions, kv_dtype=self._kv_dtype, eos_token_ids=self._eos)
         self.audio_tokenizer = BiCodecTokenizer(self.model_dir, device=self.device, max_batch=self._max_batch,
                                                 max_frames=self._max_frames)
         self._map = _TokenMap(self.tokenizer)
@@ -150,6 +147,13 @@ class SparkTTS:
                 prompts.append(p)
                 globals_.append(g)
         ids = [self.tokenizer([p], return_tensors="pt").input_ids[0].tolist() for p in prompts]
+        # the reference's budget (3000) against a 32k-position model never binds; here the KV arena holds max_positions
+        # tokens per sequence, so the budget shrinks with the prompt (as inference_stream and serve do) -- only a
+        # prompt that itself does not fit is an error
+        room = self._max_positions - max(len(i) for i in ids)
+        if room < 1:
+            raise ValueError(f"a prompt of {max(len(i) for i in ids)} tokens does not fit max_positions={self._max_positions}")
+        max_new_tokens = min(int(max_new_tokens), room)
         if do_sample:
             new = self.model.generate_ids(ids, max_new_tokens, self._eos, do_sample=True, temperature=temperature,
                                           top_k=int(top_k), top_p=float(top_p), seed=seed)
@@ -260,8 +264,9 @@ class SparkTTS:
                 yield i, ids, min(max_new_tokens, self._max_positions - len(ids) - decode_stride), self._eos
 
         for i, toks in self.model.serve(llm_requests(), max_live=self._max_batch, decode_stride=decode_stride):
-            if self._eos is not None and self._eos in toks:
-                toks = toks[: toks.index(self._eos) + 1]
+            stops = [toks.index(e) for e in self._eos if e in toks]
+            if stops:
+                toks = toks[: min(stops) + 1]
             sem, glob = self._parse(toks)
             g = torch.tensor(glob, dtype=torch.long) if globals_[i] is None else torch.as_tensor(globals_[i]).reshape(-1).long()
             if g.numel() != ntok:

@@ -84,7 +84,9 @@ class SyntheticLLM:
     bf16 GPU arena and the fp32 oracle hold *identical* weight values."""
 
     def __init__(self, cfg: LLMConfig, seed: int = 0, embed_std: float = None,
-                 w_std: float = None, bias_std: float = 0.02):
+                 w_std: float = None, bias_std: float = 0.02, bf16_exact: bool = True):
+        # bf16_exact=False: full-precision fp32 matrices, i.e. what an fp32-saved checkpoint looks like (the arena
+        # packer then rounds them; used to measure that rounding against the fp32 oracle)
         # 1.6/sqrt(hidden): layer outputs are O(1) per element, so greedy decoding of the random
         # net wanders over the vocabulary instead of locking onto one token (a fixed point would
         # make the KV-cache / position parity tests vacuous), and logits have std ~1.6.
@@ -93,6 +95,7 @@ class SyntheticLLM:
         self.embed_std = s if embed_std is None else embed_std
         self.w_std = s if w_std is None else w_std
         self.bias_std = bias_std
+        self.bf16_exact = bf16_exact
         self._shapes = dict(llm_tensor_names(cfg))
 
     def names(self) -> List[str]:
@@ -108,7 +111,8 @@ class SyntheticLLM:
         if name.endswith(".bias"):
             return normal(name, shape, self.bias_std, 0.0, self.seed)
         std = self.embed_std if ("embed_tokens" in name or "lm_head" in name) else self.w_std
-        return round_bf16(normal(name, shape, std, 0.0, self.seed))
+        w = normal(name, shape, std, 0.0, self.seed)
+        return round_bf16(w) if self.bf16_exact else w
 
 
 def load_llm_state(llm_dir) -> Dict[str, np.ndarray]:

@@ -28,7 +28,16 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(l, n), f"{n} declared in sparkmi.h but not exported"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes signature in sparkmi/_lib.py"
-    assert l.smi_version() == 1
+    assert l.smi_version() == _lib.ABI_VERSION == 2
+
+
+def test_product_library_exports_only_the_declared_abi():
+    """Diagnostics (micro-benchmarks) live in libsparkmi_diag.so; the product library's dynamic symbol table holds the
+    header's entry points and nothing else of ours."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", str(_lib.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    ours = sorted(set(re.findall(r" T (smi_[a-z0-9_]+)$", out, flags=re.M)))
+    assert ours == _header_symbols(), set(ours) ^ set(_header_symbols())
 
 
 def test_llm_arena_layout_is_consistent():

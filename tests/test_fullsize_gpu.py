@@ -1,0 +1,119 @@
+"""GPU parity at the sizes BASELINE.json's configs name (Spark-TTS-0.5B shape, synthetic weights), on the paths the
+bench actually runs: the prefill GEMM (k_pgemm) at 32 x 128 and 8 x ~460 prompt rows, free-running bf16-KV + hipGraph
+decode through the vocoder (north_star's acceptance sentence: fp32 waveform within 1e-3 of the CPU path for fixed greedy
+seeds), and the 32-row padded vocoder batch.  Oracle: oracle/llm_ref.py (pinned to transformers), oracle/bicodec_ref.py
+(pinned to the reference's modules), tests/golden/llm_full.npz (transformers' own tokens)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import FULL_MAX_POS
+
+pytestmark = pytest.mark.gpu
+
+
+def _llm(cfg, arena, **kw):
+    from sparkmi.llm import SparkLLM
+    return SparkLLM(cfg, None, "cuda:0", max_positions=FULL_MAX_POS, arena=arena, **kw)
+
+
+@pytest.mark.parametrize("kv", ["f32", "bf16"])
+def test_config3_prompts_through_the_prefill_gemm(full_llm, golden_dir, kv):
+    """configs[2]'s prefill: 32 prompts x 128 tokens = 4064 prompt rows -> k_pgemm (28 / 152 k tiles, three-register-set
+    weight rotation).  Every row's tokens equal its own B = 1 run (127 rows: the row-grouped decode GEMMs, another
+    kernel); row 0 is the golden prompt and equals transformers' greedy tokens (f32 KV, like the golden)."""
+    cfg, syn, arena = full_llm
+    g = np.load(os.path.join(golden_dir, "llm_full.npz"))
+    rng = np.random.Generator(np.random.PCG64(2024))
+    prompts = [g["prompt"].tolist()] + [rng.integers(0, cfg.vocab_size, size=128).tolist() for _ in range(31)]
+    assert sum(len(p) - 1 for p in prompts) >= 3072      # the k_pgemm threshold (SPARKMI_PGEMM_MIN_ROWS default)
+    n = 12
+    big = _llm(cfg, arena, max_slots=32, kv_dtype=kv)
+    one = _llm(cfg, arena, max_slots=1, kv_dtype=kv)
+    batched = big.generate_ids(prompts, n)
+    for b in range(32):
+        assert one.generate_ids([prompts[b]], n)[0] == batched[b], f"row {b}"
+    if kv == "f32":
+        assert batched[0] == g["greedy"][:n].tolist()
+
+
+def test_config5_clone_length_prompts_through_the_prefill_gemm(full_llm, full_llm_oracle):
+    """configs[4]'s prefill shape: 8 voice-clone prompts of ~460 tokens (text + 32 global + ~300 semantic prompt tokens)
+    = 3672+ rows -> k_pgemm with ragged lengths; every row equals its B = 1 run and two rows equal the CPU oracle."""
+    cfg, syn, arena = full_llm
+    rng = np.random.Generator(np.random.PCG64(460))
+    lens = [460, 441, 478, 452, 469, 447, 473, 458]
+    prompts = [rng.integers(0, cfg.vocab_size, size=L).tolist() for L in lens]
+    assert sum(L - 1 for L in lens) >= 3072
+    n = 10
+    batched = _llm(cfg, arena, max_slots=8).generate_ids(prompts, n)
+    one = _llm(cfg, arena, max_slots=1)
+    for b in range(8):
+        assert one.generate_ids([prompts[b]], n)[0] == batched[b], f"row {b}"
+    ref = full_llm_oracle
+    ref.kv_dtype = "bf16"
+    for b in (0, 6):
+        assert ref.generate_greedy(prompts[b], n) == batched[b], f"row {b} vs oracle"
+
+
+def test_config2_free_running_bf16_kv_graph_to_waveform(full_llm, full_llm_oracle, full_voc, golden_dir):
+    """configs[1] exactly as the bench runs it -- bf16 KV cache, decode step replayed as a hipGraph, 128-token prompt,
+    150 free-running greedy tokens -> 150 frames -> 48 000 samples -- against the CPU path end to end
+    (cli/SparkTTS.py:197-234): tokens equal the oracle's (bf16-KV emulation), waveform within north_star's 1e-3."""
+    from oracle.bicodec_ref import BiCodecDetokRef
+    from sparkmi.bicodec import BiCodecVocoder
+    cfg, syn, arena = full_llm
+    vcfg, sd, folded = full_voc
+    g = np.load(os.path.join(golden_dir, "llm_full.npz"))
+    prompt = g["prompt"].tolist()
+    llm = _llm(cfg, arena, max_slots=1, kv_dtype="bf16", use_graph=True)
+    toks = llm.generate_ids([prompt], 150)[0]
+    again = llm.generate_ids([prompt], 150)[0]            # second utterance on the SAME captured graph
+    assert toks == again and len(toks) == 150
+    ref = full_llm_oracle
+    ref.kv_dtype = "bf16"
+    want = ref.generate_greedy(prompt, 150)
+    assert toks == want
+    glob = np.random.Generator(np.random.PCG64(1235)).integers(0, 4096, size=(1, 1, vcfg.spk_token_num))
+    sem = torch.tensor([[t % vcfg.codebook_size for t in toks]])
+    voc = BiCodecVocoder(vcfg, sd, "cuda:0", max_batch=1, max_frames=160)
+    wav = voc.detokenize(sem, torch.from_numpy(glob)).cpu().numpy()
+    owav = BiCodecDetokRef(vcfg, folded).detokenize(sem, torch.from_numpy(glob)).numpy()
+    assert wav.shape == owav.shape == (1, 1, 48000)
+    err = float(np.abs(wav - owav).max())
+    assert err < 1e-3, f"waveform max |diff| {err}"       # north_star
+    assert err < 3e-4, f"waveform max |diff| {err}"       # what exact-product fp32 accumulation gives
+
+
+def test_config3_vocoder_batch_of_32_ragged_rows(full_voc):
+    """configs[2]'s vocoder call: 32 rows of 120..180 frames, padded to the longest (another launch plan than B <= 2:
+    tile width, channel split and three-wave blocks are chosen from (B, longest row)).  Every row equals its own
+    un-padded run to fp32 re-association and three rows equal the CPU oracle."""
+    from oracle.bicodec_ref import BiCodecDetokRef
+    from sparkmi.bicodec import BiCodecVocoder
+    vcfg, sd, folded = full_voc
+    rng = np.random.Generator(np.random.PCG64(3232))
+    lens = [int(x) for x in rng.integers(120, 181, size=32)]
+    lens[5], lens[17] = 180, 120
+    B, T = 32, max(lens)
+    sem = rng.integers(0, vcfg.codebook_size, size=(B, T))
+    glob = rng.integers(0, 4096, size=(B, 1, vcfg.spk_token_num))
+    voc = BiCodecVocoder(vcfg, sd, "cuda:0", max_batch=B, max_frames=T)
+    wav = voc.detokenize(torch.from_numpy(sem), torch.from_numpy(glob), lengths=lens).cpu().numpy()
+    again = voc.detokenize(torch.from_numpy(sem), torch.from_numpy(glob), lengths=lens).cpu().numpy()
+    assert np.array_equal(wav, again)
+    one = BiCodecVocoder(vcfg, None, "cuda:0", max_batch=1, max_frames=T, arena=voc.arena)   # the arena layout does not depend on the batch
+    hop = vcfg.hop
+    for b, n in enumerate(lens):
+        assert not wav[b, 0, n * hop:].any(), f"row {b}: samples behind its own length"
+        solo = one.detokenize(torch.from_numpy(sem[b:b + 1, :n]), torch.from_numpy(glob[b:b + 1])).cpu().numpy()
+        d = float(np.abs(wav[b, 0, : n * hop] - solo[0, 0]).max())
+        assert d < 2e-5, f"row {b} ({n} frames) differs from its un-padded run by {d}"
+    ref = BiCodecDetokRef(vcfg, folded)
+    for b in (5, 17, 30):
+        n = lens[b]
+        o = ref.detokenize(torch.from_numpy(sem[b:b + 1, :n]), torch.from_numpy(glob[b:b + 1])).numpy()
+        d = float(np.abs(wav[b, 0, : n * hop] - o[0, 0]).max())
+        assert d < 3e-4, f"row {b} vs oracle: {d}"

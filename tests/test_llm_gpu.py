@@ -160,39 +160,37 @@ def test_bad_arguments_are_reported(tiny):
         _llm(cfg, syn, max_positions=64).decode(1)   # decode before prefill
 
 
-def test_full_size_0p5b_against_transformers_golden(golden_dir):
+def test_full_size_0p5b_against_transformers_golden(golden_dir, full_llm):
     """Spark-TTS-0.5B shape (24 layers, vocab 166000), synthetic weights: last-position logits and
     the 150 greedy tokens transformers produced in the build container."""
-    cfg = C.spark_0p5b_llm()
-    syn = W.SyntheticLLM(cfg)
+    from conftest import FULL_MAX_POS
+    cfg, syn, arena = full_llm
     g = np.load(os.path.join(golden_dir, "llm_full.npz"))
-    llm = _llm(cfg, syn, max_positions=512, kv_dtype="f32")
+    llm = _llm(cfg, None, max_positions=FULL_MAX_POS, kv_dtype="f32", arena=arena)
     logits = llm.forward_logits(g["prompt"])[-1].cpu().numpy()
     np.testing.assert_allclose(logits[g["last_top_ids"]], g["last_top_vals"], rtol=0, atol=LOGIT_ATOL)
     assert abs(float(np.abs(logits.astype(np.float64)).sum()) - float(g["last_logits_abs"])) < 1e-4 * float(g["last_logits_abs"])
     got = llm.generate_ids([g["prompt"].tolist()], 150)[0]
     assert got == g["greedy"].tolist()
     # production setting (bf16 KV, hipGraph): teacher-forced agreement with the fp32 result
-    llm16 = _llm(cfg, syn, max_positions=512, kv_dtype="bf16")
+    llm16 = _llm(cfg, None, max_positions=FULL_MAX_POS, kv_dtype="bf16", arena=arena)
     seq = np.concatenate([g["prompt"], g["greedy"][:-1]])
     lg = llm16.forward_logits(seq)[127:].argmax(-1).cpu().numpy()
     agree = float((lg == g["greedy"]).mean())
     assert agree > 0.9, f"bf16-KV teacher-forced token agreement {agree}"
 
 
-def test_full_size_batch_is_bit_identical_to_single_runs():
+def test_full_size_batch_is_bit_identical_to_single_runs(full_llm):
     """0.5B shape, 20 ragged sequences (two m-tiles, K-chunked LDS staging) vs B=1 runs: identical
     tokens AND identical logits bits -- the summation order of a row never depends on the batch."""
-    cfg = C.spark_0p5b_llm()
-    syn = W.SyntheticLLM(cfg)
+    from conftest import FULL_MAX_POS
+    cfg, syn, arena = full_llm
     rng = np.random.Generator(np.random.PCG64(99))
     B = 20
     prompts = [rng.integers(0, cfg.vocab_size, size=int(rng.integers(3, 70))).tolist() for _ in range(B)]
     from sparkmi.llm import SparkLLM
-    from sparkmi.arena import llm_cfg_struct, pack_llm_arena
-    arena = torch.from_numpy(pack_llm_arena(cfg, syn, llm_cfg_struct(cfg, 1, 160, "bf16", True))).to("cuda:0")
-    big = SparkLLM(cfg, None, "cuda:0", max_slots=B, max_positions=160, arena=arena)
-    one = SparkLLM(cfg, None, "cuda:0", max_slots=1, max_positions=160, arena=arena)
+    big = SparkLLM(cfg, None, "cuda:0", max_slots=B, max_positions=FULL_MAX_POS, arena=arena)
+    one = SparkLLM(cfg, None, "cuda:0", max_slots=1, max_positions=FULL_MAX_POS, arena=arena)
     batched = big.generate_ids(prompts, 12)
     for b in (0, 5, 13, 19):
         assert one.generate_ids([prompts[b]], 12)[0] == batched[b], f"sequence {b}"
@@ -267,13 +265,13 @@ def test_continuous_batching_equals_standalone_runs(tiny):
         llm.admit([[1, 2]] * 4)            # 2 live + 4 new > 4 slots
 
 
-def test_full_size_sampling_fast_path_matches_the_warper_chain():
+def test_full_size_sampling_fast_path_matches_the_warper_chain(full_llm):
     """0.5B vocabulary (166 000 logits, 512 lm_head blocks): the sampler's one-pass candidate collection (threshold from
     the blocks' maxima) must give the same distribution as transformers' temperature -> top-k -> top-p chain."""
-    cfg = C.spark_0p5b_llm()
-    syn = W.SyntheticLLM(cfg)
+    from conftest import FULL_MAX_POS
+    cfg, syn, arena = full_llm
     prompt = np.random.Generator(np.random.PCG64(5)).integers(0, cfg.vocab_size, size=24).tolist()
-    llm = _llm(cfg, syn, max_slots=32, max_positions=64)
+    llm = _llm(cfg, None, max_slots=32, max_positions=FULL_MAX_POS, arena=arena)
     logits = llm.forward_logits(prompt)[-1].cpu()
     T_, K, P = 0.8, 50, 0.95
     want = _expected_sampling_probs(logits, T_, K, P).numpy()
@@ -335,3 +333,73 @@ def test_sixty_four_concurrent_sequences_equal_single_runs(tiny):
     from sparkmi._lib import SparkMIError
     with pytest.raises(SparkMIError):
         _llm(cfg, syn, max_slots=65, max_positions=64)
+
+
+def test_generate_called_exactly_as_the_reference_calls_it(tiny):
+    """cli/SparkTTS.py:197-204: ``model.generate(**model_inputs, max_new_tokens=3000, do_sample=True, top_k=..,
+    top_p=.., temperature=..)`` -- no eos argument, a budget far beyond this engine's cache.  HF stops on ANY id of
+    generation_config.json's eos_token_id (a list), so the drop-in must too, and must not raise over the budget."""
+    cfg, syn = tiny
+    prompt = [11, 22, 33, 44, 55]
+    free = _llm(cfg, syn, max_positions=128, kv_dtype="f32").generate_ids([prompt], 40)[0]
+    # two stop ids; the SECOND of the list is emitted first (position 9), the first one later (position 20)
+    second, first = free[9], free[20]
+    assert second not in free[:9] and first not in free[:9]
+    llm = _llm(cfg, syn, max_positions=128, kv_dtype="f32", eos_token_ids=[first, second])
+    ids = torch.tensor([prompt])
+    out = llm.generate(input_ids=ids, attention_mask=torch.ones_like(ids), max_new_tokens=3000, do_sample=True,
+                       top_k=1, top_p=0.95, temperature=0.8)      # top_k = 1: the sampled path, deterministic
+    new = out[0, len(prompt):].tolist()
+    assert new == free[:10]
+    assert Qwen2Ref(cfg, syn).generate_greedy(prompt, 3000, eos_ids=[first, second]) == new
+    # no stop id emitted within the cache: generation ends at the context limit instead of raising
+    llm2 = _llm(cfg, syn, max_positions=64, kv_dtype="f32", eos_token_ids=[cfg.vocab_size - 1])
+    out2 = llm2.generate(input_ids=ids, max_new_tokens=3000)
+    assert out2.shape[1] == 64 or (cfg.vocab_size - 1) in out2[0].tolist()
+    with pytest.raises(ValueError):
+        llm.generate_ids([prompt], 10, eos_token_id=[1, 2, 3, 4, 5])     # more stop ids than the step kernel checks
+
+
+def test_fp32_checkpoint_is_rounded_and_reported(tiny):
+    """An fp32-saved checkpoint is NOT what the bf16 weight arena holds: packing rounds it (north_star fixes bf16
+    weights) and says so.  The GPU then computes exactly the bf16-rounded model; its distance from the fp32 model is
+    what a user of an fp32 checkpoint sees against the reference's CPU run."""
+    import warnings
+    from sparkmi import arena as A
+    cfg, _ = tiny
+    raw = W.SyntheticLLM(cfg, bf16_exact=False)
+    ids = np.random.Generator(np.random.PCG64(17)).integers(0, cfg.vocab_size, size=40)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        llm = _llm(cfg, raw, max_positions=96, kv_dtype="f32")
+    assert any("not bf16-representable" in str(w.message) for w in rec)
+    with pytest.raises(ValueError, match="bf16-representable"):
+        A.pack_llm_arena(cfg, raw, A.llm_cfg_struct(cfg, 1, 96, "f32", True), strict_bf16=True)
+    got = llm.forward_logits(ids).cpu().numpy()
+    rounded = {n: (W.round_bf16(raw[n]) if raw[n].ndim == 2 else raw[n]) for n in raw.names()}
+    same = Qwen2Ref(cfg, rounded).forward(ids).numpy()
+    assert np.abs(got - same).max() < LOGIT_ATOL                   # the GPU runs the rounded model exactly
+    full = Qwen2Ref(cfg, raw).forward(ids).numpy()
+    dev = float(np.abs(got - full).max())
+    agree = float((got.argmax(-1) == full.argmax(-1)).mean())
+    print(f"fp32 checkpoint through the bf16 arena: max |logit diff| {dev:.3e}, greedy agreement {agree:.3f}")
+    assert LOGIT_ATOL < dev < 0.5 and agree > 0.8                  # visible, bounded: bf16 weight rounding (2^-9 relative)
+
+
+def test_sampled_tokens_do_not_depend_on_batch_composition(tiny):
+    """The sampler's stream is keyed by (seed; the sequence's admission number, its own token index): a request
+    draws the same tokens whether it runs alone, beside others, or lands in another row after a neighbour retires."""
+    cfg, syn = tiny
+    rng = np.random.Generator(np.random.PCG64(31))
+    reqs = [(i, rng.integers(0, cfg.vocab_size, size=int(rng.integers(3, 30))).tolist(), int(rng.integers(6, 30)), None)
+            for i in range(6)]
+    llm = _llm(cfg, syn, max_slots=4, max_positions=96)
+    llm.set_sampling(True, 0.9, 40, 0.95, seed=77)
+    alone = dict(llm.serve(iter(reqs), max_live=1, decode_stride=3))
+    llm.set_sampling(True, 0.9, 40, 0.95, seed=77)
+    crowd = dict(llm.serve(iter(reqs), max_live=4, decode_stride=3))
+    for i, _, n, _ in reqs:
+        assert crowd[i][:n] == alone[i][:n], f"request {i}"
+    llm.set_sampling(True, 0.9, 40, 0.95, seed=78)
+    other = dict(llm.serve(iter(reqs), max_live=4, decode_stride=3))
+    assert any(other[i] != crowd[i] for i, *_ in reqs)

@@ -105,6 +105,44 @@ def test_control_mode_needs_the_speaker_tokens(model_dir):
         tts.inference("hello", gender="male", pitch="low", speed="high", do_sample=False, max_new_tokens=16)
 
 
+def test_control_mode_positive_path(model_dir, monkeypatch):
+    """cli/SparkTTS.py:222-228: in voice-creation mode the LM first emits the 32 global tokens, then the semantic ones;
+    the global ids are parsed OUT OF THE LM OUTPUT and handed to the speaker decoder.  Random weights never produce that
+    sequence, so the LM output is injected here; everything downstream (parse, tensors, detokenize) runs for real and
+    must equal the oracle vocoder on the same ids."""
+    from sparkmi.pipeline import SparkTTS
+    d, (lcfg, vcfg) = model_dir
+    tts = SparkTTS(d, torch.device("cuda:0"), max_positions=512, max_frames=256)
+    sem_id = {v: k for k, v in tts._map.sem.items()}
+    glob_id = {v: k for k, v in tts._map.glob.items()}
+    rng = np.random.Generator(np.random.PCG64(55))
+    glob = rng.integers(0, 4096, size=vcfg.spk_token_num).tolist()
+    sem = rng.integers(0, vcfg.codebook_size, size=37).tolist()
+    eos = tts._eos[0]
+    lm_out = [glob_id[g] for g in glob] + [sem_id[s_] for s_ in sem] + [eos]
+    seen = {}
+
+    def fake_generate_ids(prompts, max_new_tokens, eos_token_id=None, **kw):
+        seen["prompt"], seen["eos"], seen["kw"] = list(prompts[0]), eos_token_id, kw
+        return [list(lm_out)]
+
+    monkeypatch.setattr(tts.model, "generate_ids", fake_generate_ids)
+    wav = tts.inference("A calm voice.", gender="female", pitch="moderate", speed="low", do_sample=False)
+    want_prompt = tts.tokenizer([tts.process_prompt_control("female", "moderate", "low", "A calm voice.")],
+                                return_tensors="pt").input_ids[0].tolist()
+    assert seen["prompt"] == want_prompt and list(seen["eos"]) == list(tts._eos)
+    voc = BiCodecDetokRef(vcfg, W.fold_weight_norm(W.load_bicodec_state(d / "BiCodec")))
+    want = voc.detokenize_numpy(torch.tensor([glob]), torch.tensor([sem]))
+    assert wav.dtype == np.float32 and wav.shape == want.shape == (len(sem) * vcfg.hop,)
+    assert np.abs(wav - want).max() < 2e-4
+    # the reference's regex route (decode + findall) gives the same ids as the id-table fast path
+    text = tts.tokenizer.batch_decode([lm_out], skip_special_tokens=True)[0]
+    from sparkmi.pipeline_text import parse_global
+    assert parse_semantic(text) == sem and parse_global(text) == glob
+    # the streaming front end takes its speaker tokens from the LM output too
+    monkeypatch.undo()
+
+
 def _write_wav(path, x, sr=16000):
     import wave
     with wave.open(str(path), "wb") as w:

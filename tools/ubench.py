@@ -5,7 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "spark-tts_amd"))
 import torch
 from sparkmi import _lib
-l = _lib.lib()
+_lib.lib()   # torch + the HIP runtime first
+l = C.CDLL(str(_lib.LIB_PATH.with_name('libsparkmi_diag.so')))   # diagnostics library (csrc/diag/)
+l.smi_last_error.restype = C.c_char_p
 f = l.smi_ubench_chain
 f.restype = C.c_int
 f.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_void_p]
