@@ -6,22 +6,38 @@ for the whole node + real-time factor).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One step = one batch of `--batch` utterances through the whole hot path on one GPU:
-128-token synthetic prompt -> prefill -> 149 greedy decode steps (150 new tokens, EOS
-suppressed) -> host token parse (id mod codebook size, synthetic weights) -> BiCodec vocoder
-(150 frames -> 48 000 samples = 3.0 s at 16 kHz).  Weights are synthetic (no checkpoint exists
-offline), generated on rank 0 and broadcast over RCCL; inputs are already in HBM when the timed
-region starts (prompt ids are 1 KiB of host data per utterance, passed by value at prefill).
+One step = one batch of `--batch` utterances through the whole hot path on one GPU: synthetic prompt
+-> prefill -> greedy decode (EOS suppressed) -> host token parse (id mod codebook size, synthetic
+weights) -> BiCodec vocoder.  Workloads:
+
+  --batch 1  (default; BASELINE configs[1])  128-token prompt -> 150 tokens -> 48 000 samples (3.0 s)
+  --batch 32 (configs[2])  ragged: prompt lengths U{96..160}, N_i U{120..180} tokens per utterance, seeds
+             2000+i; the batch decodes max(N_i) steps, row i keeps its first N_i tokens (a static batch
+             whose rows stop at their own length), the vocoder batch is padded to max(N_i) with per-row
+             lengths.  `--uniform` keeps 32 x (128 -> 150) for comparison with round-1 numbers.
+  --clone --batch 8 (configs[4])  each utterance first encodes a 6 s prompt wav on the GPU.
+  --gpus N   one rank per GPU: `value` = the same per-rank loop on every rank (weak scaling, N x the work).
+             Started without WORLD_SIZE it spawns the N ranks itself (torch.distributed.run, before any
+             GPU call) and exits with their code.  Every line also carries `config4` (configs[3]): the
+             256-utterance set (cfg-3-style inputs, seeds 3000+i) dealt over the ranks by
+             sparkmi.dist.shard_indices, batches of <= 32 per GPU, one pass = strong scaling.
+
+Weights are synthetic (no checkpoint exists offline), generated on rank 0 and broadcast over RCCL;
+inputs are already in HBM when the timed region starts (prompt ids are ~1 KiB of host data per
+utterance, passed by value at prefill).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant decode kernel, measured live with HIP
 events on the launch stream; `cpu_baseline` times the CPU oracle (a port of the reference's
-PyTorch-CPU arithmetic) on this box's host cores on a bounded sample of the same workload.
+PyTorch-CPU arithmetic) on this box's host cores: the whole configs[1] utterance, 1 warm-up + median of 3.
 """
 from __future__ import annotations
 
 import argparse
+import glob
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -47,7 +63,11 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probes", action="store_true")
-    ap.add_argument("--cpu-tokens", type=int, default=32, help="decode tokens in the bounded CPU sample")
+    ap.add_argument("--cpu-tokens", type=int, default=150, help="tokens of the CPU-oracle utterance (SURVEY 8d: the whole configs[1] utterance)")
+    ap.add_argument("--cpu-runs", type=int, default=3, help="timed CPU-oracle runs (median reported) after one warm-up run")
+    ap.add_argument("--uniform", action="store_true", help="--batch > 1 with identical lengths (--prompt-len -> --new-tokens) instead of the ragged configs[2] inputs")
+    ap.add_argument("--no-config4", action="store_true", help="skip the 256-utterance sharded set (BASELINE configs[3])")
+    ap.add_argument("--set-size", type=int, default=256, help="utterances of the configs[3] set")
     ap.add_argument("--clone", action="store_true",
                     help="voice-clone path (BASELINE configs[4]): every utterance first encodes a prompt wav on the GPU "
                          "(wav2vec2 + BiCodec encoder + speaker encoder), its tokens join the LLM prompt; use with --batch 8")
@@ -75,8 +95,9 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(llm_cfg, voc_cfg, prompt, glob, n_tokens):
-    """The oracle (CPU restatement pinned to the reference by tests/golden) on the host cores."""
+def cpu_baseline(llm_cfg, voc_cfg, prompt, glob, n_tokens, runs):
+    """The oracle (CPU restatement pinned to the reference by tests/golden) on the host cores: SURVEY 8d's protocol --
+    the configs[1] utterance (prefill + n_tokens greedy tokens + their vocoder frames), 1 warm-up + `runs` timed, median."""
     from oracle.llm_ref import Qwen2Ref
     from oracle.bicodec_ref import BiCodecDetokRef
     from sparkmi import weights as W
@@ -87,21 +108,26 @@ def cpu_baseline(llm_cfg, voc_cfg, prompt, glob, n_tokens):
     ref = Qwen2Ref(llm_cfg, W.SyntheticLLM(llm_cfg))
     voc = BiCodecDetokRef(voc_cfg, W.fold_weight_norm(W.bicodec_detok_state(voc_cfg)))
     build_s = time.time() - t0
-    log(f"cpu_baseline: weights ready in {build_s:.1f}s; generating {n_tokens} tokens")
-    t0 = time.time()
-    toks = ref.generate_greedy(prompt, n_tokens)
-    t_llm = time.time() - t0
-    sem = torch.tensor([[t % voc_cfg.codebook_size for t in toks]])
-    t0 = time.time()
-    wav = voc.detokenize(sem, torch.as_tensor(glob)[None, None])
-    t_voc = time.time() - t0
-    samples = wav.shape[-1]
-    total = t_llm + t_voc
+    times, toks, samples = [], None, 0
+    for r in range(runs + 1):
+        log(f"cpu_baseline: run {r} of 1 warm-up + {runs} ({n_tokens} tokens)")
+        t0 = time.time()
+        toks = ref.generate_greedy(prompt, n_tokens)
+        t_llm = time.time() - t0
+        sem = torch.tensor([[t % voc_cfg.codebook_size for t in toks]])
+        t0 = time.time()
+        wav = voc.detokenize(sem, torch.as_tensor(glob)[None, None])
+        t_voc = time.time() - t0
+        samples = wav.shape[-1]
+        if r > 0:
+            times.append((t_llm + t_voc, t_llm, t_voc))
+    total, t_llm, t_voc = sorted(times)[len(times) // 2]
     return {
         "value": samples / total, "unit": "audio samples/s", "cores": cores, "kind": "port",
         "rtf": total / (samples / 16000.0),
-        "sample": f"1 utterance: {len(prompt)}-token prefill + {n_tokens} greedy tokens ({t_llm:.2f}s) + vocoder of "
-                  f"those {n_tokens} frames ({t_voc:.2f}s), fp32 torch-CPU oracle, weights build {build_s:.1f}s excluded",
+        "sample": f"the configs[1] utterance: {len(prompt)}-token prefill + {n_tokens} greedy tokens ({t_llm:.2f}s) + vocoder of "
+                  f"those {n_tokens} frames ({t_voc:.2f}s), fp32 torch-CPU oracle, 1 warm-up + median of {runs} runs "
+                  f"({', '.join(f'{t[0]:.2f}' for t in times)} s), weights build {build_s:.1f}s excluded",
         "cpu_model": _cpu_model(), "first_tokens": toks[:8],
     }
 
@@ -116,13 +142,66 @@ def _cpu_model():
     return "unknown"
 
 
+def build_hash() -> str:
+    """sha1 over the HIP sources the product library is built from: ties a PMC profile to the build it was taken on."""
+    h = hashlib.sha1()
+    src = os.path.join(ROOT, "spark-tts_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "smi_*.hip")) + glob.glob(os.path.join(src, "smi_*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
+def pmc_traffic(batch: int):
+    """HBM bytes per launch per decode kernel from the newest profiles/r*_pmc_traffic*.json (tools/pmc_traffic.sh:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied) taken on THIS build and batch;
+    (None, why) when there is none -- the number is never typed in."""
+    bh = build_hash()
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), key=os.path.getmtime, reverse=True)
+    seen = []
+    for f in cands:
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        seen.append(f"{os.path.basename(f)}: build {d.get('build')} batch {d.get('batch')}")
+        if d.get("build") == bh and int(d.get("batch", -1)) == batch:
+            return d, os.path.basename(f)
+    return None, f"no PMC profile for build {bh} at batch {batch} under profiles/ ({'; '.join(seen) or 'none at all'})"
+
+
+def cfg3_inputs(n, seed0, vocab, n_glob, uniform=None):
+    """SURVEY 8d, cfg 3 / cfg 4: utterance i has a prompt of U{96..160} ids and wants U{120..180} tokens, seeded seed0 + i
+    (`uniform` = (P, N): fixed lengths)."""
+    out = []
+    for i in range(n):
+        g = np.random.Generator(np.random.PCG64(seed0 + i))
+        P = int(g.integers(96, 161)) if uniform is None else uniform[0]
+        N = int(g.integers(120, 181)) if uniform is None else uniform[1]
+        out.append({"prompt": g.integers(0, vocab, size=P).tolist(), "n": N, "glob": g.integers(0, 4096, size=n_glob)})
+    return out
+
+
+def spawn_ranks(n: int) -> int:
+    """`bench.py --gpus N` started by hand: become the launcher (no GPU call has happened in this process)."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {n} without WORLD_SIZE: spawning the ranks: {' '.join(cmd)}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: refusing to report a number for another rank count")
     import torch.distributed as dist
     from sparkmi import config as C, weights as W, arena as A, bicodec as BC, _lib
     from sparkmi.llm import SparkLLM
@@ -149,14 +228,31 @@ def main():
 
     llm_cfg, voc_cfg = C.spark_0p5b_llm(), C.spark_0p5b_bicodec()
     B, P, N = a.batch, a.prompt_len, a.new_tokens
-    max_pos = P + N + 80
+    ragged = B > 1 and not a.uniform and not a.clone
+    ntok_glob = voc_cfg.spk_token_num
+    # ---- synthetic inputs.  cfg 2: prompt ids ~ U[0,V) PCG64(1234), global ids PCG64(1235); cfg 3: ragged, seeds 2000+i
+    if ragged:
+        utts = cfg3_inputs(B, 2000 + rank * 1000, llm_cfg.vocab_size, ntok_glob)
+    else:
+        utts = []
+        for i in range(B):
+            s_ = rank * 1000 + i
+            utts.append({"prompt": np.random.Generator(np.random.PCG64(1234 + 2 * s_)).integers(0, llm_cfg.vocab_size, size=P).tolist(),
+                         "n": N, "glob": np.random.Generator(np.random.PCG64(1235 + 2 * s_)).integers(0, 4096, size=ntok_glob)})
+    prompts = [u["prompt"] for u in utts]
+    want = [u["n"] for u in utts]
+    globs = [u["glob"] for u in utts]
+    Nmax, Pmax = max(want), max(len(p) for p in prompts)
+    do_cfg4 = not a.no_config4 and not a.clone and not a.no_probes
+    max_pos = max(Pmax + Nmax, (160 + 180) if do_cfg4 else 0) + 32
     if a.clone:
         from sparkmi import config_tok as T
         from sparkmi.encoder import BiCodecEncoder, get_ref_clip
         wcfg, tcfg = T.xlsr53(), T.spark_0p5b_tok()
         max_pos += wcfg.frames(int(16000 * a.prompt_seconds)) + tcfg.spk_token_num
+    max_frames = max(Nmax, 180 if do_cfg4 else 0) + 10
     cs_llm = A.llm_cfg_struct(llm_cfg, B, max_pos, a.kv, not a.no_graph)
-    cs_voc = BC.voc_cfg_struct(voc_cfg, B, N + 10)
+    cs_voc = BC.voc_cfg_struct(voc_cfg, B, max_frames)
 
     # ---- weights: rank 0 builds the arenas, everyone else receives them over RCCL/xGMI
     t0 = time.time()
@@ -172,7 +268,7 @@ def main():
 
     llm = SparkLLM(llm_cfg, None, dev, max_slots=B, max_positions=max_pos, kv_dtype=a.kv,
                    use_graph=not a.no_graph, arena=llm_arena)
-    voc = BiCodecVocoder(voc_cfg, None, dev, max_batch=B, max_frames=N + 10, arena=voc_arena)
+    voc = BiCodecVocoder(voc_cfg, None, dev, max_batch=B, max_frames=max_frames, arena=voc_arena)
     enc = None
     if a.clone:
         if rank == 0:
@@ -191,15 +287,33 @@ def main():
             pwavs.append(x)
             prefs.append(get_ref_clip(x, 16000, 6.0, 320).astype(np.float32))
 
-    # ---- synthetic inputs: prompt ids ~ U[0,V) PCG64(1234+i), global ids PCG64(1235+i)
-    prompts, globs = [], []
-    for i in range(B):
-        s = rank * 1000 + i
-        prompts.append(np.random.Generator(np.random.PCG64(1234 + 2 * s)).integers(0, llm_cfg.vocab_size, size=P).tolist())
-        globs.append(np.random.Generator(np.random.PCG64(1235 + 2 * s)).integers(0, 4096, size=voc_cfg.spk_token_num))
     glob_t = torch.from_numpy(np.stack(globs)).to(dev, torch.int32).unsqueeze(1)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     decode_ms, voc_ms, enc_ms = [], [], []
+
+    def run_batch(eng, vocoder, pr, wants, glob_dev, timed=False):
+        """prefill -> decode max(N_i) - 1 steps -> row i keeps its first N_i tokens -> ragged vocoder batch -> host."""
+        nmax = max(wants)
+        eng.prefill(pr, None)
+        if timed:
+            ev[0].record()
+        eng.decode(nmax - 1)
+        if timed:
+            ev[1].record()
+        toks = eng.tokens(nmax)                              # sync + D2H: the host parses ids like the reference
+        sem = torch.zeros((len(pr), nmax), dtype=torch.long)
+        for b, t in enumerate(toks):
+            sem[b, : wants[b]] = torch.tensor(t[: wants[b]], dtype=torch.long) % voc_cfg.codebook_size
+        if timed:
+            ev[2].record()
+        wav = vocoder.detokenize(sem.to(dev), glob_dev, lengths=wants)
+        if timed:
+            ev[3].record()
+        out = wav.cpu()                                      # 192 KB per 3 s utterance back to the host
+        if timed:
+            decode_ms.append(ev[0].elapsed_time(ev[1]))
+            voc_ms.append(ev[2].elapsed_time(ev[3]))
+        return out, toks
 
     def step(timed=False):
         nonlocal glob_t
@@ -215,24 +329,7 @@ def main():
             pr = [prompts[i] + (g_h[i] % llm_cfg.vocab_size).tolist() + (sem_h[i] % llm_cfg.vocab_size).tolist() for i in range(B)]
             if timed:
                 enc_ms.append((time.perf_counter() - t0) * 1e3)
-        llm.prefill(pr, None)
-        if timed:
-            ev[0].record()
-        llm.decode(N - 1)
-        if timed:
-            ev[1].record()
-        toks = llm.tokens(N)                                 # sync + D2H: the host parses ids like the reference
-        sem = torch.tensor(toks, dtype=torch.long) % voc_cfg.codebook_size
-        if timed:
-            ev[2].record()
-        wav = voc.detokenize(sem.to(dev), glob_t)
-        if timed:
-            ev[3].record()
-        out = wav.cpu()                                      # 192 KB per utterance back to the host
-        if timed:
-            decode_ms.append(ev[0].elapsed_time(ev[1]))
-            voc_ms.append(ev[2].elapsed_time(ev[3]))
-        return out, toks
+        return run_batch(llm, voc, pr, want, glob_t, timed)
 
     if rank == 0:
         log(f"weights packed in {t_build:.1f}s, broadcast {bcast_ms:.1f} ms; warm-up")
@@ -255,9 +352,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
-    samples_per_step = B * N * voc_cfg.hop
+    samples_per_step = sum(want) * voc_cfg.hop
     value = world * a.steps * samples_per_step / el
     audio_s = world * a.steps * samples_per_step / 16000.0
+    cfg_idx = 4 if a.clone else (1 if B == 1 else 2)
+    shape = (f"ragged: prompts {min(len(p) for p in prompts)}..{Pmax} ids, {min(want)}..{Nmax} tokens per utterance (SURVEY 8d cfg 3, seeds 2000+i)"
+             if ragged else f"{P}-token prompt -> {N} tokens -> {N * voc_cfg.hop / 16000.0:.1f} s audio per utterance")
     res = {
         "metric": "audio samples/sec (whole node), Spark-TTS-0.5B greedy", "value": value, "unit": "audio samples/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1000.0 * el / a.steps,
@@ -265,40 +365,88 @@ def main():
         "dtype": "bf16 weights + KV, fp32 activations/accumulate (LLM); fp32 (vocoder)" if a.kv == "bf16"
                  else "bf16 weights, fp32 KV/activations (LLM); fp32 (vocoder)",
         "data": "synthetic (seeded prompts and weights; no checkpoint or dataset offline)",
-        "config": {"workload": f"Spark-TTS-0.5B, batch={B} greedy, {P}-token prompt -> {N} tokens -> "
-                               f"{N * voc_cfg.hop / 16000.0:.1f} s audio per utterance (BASELINE.json configs[{4 if a.clone else (1 if B == 1 else 2)}])",
+        "config": {"workload": f"Spark-TTS-0.5B, batch={B} greedy, {shape} (BASELINE.json configs[{cfg_idx}])",
                    **({"voice_clone": f"each utterance encodes a {a.prompt_seconds:.1f} s prompt wav on the GPU first (BASELINE.json configs[4])"} if a.clone else {}),
-                   "batch_per_gpu": B, "prompt_len": P, "new_tokens": N, "kv_cache": a.kv,
-                   "hipgraph": not a.no_graph, "parallelism": f"utterance-parallel x{world}", "device": arch},
+                   "batch_per_gpu": B, "prompt_len": [len(p) for p in prompts] if ragged else P, "new_tokens": want if ragged else N,
+                   "kv_cache": a.kv, "hipgraph": not a.no_graph, "parallelism": f"utterance-parallel x{world} (same per-rank loop on every rank)",
+                   "device": arch, "build": build_hash()},
         "rtf": el / audio_s, "x_realtime": audio_s / el,
         "utterances_per_s": world * a.steps * B / el,
         "weights": {"build_s_rank0": t_build, "rccl_broadcast_ms": bcast_ms,
                     "llm_arena_bytes": int(llm_arena.numel()), "voc_arena_bytes": int(voc_arena.numel()) * 4},
-        "stage_ms": {"decode_149_steps": float(np.median(decode_ms)), "vocoder": float(np.median(voc_ms)),
+        "stage_ms": {f"decode_{Nmax - 1}_steps": float(np.median(decode_ms)), "vocoder": float(np.median(voc_ms)),
                      **({"prompt_encode_all": float(np.median(enc_ms))} if enc_ms else {})},
         "first_tokens": toks[0][:8], "wav_std": float(wav.std()),
     }
 
+    # ---- BASELINE configs[3]: the 256-utterance set, sharded over the ranks, batches of <= 32 per GPU (strong scaling)
+    if do_cfg4:
+        SET, GB = a.set_size, 32
+        reqs = cfg3_inputs(SET, 3000, llm_cfg.vocab_size, ntok_glob)
+        mine = SD.shard_indices([r["n"] for r in reqs], rank, world)
+        if B == GB:
+            llm32, voc32 = llm, voc
+        else:
+            llm32 = SparkLLM(llm_cfg, None, dev, max_slots=GB, max_positions=max_pos, kv_dtype=a.kv, use_graph=not a.no_graph, arena=llm_arena)
+            voc32 = BiCodecVocoder(voc_cfg, None, dev, max_batch=GB, max_frames=max_frames, arena=voc_arena)
+
+        def run_shard():
+            got = 0
+            for i in range(0, len(mine), GB):
+                grp = [reqs[j] for j in mine[i: i + GB]]
+                g_dev = torch.from_numpy(np.stack([r["glob"] for r in grp])).to(dev, torch.int32).unsqueeze(1)
+                run_batch(llm32, voc32, [r["prompt"] for r in grp], [r["n"] for r in grp], g_dev)
+                got += sum(r["n"] for r in grp)
+            return got
+
+        if rank == 0:
+            log(f"config4: {SET} utterances, {len(mine)} on this rank, batches of {GB}")
+        grp0 = [reqs[j] for j in mine[:GB]]
+        run_batch(llm32, voc32, [r["prompt"] for r in grp0], [r["n"] for r in grp0],
+                  torch.from_numpy(np.stack([r["glob"] for r in grp0])).to(dev, torch.int32).unsqueeze(1))     # warm-up (graph capture at this batch)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_shard()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el4 = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el4], device="cpu" if one_gpu else dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el4 = float(t.item())
+        tot = sum(r["n"] for r in reqs) * voc_cfg.hop
+        res["config4"] = {"workload": f"BASELINE.json configs[3]: {SET} utterances (prompts U{{96..160}} ids, U{{120..180}} tokens, seeds 3000+i) "
+                                      f"dealt over {world} rank(s) by sparkmi.dist.shard_indices (longest first, serpentine), batches of <= {GB} per GPU, one pass",
+                          "value": tot / el4, "unit": "audio samples/s", "scaling": "strong", "seconds": el4,
+                          "utterances_per_s": SET / el4, "x_realtime": tot / 16000.0 / el4, "n_gpus": world,
+                          "utterances_per_rank": len(mine), "rccl_broadcast_ms": bcast_ms}
+        if llm32 is not llm:
+            llm32.close()
+
     if rank == 0:
         log(f"timed: {el:.3f}s for {a.steps} steps -> {value:.0f} samples/s; probing kernels")
-        # ---- roofline: decode step is HBM-bound; algorithmic bytes = weights once + KV read + KV write
+        # ---- roofline: decode step is HBM-bound; algorithmic bytes = weights once + KV read + KV write.  Every row steps
+        # through all Nmax - 1 decode steps (rows past their own length are the padding of a static batch).
         wb = llm.step_weight_bytes()
         kvb = llm.kv_bytes_per_token()
-        ctx_sum = sum(P + j for j in range(1, N))   # decode step j reads positions 0..P+j-1 (+ its own)
-        step_bytes = wb + kvb * B * (ctx_sum / (N - 1) + 1) + kvb * B
-        dec_step_ms = res["stage_ms"]["decode_149_steps"] / (N - 1)
+        ctx_sum = sum(len(p) + j for p in prompts for j in range(1, Nmax))   # decode step j of a row reads its positions 0..P+j-1
+        step_bytes = wb + kvb * (ctx_sum / (Nmax - 1) + B) + kvb * B          # KV read (cached + own) + KV write
+        dec_step_ms = res["stage_ms"][f"decode_{Nmax - 1}_steps"] / (Nmax - 1)
         res["roofline_step"] = {
             "bound": "hbm", "achieved": step_bytes / (dec_step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": step_bytes / (dec_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
             "bytes_per_step": step_bytes, "ms_per_step": dec_step_ms,
-            "note": "whole decode step (122 kernels in one hipGraph), events inside the timed region"}
+            "note": "whole decode step of this workload (one hipGraph replay), events inside the timed region"}
         if not a.no_probes:
             llm.prefill(prompts, None)
-            llm.decode(N // 2)
-            ctx = P + N // 2
+            llm.decode(Nmax // 2)
             kb = llm.weight_bytes()
+            ctx_now = sum(len(p) + Nmax // 2 for p in prompts)
             per = {"qkv": kb["qkv"] + kvb // llm_cfg.num_hidden_layers * B,
-                   "attn": kvb // llm_cfg.num_hidden_layers * B * ctx,
+                   "attn": kvb // llm_cfg.num_hidden_layers * ctx_now,
                    "o_proj": kb["o_proj"], "gate_up": kb["gate_up"], "down": kb["down"], "lm_head": kb["lm_head"]}
             count = {k: llm_cfg.num_hidden_layers for k in per}
             count["lm_head"] = 1
@@ -312,16 +460,13 @@ def main():
                            "bytes": per[name], "GBps": per[name] / (ms * 1e-3) / 1e9,
                            "us_per_step": ms * 1e3 * count[name]})
             dom = max(ks, key=lambda k: k["us_per_step"])
-            # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes on this build and shape
-            # (profiles/r01_pmc_hbm_traffic_v13.txt; FETCH_SIZE doubled per the gfx950 rule); null for other shapes
-            # (profiles/r01_pmc_hbm_traffic_v13.txt: a producer's helper-block prefetch is part of ITS launch's traffic; gate_up's own
-            # in-graph traffic cannot be observed -- counter collection runs every kernel alone with the L2 invalidated)
-            pmc = {"gate_up": None, "down": 11.17e6, "qkv": 10.95e6, "o_proj": 1.77e6, "lm_head": 297.63e6, "attn": 9.61e6}
-            std = B == 1 and P == 128 and a.kv == "bf16"
+            prof, src = pmc_traffic(B)
+            traffic = None
+            if prof is not None and dom["kernel"] in prof.get("kernels", {}):
+                traffic = prof["kernels"][dom["kernel"]]["hbm_bytes_per_launch"]
             res["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS,
-                               "traffic": pmc.get(dom["kernel"]) if std else None,
-                               "bytes_per_launch": dom["bytes"], "avg_us": dom["avg_us"]}
+                               "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+                               "traffic_source": src, "bytes_per_launch": dom["bytes"], "avg_us": dom["avg_us"]}
             res["kernels"] = ks
             # the reference's default mode (temperature 0.8 / top-k 50 / top-p 0.95): decode step with the sampler in the graph
             llm.set_sampling(True, 0.8, 50, 0.95, 1234)
@@ -360,7 +505,7 @@ def main():
                 res["streaming"] = {"first_chunk_ms": 1e3 * t_first, "all_chunks_ms": 1e3 * (time.perf_counter() - ts),
                                     "chunks": nchunks, "schedule": "1.0 s first chunk, x8 growth, 0.1 s overlap (reference defaults)"}
             # vocoder launches (MFMA-bound side of the path)
-            voc.detokenize(torch.tensor(toks, dtype=torch.long).to(dev) % voc_cfg.codebook_size, glob_t)
+            run_batch(llm, voc, prompts, want, glob_t)
             vl = []
             for i in range(voc.launches()):
                 nm, ms, fl = voc.time_launch(i, iters=5)
@@ -375,7 +520,11 @@ def main():
             res["roofline"] = dict(res["roofline_step"])
         if not a.no_cpu_baseline and world == 1:
             log("gpu side done; timing the CPU oracle")
-            res["cpu_baseline"] = cpu_baseline(llm_cfg, voc_cfg, prompts[0], globs[0], a.cpu_tokens)
+            c1 = cfg3_inputs(0, 0, 1, 1)   # (keeps the helper imported in one place)
+            del c1
+            cprompt = np.random.Generator(np.random.PCG64(1234)).integers(0, llm_cfg.vocab_size, size=128).tolist()
+            cglob = np.random.Generator(np.random.PCG64(1235)).integers(0, 4096, size=ntok_glob)
+            res["cpu_baseline"] = cpu_baseline(llm_cfg, voc_cfg, cprompt, cglob, a.cpu_tokens, a.cpu_runs)
             res["gpu_over_cpu_rtf"] = res["cpu_baseline"]["rtf"] / res["rtf"]
         print(json.dumps(res))
     if world > 1:

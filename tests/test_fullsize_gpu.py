@@ -14,9 +14,29 @@ from conftest import FULL_MAX_POS
 pytestmark = pytest.mark.gpu
 
 
+TIE = 2e-2   # logit gap (logit std ~1.6) below which two summation orders may pick different tokens once K/V are rounded to bf16
+
+
 def _llm(cfg, arena, **kw):
     from sparkmi.llm import SparkLLM
     return SparkLLM(cfg, None, "cuda:0", max_positions=FULL_MAX_POS, arena=arena, **kw)
+
+
+def _assert_same_or_tie(probe, prompt, got, want, what):
+    """`got` and `want` are two valid runs of one sequence (two kernels with different fp32 summation orders, or kernel vs
+    CPU oracle).  With an f32 KV cache they must be identical.  With a bf16 cache an fp32 last-bit difference in a K/V
+    element can move it to the neighbouring bf16 value (2^-9 relative), which may flip a NEAR-TIE arg-max; every later
+    token then differs legitimately.  So: identical, or the first difference sits on a tie -- both tokens are the top two
+    of the teacher-forced logits there and less than TIE apart.  Returns True when the runs were identical."""
+    if got == want:
+        return True
+    i = next(k for k in range(min(len(got), len(want))) if got[k] != want[k])
+    lg = probe.forward_logits(list(prompt) + list(want[:i]))[-1].float().cpu()
+    top = torch.topk(lg, 2)
+    assert {int(top.indices[0]), int(top.indices[1])} == {got[i], want[i]}, f"{what}: token {i} differs and is not a top-2 tie: {got[i]} vs {want[i]}, top {top.indices.tolist()}"
+    gap = float(top.values[0] - top.values[1])
+    assert gap < TIE, f"{what}: token {i} differs at a logit gap of {gap}"
+    return False
 
 
 @pytest.mark.parametrize("kv", ["f32", "bf16"])
@@ -33,8 +53,15 @@ def test_config3_prompts_through_the_prefill_gemm(full_llm, golden_dir, kv):
     big = _llm(cfg, arena, max_slots=32, kv_dtype=kv)
     one = _llm(cfg, arena, max_slots=1, kv_dtype=kv)
     batched = big.generate_ids(prompts, n)
+    same = 0
     for b in range(32):
-        assert one.generate_ids([prompts[b]], n)[0] == batched[b], f"row {b}"
+        solo = one.generate_ids([prompts[b]], n)[0]
+        if kv == "f32":
+            assert solo == batched[b], f"row {b}"
+            same += 1
+        else:
+            same += _assert_same_or_tie(one, prompts[b], batched[b], solo, f"row {b}")
+    assert same >= 16, f"only {same} of 32 rows identical"   # observed 27: ~1 token in 80 sits on a tie closer than the bf16-KV noise
     if kv == "f32":
         assert batched[0] == g["greedy"][:n].tolist()
 
@@ -48,14 +75,26 @@ def test_config5_clone_length_prompts_through_the_prefill_gemm(full_llm, full_ll
     prompts = [rng.integers(0, cfg.vocab_size, size=L).tolist() for L in lens]
     assert sum(L - 1 for L in lens) >= 3072
     n = 10
-    batched = _llm(cfg, arena, max_slots=8).generate_ids(prompts, n)
-    one = _llm(cfg, arena, max_slots=1)
-    for b in range(8):
-        assert one.generate_ids([prompts[b]], n)[0] == batched[b], f"row {b}"
-    ref = full_llm_oracle
-    ref.kv_dtype = "bf16"
-    for b in (0, 6):
-        assert ref.generate_greedy(prompts[b], n) == batched[b], f"row {b} vs oracle"
+    for kv in ("f32", "bf16"):
+        batched = _llm(cfg, arena, max_slots=8, kv_dtype=kv).generate_ids(prompts, n)
+        one = _llm(cfg, arena, max_slots=1, kv_dtype=kv)
+        same = 0
+        for b in range(8):
+            solo = one.generate_ids([prompts[b]], n)[0]
+            if kv == "f32":
+                assert solo == batched[b], f"row {b}"
+                same += 1
+            else:
+                same += _assert_same_or_tie(one, prompts[b], batched[b], solo, f"row {b}")
+        assert same >= 6
+        ref = full_llm_oracle
+        ref.kv_dtype = kv
+        for b in (0, 6):
+            want = ref.generate_greedy(prompts[b], n)
+            if kv == "f32":
+                assert want == batched[b], f"row {b} vs oracle"
+            else:
+                _assert_same_or_tie(one, prompts[b], batched[b], want, f"row {b} vs oracle")
 
 
 def test_config2_free_running_bf16_kv_graph_to_waveform(full_llm, full_llm_oracle, full_voc, golden_dir):
@@ -75,7 +114,12 @@ def test_config2_free_running_bf16_kv_graph_to_waveform(full_llm, full_llm_oracl
     ref = full_llm_oracle
     ref.kv_dtype = "bf16"
     want = ref.generate_greedy(prompt, 150)
-    assert toks == want
+    if not _assert_same_or_tie(llm, prompt, toks, want, "bf16-KV free-running vs oracle"):
+        # a near-tie was decided the other way: the waveform check below then runs on the GPU's own tokens
+        # (both sequences are valid greedy runs); the teacher-forced agreement pins the rest of the sequence
+        seq = list(prompt) + list(want[:-1])
+        tf = llm.forward_logits(seq)[len(prompt) - 1:].argmax(-1).cpu().tolist()
+        assert np.mean(np.array(tf) == np.array(want)) > 0.97
     glob = np.random.Generator(np.random.PCG64(1235)).integers(0, 4096, size=(1, 1, vcfg.spk_token_num))
     sem = torch.tensor([[t % vcfg.codebook_size for t in toks]])
     voc = BiCodecVocoder(vcfg, sd, "cuda:0", max_batch=1, max_frames=160)
