@@ -64,6 +64,15 @@ typedef struct smi_llm_cfg {
   int32_t kv_dtype;          /* 0 = bf16 KV cache, 1 = f32 KV cache */
   int32_t use_graph;         /* 1 = replay the decode step as a hipGraph */
   float rms_eps;
+  /* Paged KV cache (the functional analogue of TensorRT-LLM's paged KV under in-flight batching,
+   * runtime/triton_trtllm/run.sh:50-65): kv_page_tokens = 0 gives every slot max_positions contiguous tokens
+   * (max_slots x max_positions reserved).  A power of two in 16..1024 that divides max_positions makes the cache a
+   * POOL of kv_pages pages of that many tokens; a sequence holds only the pages its length needs (allocated as it
+   * grows, returned at smi_llm_retire / the next prefill), so many live sequences do not each reserve the longest
+   * context.  A call that needs more pages than are free fails with SMI_ENOMEM and changes nothing.  Tokens are the
+   * same either way. */
+  int32_t kv_page_tokens;
+  int32_t kv_pages;
 } smi_llm_cfg;
 
 /* Arena sections.  The arena is one device buffer the caller fills (see sparkmi/arena.py):
@@ -71,6 +80,8 @@ typedef struct smi_llm_cfg {
  *             (one tile = 1 KiB = exactly one wave64 x 16-byte load = one MFMA 16x16x32 A operand);
  *   QKV rows: q heads, then k heads, then v heads; inside each q/k head the 64 rows are ordered
  *             (0,32,1,33,...) so a RoPE pair sits in adjacent rows; QKV bias in the same order;
+ *   WO columns (the attention output it multiplies): 32-column k tiles head-interleaved -- tile (half * num_heads + head)
+ *             holds dims 32*half .. 32*half+31 of that head (sparkmi/arena.py: o_proj_col_perm);
  *   GATE_UP rows: gate and up interleaved (g0,u0,g1,u1,...);
  *   LM_HEAD: vocab padded up to a multiple of 16 rows with zeros (also the embedding table);
  *   norms/bias: f32;  ROPE: float2 (cos,sin) [max_positions][head_dim/2].                      */
@@ -127,6 +138,8 @@ int smi_llm_status(smi_llm* h, int32_t* count_host, int32_t* finished_host, void
 int smi_llm_forward_logits(smi_llm* h, const int64_t* ids_host, int S, float* logits_dev, void* stream);
 /* Steps generated so far per sequence (including the prefill token), and the KV bytes per token. */
 int smi_llm_steps(smi_llm* h);
+/* Paged KV cache: pages in the pool and pages currently free (both 0 when the cache is not paged). */
+int smi_llm_kv_pages(smi_llm* h, int32_t* total, int32_t* free_pages);
 /* Per-kernel timing probe used by bench.py: launches ONLY the named decode-step kernel of `layer`
  * `iters` times on `stream` (inputs are whatever the scratch holds), bracketed by HIP events, and
  * returns the average milliseconds per launch.  kernel: 0 qkv, 1 attn, 2 o_proj, 3 gate_up,

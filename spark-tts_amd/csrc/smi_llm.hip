@@ -48,7 +48,12 @@ struct Ctl {
   int32_t seqid[SMI_MAX_ROWS];    // per KV slot: admission number of the sequence living there (sampler stream key)
 };
 
-enum { PRO_PLAIN = 0, PRO_NORM = 1 };
+struct KvMap {
+  const int32_t* ptab;   // [slots][ppslot] page ids, or null
+  int pshift, ppslot;
+};
+
+enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_FUSEDO = 2 };   // FUSEDO: RMSNorm operand built in the kernel from the fused o_proj's per-head partials
 enum { EPI_RESID = 0, EPI_SWIGLU = 1, EPI_QKV = 2, EPI_LM = 3 };
 
 // Same-XCD L2 prefetch for a LATER kernel: block b of every kernel of a graph lands on XCD (s + b) mod 8
@@ -85,6 +90,7 @@ struct GemmP {
   void* kcache;          // this layer's K cache: [slot][kvh][max_pos][64]
   void* vcache;
   int q_dim, kv_dim, n_kv, max_pos;
+  KvMap km;              // QKV: paged KV cache (ptab null: contiguous slots)
   int V;                 // LM: true vocab size
   float* pval;           // LM: [rows][work_blocks] per-block best logit
   int* pidx;
@@ -97,7 +103,27 @@ struct GemmP {
   PfDesc pf;
   int ldsb;              // few rows: bytes of wave-private LDS for the activation triples (0 = read them from global per tile)
   int lt_shift;          // log2(lanes that fetch one k tile's 12*M pieces)
+  // fused o_proj (one row): PRO_FUSEDO builds its operand from these instead of reading XS / sspart; RESID reads its residual from Yin
+  const float* part_o;   // [n_oheads][K] per-head partials of the o_proj (k_attn<.., FUSE>)
+  int n_oheads;
+  const float* hres;     // [K] residual stream before the attention block's contribution
+  const float* gam;      // [K] this RMSNorm's weight
+  float* h2out;          // [K] block 0 leaves h + o_proj here (the residual down_proj adds to)
+  const float* Yin;      // RESID: residual row source when it is not Y itself (null: Y)
 };
+constexpr int kMaxOHeads = 16;
+
+// One weight tile piece (16 B per lane).  -DSMI_W_NT builds the A/B variant whose once-read decode weight streams use the
+// non-temporal policy (MI355X_MICROARCH.md, row nt-weights); the default build uses plain loads.
+__device__ __forceinline__ uint4 smi_ldw(const uint4* q) {
+#ifdef SMI_W_NT
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)q);
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *q;
+#endif
+}
 
 // exact 3-way bf16 split: x == hi + mid + lo (8 + 8 + 8 mantissa bits)
 __device__ __forceinline__ void split3(float x, uint32_t& hi, uint32_t& mi, uint32_t& lo) {
@@ -111,6 +137,22 @@ __device__ __forceinline__ void split3(float x, uint32_t& hi, uint32_t& mi, uint
 __device__ __forceinline__ size_t xs_off(int kt, int s, int k8, int m, int M) {
   return ((size_t)((kt * 3 + s) * 4 + k8) * M + m) * 16;
 }
+// Where token `pos` of (slot, kv head) lives in a layer's K (or V) cache, in rows of 64 elements.  Contiguous slots:
+// [slot][kvh][max_pos]; paged (ptab != null): the cache is a pool of pages [page][kvh][1 << pshift] and a slot's
+// positions map to pages through its row of the page table (smi_llm_cfg.kv_page_tokens / kv_pages).
+__device__ __forceinline__ size_t kv_row(const KvMap& km, int slot, int kvh, int n_kv, int max_pos, int pos) {
+  if (km.ptab) {
+    const int pg = km.ptab[(size_t)slot * km.ppslot + (pos >> km.pshift)];
+    return (((size_t)pg * n_kv + kvh) << km.pshift) + (size_t)(pos & ((1 << km.pshift) - 1));
+  }
+  return ((size_t)slot * n_kv + kvh) * max_pos + pos;
+}
+
+// o_proj's reduction index is stored head-interleaved: k tile (half * n_heads + head) holds dims 32 * half .. + 31 of
+// `head` (W_o's columns in the arena and the attention output operand alike).  With the k tile -> wave map
+// kt mod n_heads of the o_proj kernel, wave w then sums exactly head w's two tiles: the per-head partial that the
+// one-row attention kernel can also produce itself (fused o_proj, below) -- same bits either way.
+__device__ __forceinline__ int o_ktile(int head, int d, int n_heads) { return (d >> 5) * n_heads + head; }
 
 // ------------------------------------------------------------------------------------------
 // GEMM: Y[m][n] = sum_k W[n][k] * X[m][k], X given as exact bf16 triples in global memory.
@@ -145,6 +187,7 @@ __device__ __forceinline__ float smi_ss_lane_sum(const float* sp, int npart, int
 template <int MT, int NTB, int NW, int U, int WB, int PRO, int EPI, int KVF32, int H = 1, int OCC = 1, int LEAN = 0>
 __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
   static_assert(H == 1 || ((H == 2 || H == 4) && NTB == 1 && EPI == EPI_RESID), "row-split tiles: RESID, one tile per block");
+  static_assert(PRO != PRO_FUSEDO || (LEAN == 2 && MT == 1 && EPI == EPI_SWIGLU), "PRO_FUSEDO: the one-row gate_up kernel");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if ((int)blockIdx.x >= p.work_blocks) {
@@ -182,7 +225,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
       for (int nb = 0; nb < NTB; ++nb) {
         int nt = nt0 + nb;
         nt = nt < NT ? nt : NT - 1;
-        dst[u][nb] = wact ? p.W[((size_t)nt * KT + j) * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
+        dst[u][nb] = wact ? smi_ldw(&p.W[((size_t)nt * KT + j) * 64 + lane]) : make_uint4(0u, 0u, 0u, 0u);
       }
     }
   };
@@ -207,6 +250,24 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
       const int m = mbase + mt * 16 + em;
       if (LEAN != 2) erd[mt] = p.rows[m < M ? m : M - 1];
     }
+  }
+  // PRO_FUSEDO: the per-head o_proj partials, the residual row and gamma of this wave's k tiles (two tiles per round, lane =
+  // one k) are requested BEFORE the weight tiles: loads return in issue order, so behind the (cold) weights they would only
+  // arrive after them and the whole operand build would sit between the weights' arrival and the first MFMA
+  constexpr int FRND = PRO == PRO_FUSEDO ? 2 : 1;
+  float fpv[FRND][kMaxOHeads], fhv[FRND], fgv[FRND];
+  int fkk[FRND];
+  if constexpr (PRO == PRO_FUSEDO) {
+    const int tw = (KT - wave + NW - 1) / NW, K = KT * 32;
+#pragma unroll
+    for (int r = 0; r < FRND; ++r) {
+      const int tl = 2 * r + (lane >> 5);
+      fkk[r] = (wave + (tl < tw ? tl : tw - 1) * NW) * 32 + (lane & 31);
+#pragma unroll
+      for (int hd = 0; hd < kMaxOHeads; ++hd) fpv[r][hd] = p.part_o[(size_t)(hd < p.n_oheads ? hd : p.n_oheads - 1) * K + fkk[r]];
+      fhv[r] = p.hres[fkk[r]]; fgv[r] = p.gam[fkk[r]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int b = 0; b < WB; ++b)
@@ -243,7 +304,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
             erope[mt][1] = p.rope[(size_t)erd[mt].pos * 32 + i0 + 1];
           }
         }
-        if (EPI == EPI_RESID) epre[mt] = *(const float4*)(p.Y + (size_t)m * (NT * 16) + n);
+        if (EPI == EPI_RESID) epre[mt] = *(const float4*)((p.Yin ? p.Yin : p.Y) + (size_t)m * (NT * 16) + n);
       }
     }
   }
@@ -255,7 +316,41 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
   float ss0 = 0.f, ss1 = 0.f, ss2 = 0.f, ss3 = 0.f;
   const bool ss_pre = LEAN >= 1 && PRO == PRO_NORM && p.npart <= 256 && wave < MT * 16 && mbase + wave < M;
   unsigned char* bw = smem + (size_t)NW * NTB * MT * 1024 + 32 * 4 + NTB * 32 * 8 + (size_t)wave * p.ldsb;
-  if (vlds) {
+  float* ssp = (float*)(smem + (size_t)NW * NTB * MT * 1024 + 32 * 4 + NTB * 32 * 8 + (size_t)NW * p.ldsb);   // PRO_FUSEDO: [K / 4] partial sums of squares
+  if constexpr (PRO == PRO_FUSEDO) {
+    // The operand of this GEMV is gamma * (h + o_proj(attention)), and the o_proj arrives as one partial per head.  Each wave
+    // builds the 32-value tiles it owns: lane = one k (two tiles per round), heads added in order (the order k_gemm<RESID> with
+    // NW = heads sums its waves in), then exactly the RESID epilogue's arithmetic: residual add, sum of squares per 4 columns,
+    // gamma, exact 3-way split -- written as B-operand pieces into the wave's private staging slice.  All loads of a round
+    // are issued together; they are L2 hits and land long before the weight tiles requested above.
+    const int tw = (KT - wave + NW - 1) / NW;
+#pragma unroll
+    for (int r = 0; r < FRND; ++r) {
+      const int tl = 2 * r + (lane >> 5), k = fkk[r];
+      const bool ok = tl < tw;
+      float (&pv)[FRND][kMaxOHeads] = fpv;
+      float (&hv)[FRND] = fhv;
+      float (&gv)[FRND] = fgv;
+      float y = pv[r][0];
+#pragma unroll
+      for (int hd = 1; hd < kMaxOHeads; ++hd)
+        if (hd < p.n_oheads) y += pv[r][hd];   // wave-uniform
+      const float hm = hv[r] + y;
+      uint32_t hi, mi, lo;
+      split3(gv[r] * hm, hi, mi, lo);
+      float sq = hm * hm;
+      sq += __shfl_xor(sq, 1, 64);
+      sq += __shfl_xor(sq, 2, 64);          // lanes k % 4 == 0: (x^2 + y^2) + (z^2 + w^2), the RESID epilogue's partial
+      if (ok) {
+        unsigned char* q = bw + (size_t)(tl * 12 + ((lane >> 3) & 3)) * 16 + (lane & 7) * 2;
+        *(uint16_t*)q = (uint16_t)hi;
+        *(uint16_t*)(q + 64) = (uint16_t)mi;
+        *(uint16_t*)(q + 128) = (uint16_t)lo;
+        if ((lane & 3) == 0) ssp[k >> 2] = sq;
+        if (blockIdx.x == 0) p.h2out[k] = hm;
+      }
+    }
+  } else if (vlds) {
     const int tw = (KT - wave + NW - 1) / NW;          // this wave's k tiles
     const int lts = LEAN == 2 ? 4 : p.lt_shift;
     const int per = 64 >> lts, pm = 12 * M;
@@ -405,6 +500,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
         const float r = rarr[m < M ? ml : 0];
         s.x *= r; s.y *= r; s.z *= r; s.w *= r;
       }
+      if constexpr (PRO == PRO_FUSEDO) {   // the waves left their partial sums of squares in LDS; summed as smi_ss_lane_sum would
+        const int npart = KT * 8;
+        float v = lane < npart ? ssp[lane] : 0.f;
+        v += lane + 64 < npart ? ssp[lane + 64] : 0.f;
+        v += lane + 128 < npart ? ssp[lane + 128] : 0.f;
+        v += lane + 192 < npart ? ssp[lane + 192] : 0.f;
+        v = smi_wave_sum(v);
+        const float r = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
+        s.x *= r; s.y *= r; s.z *= r; s.w *= r;
+      }
       if (EPI == EPI_RESID) {
         float ssq = 0.f;
         if (valid) {
@@ -460,7 +565,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
           } else {
             const bool isk = n < p.q_dim + p.kv_dim;
             const int c = n - p.q_dim - (isk ? 0 : p.kv_dim);
-            const size_t off = (((size_t)rd.slot * p.n_kv + (c >> 6)) * p.max_pos + rd.pos) * 64 + (c & 63);
+            const size_t off = kv_row(p.km, rd.slot, c >> 6, p.n_kv, p.max_pos, rd.pos) * 64 + (c & 63);
             void* base = isk ? p.kcache : p.vcache;
             if (KVF32) {
               *(float4*)((float*)base + off) = s;
@@ -682,7 +787,7 @@ __global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
           } else {
             const bool isk = n < p.q_dim + p.kv_dim;
             const int c = n - p.q_dim - (isk ? 0 : p.kv_dim);
-            const size_t off = (((size_t)rd.slot * p.n_kv + (c >> 6)) * p.max_pos + rd.pos) * 64 + (c & 63);
+            const size_t off = kv_row(p.km, rd.slot, c >> 6, p.n_kv, p.max_pos, rd.pos) * 64 + (c & 63);
             void* base = isk ? p.kcache : p.vcache;
             if (KVF32) {
               *(float4*)((float*)base + off) = s;
@@ -744,7 +849,7 @@ __global__ __launch_bounds__(256 * HV) void k_lm(GemmP p, int ngroups, int m0_la
       for (int nb = 0; nb < NTB; ++nb) {
         int nt = g * NTB + nb;
         nt = nt < NT ? nt : NT - 1;
-        w[u][nb] = p.W[((size_t)nt * KT + j) * 64 + lane];
+        w[u][nb] = smi_ldw(&p.W[((size_t)nt * KT + j) * 64 + lane]);
       }
     }
   };
@@ -846,6 +951,7 @@ struct AttnP {
   unsigned char* xs_out;  // o_proj operand: exact bf16 triples [q_dim/32][3][4][M][16 B]
   int M;
   int q_dim, n_kv, group, max_pos, n_heads;
+  KvMap km;            // paged KV cache (general kernel and k_attn_pf only; the slot_is_row kernels need contiguous slots)
   int slot_is_row;     // every row m lives in KV slot m (decode): addresses need no descriptor
   int work_blocks;     // = n_heads * M * nseg; later blocks are prefetch helpers
   PfDesc pf;
@@ -853,10 +959,17 @@ struct AttnP {
   // block leaves (max, sum, out[64]) in `part` and k_attn_merge combines a row's segments in order.  nseg == 1: no split.
   int nseg;
   float* part;         // [M][n_heads][nseg][66]
+  // fused o_proj (one-row kernel): this head's two k tiles of W_o against its own output -> per-head partial of the o_proj
+  const uint4* Wo;     // [NTo][2 * n_heads][64] tiles (head-interleaved k order)
+  int NTo;             // n tiles of W_o (hidden / 16)
+  float* part_o;       // [n_heads][NTo * 16] f32
 };
 
 constexpr int kAttnWaves = 8;
 constexpr int kAttnSeg = 1024;   // tokens per segment (a multiple of the chunk of either KV type)
+constexpr int kFuseQB = 4;       // fused o_proj: blocks per head -- each repeats the head's attention (latency-bound, the CUs are idle anyway)
+                                 // and takes a quarter of W_o's n tiles: a CU pulls 28 KB of cold weights instead of 112 KB
+constexpr int kFuseOT = 2;       // W_o n tiles per wave (8 waves x 2 x 4 blocks x 16 = hidden sizes up to 1024)
 
 // 8 waves; a group of LPT lanes owns one token per pass (16-byte K and V pieces per lane, dot product
 // reduced on the DPP path), UNR passes of loads in flight together (256 tokens per chunk with bf16
@@ -867,8 +980,17 @@ constexpr int kAttnSeg = 1024;   // tokens per segment (a multiple of the chunk 
 // ONE == 1: exactly one live row in KV slot 0 and one context segment (batch-1 decode): index arithmetic folded at compile
 // time.  ONE == 2: several rows, row m in KV slot m, one context segment (plain batched decode): the K/V addresses do not
 // depend on the row descriptor, so descriptor, q and the first K/V chunk travel together as in the one-row kernel.
-template <int KVF32, int ONE = 0>
-__global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
+// FUSE (with ONE == 1): the block goes on to multiply its head's output with that head's two k tiles of W_o (requested at
+// kernel entry, in flight under the whole attention) and leaves a per-head partial of the o_proj; the consumer
+// (k_gemm<PRO_FUSEDO>: gate_up) adds the heads in order, which is the order k_gemm<RESID> with NW = n_heads sums its waves in:
+// one kernel boundary and one cold weight stream less per layer, same bits.
+// The W_o tiles are held by eight EXTRA waves (8..15) that do nothing else: they request their tiles at entry, sit at the
+// block's two barriers while waves 0..7 run the attention exactly as in the plain kernel, then multiply and store.  (Issued
+// by the attention waves themselves, the cold weight loads either hold q / K / V back -- loads return in issue order -- or,
+// issued behind them, are caught by the compiler's counted waits for K / V.)
+template <int KVF32, int ONE = 0, int FUSE = 0>
+__global__ __launch_bounds__((FUSE ? 2 : 1) * kAttnWaves * 64) void k_attn(AttnP p) {
+  static_assert(!FUSE || ONE == 1, "fused o_proj: one-row kernel only");
   constexpr int LPT = KVF32 ? 16 : 8;   // lanes per token row (each lane 16 bytes)
   constexpr int DPL = kHeadDim / LPT;   // dims per lane
   constexpr int TPW = 64 / LPT;         // tokens per wave per pass
@@ -880,10 +1002,51 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
   __shared__ __attribute__((aligned(16))) float so[kAttnWaves][TPW][kHeadDim];   // wave-private merge slices
   __shared__ float sl[kAttnWaves][TPW];
   __shared__ float pw[kAttnWaves][kHeadDim], pl[kAttnWaves];
+  __shared__ __attribute__((aligned(16))) unsigned char xsl[FUSE ? 2 * 3 * 4 * 16 : 16];   // FUSE: this head's output as B-operand pieces
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if ((int)blockIdx.x >= p.work_blocks) {
-    pf_run(p.pf, (int)blockIdx.x - p.work_blocks, (int)gridDim.x - p.work_blocks, tid, kAttnWaves * 64);
+    pf_run(p.pf, (int)blockIdx.x - p.work_blocks, (int)gridDim.x - p.work_blocks, tid, (FUSE ? 2 : 1) * kAttnWaves * 64);
     return;
+  }
+  if constexpr (FUSE) {
+    if (wave >= kAttnWaves) {   // the o_proj waves: tiles (nt, half * n_heads + head), nt = fq * fper + (wave - 8) + 8 i
+      const int fq = (int)blockIdx.x / p.n_heads, fper = p.NTo / kFuseQB, fh = (int)blockIdx.x % p.n_heads;
+      const int ow = wave - kAttnWaves, KTo = 2 * p.n_heads;
+      uint4 wo[kFuseOT][2];
+#pragma unroll
+      for (int i = 0; i < kFuseOT; ++i) {
+        int nl = ow + kAttnWaves * i;
+        nl = nl < fper ? nl : fper - 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wo[i][j] = smi_ldw(&p.Wo[((size_t)(fq * fper + nl) * KTo + j * p.n_heads + fh) * 64 + lane]);
+      }
+      __syncthreads();   // the attention waves' merge barrier
+      __syncthreads();   // the head's output is in xsl
+      // MFMA column 0 is the row (the other columns see the same operand)
+      bf16x8 bo[2][3];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) bo[j][s2] = *(const bf16x8*)(xsl + (size_t)((j * 3 + s2) * 4 + (lane >> 4)) * 16);
+#pragma unroll
+      for (int i = 0; i < kFuseOT; ++i) {
+        const int nl = ow + kAttnWaves * i, nt = fq * fper + nl;
+        if (nl < fper) {   // wave-uniform
+          f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {   // the order of k_gemm's chains: tile by tile, lo / mid / hi in their own accumulators
+            const bf16x8 a = __builtin_bit_cast(bf16x8, wo[i][j]);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bo[j][2], a2, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bo[j][1], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bo[j][0], a0, 0, 0, 0);
+          }
+          const f32x4 t = (a2 + a1) + a0;   // (lo + mid) + hi
+          if ((lane & 15) == 0)
+            *(float4*)(p.part_o + (size_t)fh * (p.NTo * 16) + nt * 16 + 4 * (lane >> 4)) = make_float4(t[0], t[1], t[2], t[3]);
+        }
+      }
+      return;
+    }
   }
   // Several rows: the query heads of one KV group (and a row's segments) are neighbours in the natural block order, but
   // consecutive block ids go to the 8 XCDs round-robin, so each of a group's 7 heads would pull the same K/V rows into a
@@ -893,7 +1056,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
     const unsigned total = (unsigned)p.work_blocks, xcd = bid & 7u, slot = bid >> 3, q8 = total >> 3, r8 = total & 7u;
     bid = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
   }
-  const int head = ONE == 1 ? (int)bid : ONE == 2 ? (int)bid % p.n_heads : (int)(bid / p.nseg) % p.n_heads,
+  const int head = ONE == 1 ? (FUSE ? (int)bid % p.n_heads : (int)bid) : ONE == 2 ? (int)bid % p.n_heads : (int)(bid / p.nseg) % p.n_heads,
             m = ONE == 1 ? 0 : ONE == 2 ? (int)bid / p.n_heads : (int)bid / (p.nseg * p.n_heads),
             seg = ONE ? 0 : (int)bid % p.nseg;
   const int tl = lane / LPT, dl = lane % LPT;
@@ -929,7 +1092,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
     for (int u = 0; u < UNR; ++u) {
       const int t = c0 + u * NGRP + grp;
       const int tc = sir ? (t < p.max_pos ? t : p.max_pos - 1) : (t < ctx ? t : ctx - 1);
-      const size_t off = (rowbase + tc) * kHeadDim + dl * DPL;
+      const size_t off = (ONE ? rowbase + tc : kv_row(p.km, slot, kvh, p.n_kv, p.max_pos, tc)) * kHeadDim + dl * DPL;
       if (KVF32) {
         kr[u] = *(const uint4*)((const float*)p.kcache + off);
         vr[u] = *(const uint4*)((const float*)p.vcache + off);
@@ -1032,14 +1195,21 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn(AttnP p) {
     }
     uint32_t hi, mi, lo;
     split3(O / Ls, hi, mi, lo);
-    const int k = head * kHeadDim + tid;
-    const int Mx = ONE == 1 ? 1 : p.M;
-    const size_t ob = xs_off(k >> 5, 0, (k >> 3) & 3, m, Mx) + (k & 7) * 2;
-    const size_t pl2 = (size_t)4 * Mx * 16;
-    *(uint16_t*)(p.xs_out + ob) = (uint16_t)hi;
-    *(uint16_t*)(p.xs_out + ob + pl2) = (uint16_t)mi;
-    *(uint16_t*)(p.xs_out + ob + 2 * pl2) = (uint16_t)lo;
+    if constexpr (FUSE) {   // B-operand pieces of this head's 64 values: [half][split][k8][8 bf16]
+      unsigned char* q = xsl + (size_t)((tid >> 5) * 12 + ((tid >> 3) & 3)) * 16 + (tid & 7) * 2;
+      *(uint16_t*)q = (uint16_t)hi;
+      *(uint16_t*)(q + 64) = (uint16_t)mi;
+      *(uint16_t*)(q + 128) = (uint16_t)lo;
+    } else {
+      const int Mx = ONE == 1 ? 1 : p.M;
+      const size_t ob = xs_off(o_ktile(head, tid, p.n_heads), 0, (tid >> 3) & 3, m, Mx) + (tid & 7) * 2;
+      const size_t pl2 = (size_t)4 * Mx * 16;
+      *(uint16_t*)(p.xs_out + ob) = (uint16_t)hi;
+      *(uint16_t*)(p.xs_out + ob + pl2) = (uint16_t)mi;
+      *(uint16_t*)(p.xs_out + ob + 2 * pl2) = (uint16_t)lo;
+    }
   }
+  if constexpr (FUSE) __syncthreads();   // the o_proj waves take over: xsl holds this head's output
 }
 
 // Prompt rows (prefill of more than one chunk): one WAVE per (row, head), eight consecutive rows of one head per
@@ -1068,7 +1238,6 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn_pf(AttnP p) {
   const int tl = lane / LPT, dl = lane % LPT;
   const RowDesc rd = p.rows[m];
   const int kvh = head / p.group;
-  const size_t rowbase = ((size_t)rd.slot * p.n_kv + kvh) * p.max_pos;
   const int ctx = rd.pos + 1;
   float qv[DPL];
   {
@@ -1084,7 +1253,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn_pf(AttnP p) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int t = c0 + u * TPW + tl;
-      const size_t off = (rowbase + (t < ctx ? t : ctx - 1)) * kHeadDim + dl * DPL;
+      const size_t off = kv_row(p.km, rd.slot, kvh, p.n_kv, p.max_pos, t < ctx ? t : ctx - 1) * kHeadDim + dl * DPL;
       if (KVF32) {
         kr[u] = *(const uint4*)((const float*)p.kcache + off);
         vr[u] = *(const uint4*)((const float*)p.vcache + off);
@@ -1149,8 +1318,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn_pf(AttnP p) {
   for (int g = 0; g < TPW; ++g) { O += so[wave][g][lane]; Ls += sl[wave][g]; }
   uint32_t hi, mi, lo;
   split3(O / Ls, hi, mi, lo);
-  const int k = head * kHeadDim + lane;
-  const size_t ob = xs_off(k >> 5, 0, (k >> 3) & 3, m, p.M) + (k & 7) * 2;
+  const size_t ob = xs_off(o_ktile(head, lane, p.n_heads), 0, (lane >> 3) & 3, m, p.M) + (lane & 7) * 2;
   const size_t pl2 = (size_t)4 * p.M * 16;
   *(uint16_t*)(p.xs_out + ob) = (uint16_t)hi;
   *(uint16_t*)(p.xs_out + ob + pl2) = (uint16_t)mi;
@@ -1176,7 +1344,7 @@ __global__ __launch_bounds__(1024) void k_attn_merge(AttnP p) {
     }
     uint32_t hi, mi, lo;
     split3(O / Ls, hi, mi, lo);
-    const size_t ob = xs_off(i >> 5, 0, (i >> 3) & 3, m, p.M) + (i & 7) * 2;
+    const size_t ob = xs_off(o_ktile(head, d, p.n_heads), 0, (d >> 3) & 3, m, p.M) + (d & 7) * 2;
     const size_t pl2 = (size_t)4 * p.M * 16;
     *(uint16_t*)(p.xs_out + ob) = (uint16_t)hi;
     *(uint16_t*)(p.xs_out + ob + pl2) = (uint16_t)mi;
@@ -1587,6 +1755,10 @@ bool cfg_ok(const smi_llm_cfg* c) {
   if (c->max_slots < 1 || c->max_slots > kMaxRows || c->max_positions < 2) return false;
   if ((c->num_heads * c->head_dim) % 32) return false;
   if (c->kv_dtype != 0 && c->kv_dtype != 1) return false;
+  if (c->kv_page_tokens != 0) {   // paged KV: a power of two in 16..1024 that divides max_positions, and a pool of at least one page
+    const int t = c->kv_page_tokens;
+    if (t < 16 || t > 1024 || (t & (t - 1)) || c->max_positions % t || c->kv_pages < 1) return false;
+  }
   return true;
 }
 
@@ -1629,6 +1801,8 @@ struct smi_llm {
   float* sspart;       // [kMaxRows][NTh * 4] partial sums of squares of h (RMSNorm), one per 4 columns
   // prefill workspace for up to big_rows rows at once (allocated at the first multi-chunk prefill)
   float *bh, *bq; unsigned char *bxs_h, *bxs_attn, *bxs_act; float* bss; int big_rows;
+  float *part_o, *h2;  // fused o_proj (one row): per-head partials [heads][H]; h + o_proj [H]
+  int fuse_o;          // config allows the fused o_proj (SPARKMI_NO_FUSE_O=1 turns it off)
   RowDesc* rows;       // live decode rows [kMaxRows]
   RowDesc* plan;       // prefill plan
   size_t plan_cap;     // rows
@@ -1636,6 +1810,13 @@ struct smi_llm {
   int64_t* hist; int32_t *count, *finished, *step;
   void *kcache, *vcache; size_t kv_layer_elems;
   int B; int started;
+  // paged KV cache (cfg.kv_page_tokens > 0): page table [max_slots][ppslot] on the device, mirrored on the host
+  int paged, pshift, ppslot;
+  int32_t* ptab;
+  std::vector<int32_t> hptab;
+  std::vector<int32_t> free_pages;
+  int slot_pages[kMaxRows];     // pages a slot holds
+  int plen[kMaxRows];           // plain (non-session) generation: prompt length per slot
   Ctl hctl; Ctl* ctl;   // host copy / device block of the generation controls
   int admit_seq;        // sequences admitted so far in this generation / session (sampler stream ids)
   // continuous batching (smi_llm_session_*): live rows map to arbitrary KV slots
@@ -1661,6 +1842,38 @@ struct smi_llm {
 };
 
 namespace {
+
+// ---- paged KV cache: host-side page allocator.  A slot's row of the table lists the pages of its positions in order.
+void pages_release(smi_llm* L, int slot) {
+  for (int i = 0; i < L->slot_pages[slot]; ++i) L->free_pages.push_back(L->hptab[(size_t)slot * L->ppslot + i]);
+  L->slot_pages[slot] = 0;
+}
+// Makes every listed slot hold pages for `tokens[i]` positions; all or nothing (SMI_ENOMEM when the pool is short).
+int pages_ensure(smi_llm* L, const int* slots, const int* tokens, int n, hipStream_t st) {
+  if (!L->paged) return SMI_OK;
+  int extra = 0;
+  for (int i = 0; i < n; ++i) {
+    const int need = (tokens[i] + (1 << L->pshift) - 1) >> L->pshift;
+    if (need > L->ppslot) { smi_set_error("KV pages: %d tokens exceed max_positions", tokens[i]); return SMI_EINVAL; }
+    extra += need > L->slot_pages[slots[i]] ? need - L->slot_pages[slots[i]] : 0;
+  }
+  if (extra == 0) return SMI_OK;
+  if (extra > (int)L->free_pages.size()) {
+    smi_set_error("KV page pool exhausted: %d more pages of %d tokens needed, %zu of %d free (retire a sequence or enlarge kv_pages)",
+                  extra, 1 << L->pshift, L->free_pages.size(), L->cfg.kv_pages);
+    return SMI_ENOMEM;
+  }
+  for (int i = 0; i < n; ++i) {
+    const int sl = slots[i], need = (tokens[i] + (1 << L->pshift) - 1) >> L->pshift;
+    while (L->slot_pages[sl] < need) {
+      L->hptab[(size_t)sl * L->ppslot + L->slot_pages[sl]++] = L->free_pages.back();
+      L->free_pages.pop_back();
+    }
+  }
+  SMI_HIP(hipMemcpyAsync(L->ptab, L->hptab.data(), L->hptab.size() * 4, hipMemcpyHostToDevice, st));
+  return SMI_OK;
+}
+KvMap kv_map(const smi_llm* L) { return KvMap{L->paged ? L->ptab : nullptr, L->pshift, L->ppslot}; }
 
 template <int MT, int NTB, int NW, int U, int WB, int PRO, int EPI, int H = 1, int OCC = 1>
 int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
@@ -1699,6 +1912,13 @@ int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
   SMI_REQUIRE(groups == 1 || EPI != EPI_LM, "lm_head takes at most 32 rows per launch");
   constexpr int kLean = (MT == 1 && EPI != EPI_LM) ? 1 : 0;
   if (kLean && p.ldsb > 0 && !p.stamps && p.M == 1 && p.lt_shift == 4) {
+    if constexpr (PRO == PRO_NORM && EPI == EPI_SWIGLU && H == 1 && MT == 1) {
+      if (p.part_o) {   // one row behind the fused o_proj: the operand is built in the kernel from the per-head partials
+        hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO_FUSEDO, EPI, 0, H, OCC, 2>), dim3(work + helpers, groups), dim3(NW * 64), lds + 1024, st, p);
+        SMI_LAUNCH_CHECK();
+        return SMI_OK;
+      }
+    }
     if (L->cfg.kv_dtype)
       hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO, EPI, 1, H, OCC, 2 * kLean>), dim3(work + helpers, groups), dim3(NW * 64), lds, st, p);
     else
@@ -1768,13 +1988,17 @@ template <int KVF32>
 int launch_attn(smi_llm* L, AttnP a, int helpers_ok, hipStream_t st) {
   a.nseg = L->attn_seg < 1 ? 1 : L->attn_seg;
   a.work_blocks = a.n_heads * a.M * a.nseg;
+  const bool fuse = a.M == 1 && a.nseg == 1 && a.slot_is_row && a.part_o;
+  if (fuse) a.work_blocks *= kFuseQB;
   if (a.nseg > 1) {
     int rc = ensure_apart(L, (size_t)a.M * a.n_heads * a.nseg * 66);
     if (rc) return rc;
     a.part = L->apart;
   }
   const int helpers = (helpers_ok && L->prefetch && a.M <= 8 && a.work_blocks < 232) ? (256 - a.work_blocks) / 8 * 8 : 0;
-  if (a.M == 1 && a.nseg == 1 && a.slot_is_row)
+  if (fuse)
+    hipLaunchKernelGGL((k_attn<KVF32, 1, 1>), dim3(a.work_blocks + helpers), dim3(2 * kAttnWaves * 64), 0, st, a);
+  else if (a.M == 1 && a.nseg == 1 && a.slot_is_row)
     hipLaunchKernelGGL((k_attn<KVF32, 1>), dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
   else if (a.nseg == 1 && a.slot_is_row)
     hipLaunchKernelGGL((k_attn<KVF32, 2>), dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
@@ -1788,8 +2012,27 @@ int launch_attn(smi_llm* L, AttnP a, int helpers_ok, hipStream_t st) {
   return SMI_OK;
 }
 
+// One live row in its own slot, one context segment: the attention kernel also computes its head's share of the o_proj
+// (k_attn<.., FUSE>), gate_up builds its operand from those partials (PRO_FUSEDO) and down_proj adds its residual from h2;
+// the o_proj kernel is not launched.  The predicate is the one launch_attn picks the one-row kernel by.
+bool fuse_o_now(const smi_llm* L, const RowDesc* rows, int M) {
+  return L->fuse_o && !L->paged && M == 1 && rows == L->rows && L->identity_slots && L->attn_seg <= 1;
+}
+
+// o_proj: NW = number of heads, so that wave w sums head w's two (head-interleaved) k tiles -- the per-head partial the
+// fused path produces -- and the block's in-order sum over the waves is the fused consumer's in-order sum over the heads.
+int launch_oproj(const smi_llm* L, const GemmP& p, int M, hipStream_t st) {
+  switch (L->cfg.num_heads) {
+    case 14: return M <= 8 ? launch_gemm<1, 14, 2, 1, PRO_PLAIN, EPI_RESID, 4>(L, p, st) : launch_gemm<1, 14, 2, 1, PRO_PLAIN, EPI_RESID, 1, 0>(L, p, st);
+    case 4: return M <= 8 ? launch_gemm<1, 4, 2, 1, PRO_PLAIN, EPI_RESID, 4>(L, p, st) : launch_gemm<1, 4, 2, 1, PRO_PLAIN, EPI_RESID, 1, 0>(L, p, st);
+    default:   // other head counts: no fused path (smi_llm_create leaves fuse_o off), eight waves as before
+      return M <= 8 ? launch_gemm<1, 8, 4, 1, PRO_PLAIN, EPI_RESID, 4>(L, p, st) : launch_gemm<1, 8, 4, 1, PRO_PLAIN, EPI_RESID, 1, 0>(L, p, st);
+  }
+}
+
 int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, float* logits, hipStream_t st) {
   const smi_llm_cfg& c = L->cfg;
+  const bool fused = fuse_o_now(L, rows, M);
   GemmP p;
   memset(&p, 0, sizeof(p));
   p.M = M; p.rows = rows; p.eps = c.rms_eps; p.sspart = L->sspart; p.npart = L->NTh * 4;
@@ -1800,7 +2043,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       p.Y = L->qbuf; p.bias = (const float*)sec(L, SMI_LLM_BQKV, layer);
       p.rope = (const float2*)sec(L, SMI_LLM_ROPE, 0);
       p.kcache = kv_layer(L, L->kcache, layer); p.vcache = kv_layer(L, L->vcache, layer);
-      p.q_dim = L->Q; p.kv_dim = L->KV; p.n_kv = c.num_kv_heads; p.max_pos = c.max_positions;
+      p.q_dim = L->Q; p.kv_dim = L->KV; p.n_kv = c.num_kv_heads; p.max_pos = c.max_positions; p.km = kv_map(L);
       // helpers: first half of this layer's gate_up slices (consumer block b reads weight tile row b)
       p.pf = PfDesc{sec(L, SMI_LLM_WGU, layer), L->KTh * 1024, L->NTgu, 0, (L->NTgu / 8 + 1) / 2};
       switch (L->tune[0]) {   // SPARKMI_TUNE=q,o,g,d: block-shape sweeps (diagnostics; NW changes the summation order)
@@ -1813,13 +2056,15 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       memset(&a, 0, sizeof(a));
       a.q = L->qbuf; a.kcache = kv_layer(L, L->kcache, layer); a.vcache = kv_layer(L, L->vcache, layer);
       a.rows = rows; a.xs_out = L->xs_attn; a.M = M; a.q_dim = L->Q; a.n_kv = c.num_kv_heads;
-      a.group = c.num_heads / c.num_kv_heads; a.max_pos = c.max_positions; a.n_heads = c.num_heads;
-      a.slot_is_row = rows == L->rows && L->identity_slots;   // the live decode rows are (slot b, ...) in order
+      a.group = c.num_heads / c.num_kv_heads; a.max_pos = c.max_positions; a.n_heads = c.num_heads; a.km = kv_map(L);
+      a.slot_is_row = rows == L->rows && L->identity_slots && !L->paged;   // the live decode rows are (slot b, ...) in order, slots contiguous
       // helpers: second half of this layer's gate_up slices
       a.pf = PfDesc{sec(L, SMI_LLM_WGU, layer), L->KTh * 1024, L->NTgu, (L->NTgu / 8 + 1) / 2, (L->NTgu + 7) / 8};
+      if (fused) { a.Wo = (const uint4*)sec(L, SMI_LLM_WO, layer); a.NTo = L->NTh; a.part_o = L->part_o; }
       return c.kv_dtype ? launch_attn<1>(L, a, 1, st) : launch_attn<0>(L, a, 1, st);
     }
     case KO:   // h += Wo attn; emits the post-attention norm's operand
+      if (fused) return SMI_OK;   // done by the attention kernel (per-head partials) and gate_up's prologue
       p.W = (const uint4*)sec(L, SMI_LLM_WO, layer); p.NT = L->NTh; p.KT = L->KTq;
       p.XS = L->xs_attn; p.Y = L->h;
       p.XSout = L->xs_h; p.gamma_next = (const float*)sec(L, SMI_LLM_LN2, layer); p.ssout = L->sspart;
@@ -1832,22 +2077,28 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
         case 5: return launch_gemm<1, 8, 4, 1, PRO_PLAIN, EPI_RESID>(L, p, st);
         case 6: return launch_gemm<1, 8, 4, 1, PRO_PLAIN, EPI_RESID, 4>(L, p, st);
         default:   // four row parts up to 8 rows: 629.8 -> 626.0 us per step once the prologues were down to one round trip
-          return M <= 8 ? launch_gemm<1, 8, 4, 1, PRO_PLAIN, EPI_RESID, 4>(L, p, st) : launch_gemm<1, 8, 4, 1, PRO_PLAIN, EPI_RESID, 1, 0>(L, p, st);
+          return launch_oproj(L, p, M, st);
       }
     case KGU:
       p.W = (const uint4*)sec(L, SMI_LLM_WGU, layer); p.NT = L->NTgu; p.KT = L->KTh;
       p.XS = L->xs_h; p.XSout = L->xs_act;
+      if (fused) {
+        p.part_o = L->part_o; p.n_oheads = c.num_heads; p.hres = L->h; p.h2out = L->h2;
+        p.gam = (const float*)sec(L, SMI_LLM_LN2, layer);
+      }
       switch (L->tune[2]) {
         case 2: return launch_gemm<1, 16, 2, 1, PRO_NORM, EPI_SWIGLU>(L, p, st);
         case 5: return launch_gemm<2, 4, 8, 1, PRO_NORM, EPI_SWIGLU>(L, p, st);
         case 6: return launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_SWIGLU, 1, 2, 6>(L, p, st);   // spills at 80 VGPRs: 2.4x slower
         case 7: return launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_SWIGLU, 1, 2>(L, p, st);      // 114 VGPRs: 2 blocks per CU, 96 of 608 wait
+        case 8: return launch_gemm<2, 8, 2, 2, PRO_NORM, EPI_SWIGLU, 1, 2, 4>(L, p, st);   // two tiles per block: half the blocks re-read the fused o_proj partials
         default:   // 69 VGPRs (>= 6 waves per SIMD): all 608 blocks are resident at once, no second round (step 745 -> 705 us)
           return launch_gemm<1, 8, 2, 2, PRO_NORM, EPI_SWIGLU, 1, 2, 6>(L, p, st);
       }
     case KD:   // h += Wd act; emits the next layer's input-norm operand (or the final norm's)
       p.W = (const uint4*)sec(L, SMI_LLM_WD, layer); p.NT = L->NTh; p.KT = L->KTi;
       p.XS = L->xs_act; p.Y = L->h;
+      if (fused) p.Yin = L->h2;   // h + o_proj, left there by gate_up's block 0
       p.XSout = L->xs_h; p.ssout = L->sspart;
       p.gamma_next = layer + 1 < c.num_layers ? (const float*)sec(L, SMI_LLM_LN1, layer + 1)
                                               : (const float*)sec(L, SMI_LLM_FINAL_NORM, 0);
@@ -1944,7 +2195,7 @@ int launch_layers_big(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
     p.W = (const uint4*)sec(L, SMI_LLM_WQKV, l); p.NT = L->NTqkv; p.KT = L->KTh; p.XS = L->bxs_h;
     p.Y = L->bq; p.bias = (const float*)sec(L, SMI_LLM_BQKV, l); p.rope = (const float2*)sec(L, SMI_LLM_ROPE, 0);
     p.kcache = kv_layer(L, L->kcache, l); p.vcache = kv_layer(L, L->vcache, l);
-    p.q_dim = L->Q; p.kv_dim = L->KV; p.n_kv = c.num_kv_heads; p.max_pos = c.max_positions;
+    p.q_dim = L->Q; p.kv_dim = L->KV; p.n_kv = c.num_kv_heads; p.max_pos = c.max_positions; p.km = kv_map(L);
     if ((rc = grouped ? launch_gemm<1, 16, 2, 1, PRO_NORM, EPI_QKV>(L, p, st) : launch_pgemm<PRO_NORM, EPI_QKV>(L, p, st))) return rc;
     if (l == c.num_layers - 1) break;
     // attention
@@ -1952,7 +2203,7 @@ int launch_layers_big(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
     memset(&a, 0, sizeof(a));
     a.q = L->bq; a.kcache = p.kcache; a.vcache = p.vcache; a.rows = rows; a.xs_out = L->bxs_attn; a.M = M;
     a.q_dim = L->Q; a.n_kv = c.num_kv_heads; a.group = c.num_heads / c.num_kv_heads; a.max_pos = c.max_positions;
-    a.n_heads = c.num_heads; a.slot_is_row = 0;
+    a.n_heads = c.num_heads; a.slot_is_row = 0; a.km = kv_map(L);
     if (L->tune2 & 1024) {   // SPARKMI_TUNE2 bit 1024: the decode attention kernel per prompt row (the path before k_attn_pf)
       if ((rc = c.kv_dtype ? launch_attn<1>(L, a, 0, st) : launch_attn<0>(L, a, 0, st))) return rc;
     } else {
@@ -1967,7 +2218,7 @@ int launch_layers_big(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
     o.M = M; o.rows = rows; o.eps = c.rms_eps; o.sspart = L->bss; o.npart = npart;
     o.W = (const uint4*)sec(L, SMI_LLM_WO, l); o.NT = L->NTh; o.KT = L->KTq; o.XS = L->bxs_attn; o.Y = L->bh;
     o.XSout = L->bxs_h; o.gamma_next = (const float*)sec(L, SMI_LLM_LN2, l); o.ssout = L->bss;
-    if ((rc = grouped ? launch_gemm<1, 8, 4, 1, PRO_PLAIN, EPI_RESID>(L, o, st) : launch_pgemm<PRO_PLAIN, EPI_RESID>(L, o, st))) return rc;
+    if ((rc = grouped ? launch_oproj(L, o, M, st) : launch_pgemm<PRO_PLAIN, EPI_RESID>(L, o, st))) return rc;
     // gate_up
     GemmP g;
     memset(&g, 0, sizeof(g));
@@ -2088,12 +2339,24 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   { L->tune[0] = L->tune[1] = L->tune[2] = L->tune[3] = 0; const char* e = getenv("SPARKMI_TUNE"); if (e) sscanf(e, "%d,%d,%d,%d", &L->tune[0], &L->tune[1], &L->tune[2], &L->tune[3]); }
   L->bh = L->bq = nullptr; L->bxs_h = L->bxs_attn = L->bxs_act = nullptr; L->bss = nullptr; L->big_rows = 0;
   L->prefetch = getenv("SPARKMI_NO_PREFETCH") ? 0 : 1;
+  L->part_o = nullptr; L->h2 = nullptr;
+  L->fuse_o = !getenv("SPARKMI_NO_FUSE_O") && (cfg->num_heads == 14 || cfg->num_heads == 4) && cfg->num_heads <= kMaxOHeads &&
+              L->NTh % kFuseQB == 0 && L->NTh / kFuseQB <= kAttnWaves * kFuseOT && L->KTh * 8 <= 256;
   { const char* e = getenv("SPARKMI_TUNE2"); L->tune2 = e ? atoi(e) : 0; }
   { const char* e = getenv("SPARKMI_PGEMM_MIN_ROWS"); L->pgemm_min_rows = e ? atoi(e) : 3072; }
   L->graph = nullptr; L->graph_B = 0; L->graph_seg = 1; L->graph_ident = 1; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->ctl = nullptr; L->admit_seq = 0; memset(&L->hctl, 0, sizeof(L->hctl));
   L->session = 0; L->identity_slots = 1; L->attn_seg = 1; L->apart = nullptr; L->apart_floats = 0; memset(L->slot_busy, 0, sizeof(L->slot_busy)); memset(L->slot_len, 0, sizeof(L->slot_len));
   const size_t esz = cfg->kv_dtype ? 4 : 2;
+  L->paged = cfg->kv_page_tokens > 0; L->pshift = 0; L->ppslot = 0; L->ptab = nullptr;
+  memset(L->slot_pages, 0, sizeof(L->slot_pages)); memset(L->plen, 0, sizeof(L->plen));
   L->kv_layer_elems = (size_t)cfg->max_slots * cfg->num_kv_heads * cfg->max_positions * kHeadDim;
+  if (L->paged) {
+    while ((1 << L->pshift) < cfg->kv_page_tokens) ++L->pshift;
+    L->ppslot = cfg->max_positions >> L->pshift;
+    L->kv_layer_elems = (size_t)cfg->kv_pages * cfg->num_kv_heads * cfg->kv_page_tokens * kHeadDim;
+    L->hptab.assign((size_t)cfg->max_slots * L->ppslot, 0);
+    for (int pg = cfg->kv_pages - 1; pg >= 0; --pg) L->free_pages.push_back(pg);
+  }
   const size_t kvbytes = L->kv_layer_elems * esz * cfg->num_layers;
 #define SMI_ALLOC(ptr, bytes)                                                      \
   if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) {                          \
@@ -2107,6 +2370,8 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   SMI_ALLOC(L->xs_attn, (size_t)kMaxRows * L->Q * 6);
   SMI_ALLOC(L->xs_act, (size_t)kMaxRows * L->I * 6);
   SMI_ALLOC(L->sspart, (size_t)kMaxRows * L->NTh * 4 * 4);
+  SMI_ALLOC(L->part_o, (size_t)kMaxOHeads * L->H * 4);
+  SMI_ALLOC(L->h2, (size_t)L->H * 4);
   SMI_ALLOC(L->rows, kMaxRows * sizeof(RowDesc));
   SMI_ALLOC(L->pval, (size_t)L->lm_cap * kMaxRows * 4);
   SMI_ALLOC(L->pidx, (size_t)L->lm_cap * kMaxRows * 4);
@@ -2116,6 +2381,10 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   SMI_ALLOC(L->step, 4);
   SMI_ALLOC(L->ctl, sizeof(Ctl));
   SMI_HIP(hipMemset(L->ctl, 0, sizeof(Ctl)));
+  if (L->paged) {
+    SMI_ALLOC(L->ptab, L->hptab.size() * 4);
+    SMI_HIP(hipMemset(L->ptab, 0, L->hptab.size() * 4));
+  }
   SMI_ALLOC(L->logits, (size_t)kMaxRows * cfg->vocab_size * 4);
   SMI_ALLOC(L->tok, kMaxRows * 4);
   SMI_ALLOC(L->cand_v, (size_t)kMaxRows * kCandCap * 4);
@@ -2152,8 +2421,8 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
 int smi_llm_destroy(smi_llm* L) {
   if (!L) return SMI_OK;
   if (L->graph) (void)hipGraphExecDestroy(L->graph);
-  void* ptrs[] = {L->h, L->qbuf, L->xs_h, L->xs_attn, L->xs_act, L->sspart, L->rows, L->plan, L->pval, L->pidx, L->hist,
-                  L->count, L->finished, L->step, L->ctl, L->kcache, L->vcache, L->logits, L->tok, L->cand_v, L->cand_i, L->cand_n, L->stamps, L->bh, L->bq, L->bxs_h, L->bxs_attn, L->bxs_act, L->bss, L->apart};
+  void* ptrs[] = {L->h, L->qbuf, L->xs_h, L->xs_attn, L->xs_act, L->sspart, L->part_o, L->h2, L->rows, L->plan, L->pval, L->pidx, L->hist,
+                  L->count, L->finished, L->step, L->ctl, L->ptab, L->kcache, L->vcache, L->logits, L->tok, L->cand_v, L->cand_i, L->cand_n, L->stamps, L->bh, L->bq, L->bxs_h, L->bxs_attn, L->bxs_act, L->bss, L->apart};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (L->ev0) (void)hipEventDestroy(L->ev0);
@@ -2253,11 +2522,18 @@ int smi_llm_prefill(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, 
   SMI_REQUIRE(L && ids && lens, "smi_llm_prefill: null argument");
   SMI_REQUIRE(B >= 1 && B <= L->cfg.max_slots, "smi_llm_prefill: B=%d outside 1..%d", B, L->cfg.max_slots);
   hipStream_t st = (hipStream_t)stream;
+  int32_t slots[kMaxRows];
+  for (int b = 0; b < kMaxRows; ++b) slots[b] = b;
+  if (L->paged) {   // a new generation: every page back to the pool, then what the prompts need
+    for (int b = 0; b < kMaxRows; ++b) pages_release(L, b);
+    for (int b = 0; b < B; ++b) SMI_REQUIRE(lens[b] >= 1 && lens[b] < L->cfg.max_positions, "smi_llm_prefill: lens[%d]=%d", b, lens[b]);
+    int rcp = pages_ensure(L, slots, lens, B, st);
+    if (rcp) return rcp;
+  }
+  for (int b = 0; b < B; ++b) L->plen[b] = lens[b];
   for (int b = 0; b < kMaxRows; ++b) L->hctl.seqid[b] = b;
   L->admit_seq = B;
   { int rc0 = upload_ctl(L, eos_ids, n_eos, st); if (rc0) return rc0; }
-  int32_t slots[kMaxRows];
-  for (int b = 0; b < kMaxRows; ++b) slots[b] = b;
   SMI_HIP(hipMemsetAsync(L->count, 0, kMaxRows * 4, st));
   SMI_HIP(hipMemsetAsync(L->finished, 0, kMaxRows * 4, st));
   SMI_HIP(hipMemsetAsync(L->step, 0, 4, st));
@@ -2281,6 +2557,8 @@ int smi_llm_session_begin(smi_llm* L, const int64_t* eos_ids, int n_eos, void* s
   hipStream_t st = (hipStream_t)stream;
   memset(L->hctl.seqid, 0, sizeof(L->hctl.seqid));
   L->admit_seq = 0;
+  if (L->paged)
+    for (int b = 0; b < kMaxRows; ++b) pages_release(L, b);
   { int rc0 = upload_ctl(L, eos_ids, n_eos, st); if (rc0) return rc0; }
   SMI_HIP(hipMemsetAsync(L->count, 0, kMaxRows * 4, st));
   SMI_HIP(hipMemsetAsync(L->finished, 0, kMaxRows * 4, st));
@@ -2328,6 +2606,10 @@ int smi_llm_admit(smi_llm* L, const int64_t* ids, const int32_t* lens, int n, in
   for (int sl = 0; sl < L->cfg.max_slots && k < n; ++sl)
     if (!L->slot_busy[sl]) slots[k++] = sl;
   SMI_REQUIRE(k == n, "smi_llm_admit: no free KV slot");
+  if (L->paged) {
+    for (int b = 0; b < n; ++b) SMI_REQUIRE(lens[b] >= 1 && lens[b] < L->cfg.max_positions, "smi_llm_admit: lens[%d]=%d", b, lens[b]);
+    if ((rc = pages_ensure(L, slots, lens, n, st))) return rc;   // all or nothing: a short pool admits nobody
+  }
   for (int b = 0; b < n; ++b) L->hctl.seqid[slots[b]] = L->admit_seq++;
   SMI_HIP(hipMemcpyAsync(L->ctl, &L->hctl, sizeof(Ctl), hipMemcpyHostToDevice, st));
   size_t tail = 0;
@@ -2368,6 +2650,7 @@ int smi_llm_retire(smi_llm* L, int slot, void* stream) {
     if (live[i].slot == slot) { live.erase(live.begin() + (long)i); break; }
   L->slot_busy[slot] = 0;
   L->slot_len[slot] = 0;
+  if (L->paged) pages_release(L, slot);   // its pages go back to the pool (stale table entries are never read: no live row names the slot)
   return session_set_rows(L, live, st);
 }
 
@@ -2404,6 +2687,17 @@ int smi_llm_decode(smi_llm* L, int n_steps, void* stream) {
   }
   hipStream_t st = (hipStream_t)stream;
   int rc;
+  if (L->paged && n_steps > 0) {   // every live sequence grows by n_steps positions: their pages first, all or nothing
+    int sl[kMaxRows], need[kMaxRows], n = 0;
+    if (L->session) {
+      for (int s2 = 0; s2 < kMaxRows; ++s2)
+        if (L->slot_busy[s2]) { sl[n] = s2; need[n++] = L->slot_len[s2] + n_steps; }
+    } else {
+      for (int b = 0; b < L->B; ++b) { sl[n] = b; need[n++] = L->plen[b] + L->steps_launched + n_steps; }
+    }
+    for (int i = 0; i < n; ++i) need[i] = need[i] < L->cfg.max_positions ? need[i] : L->cfg.max_positions;
+    if ((rc = pages_ensure(L, sl, need, n, st))) return rc;
+  }
   {   // context bound of this call -> attention segments (the partial buffer must exist before a capture starts)
     int bound = L->max_len + L->steps_launched + n_steps;
     if (L->session) {
@@ -2475,6 +2769,13 @@ int smi_llm_steps(smi_llm* L) {
   return s;
 }
 
+int smi_llm_kv_pages(smi_llm* L, int32_t* total, int32_t* free_pages) {
+  SMI_REQUIRE(L && total && free_pages, "smi_llm_kv_pages: null argument");
+  *total = L->paged ? L->cfg.kv_pages : 0;
+  *free_pages = L->paged ? (int32_t)L->free_pages.size() : 0;
+  return SMI_OK;
+}
+
 int smi_llm_get_tokens(smi_llm* L, int64_t* out, int32_t* lens, int cap, void* stream) {
   SMI_REQUIRE(L && out && lens && cap >= 0, "smi_llm_get_tokens: bad argument");
   hipStream_t st = (hipStream_t)stream;
@@ -2501,6 +2802,11 @@ int smi_llm_forward_logits(smi_llm* L, const int64_t* ids, int S, float* logits_
   const size_t nchunks = ((size_t)S + kMaxRows - 1) / kMaxRows;
   int rc;
   L->attn_seg = segs_for(S);
+  if (L->paged) {
+    for (int b = 0; b < kMaxRows; ++b) pages_release(L, b);
+    const int s0 = 0;
+    if ((rc = pages_ensure(L, &s0, &S, 1, st))) return rc;
+  }
   if ((rc = ensure_plan(L, nchunks * kMaxRows))) return rc;
   L->host_rows.assign(nchunks * kMaxRows, RowDesc{0, 0, 0, 0});
   for (int t = 0; t < S; ++t) {
@@ -2553,6 +2859,7 @@ int smi_llm_time_kernel(smi_llm* L, int kernel, int layer, int iters, float* ms_
   SMI_REQUIRE(L && ms_avg && iters > 0, "smi_llm_time_kernel: bad argument");
   SMI_REQUIRE((kernel >= 0 && kernel <= 7) || (kernel >= 16 && kernel <= 16 + KD), "smi_llm_time_kernel: kernel id %d", kernel);
   if (!L->started) { smi_set_error("smi_llm_time_kernel needs a started generation (prefill first)"); return SMI_ESTATE; }
+  if (L->paged && kernel != 7) { smi_set_error("smi_llm_time_kernel: the per-kernel probes need a contiguous KV cache (kv_page_tokens = 0)"); return SMI_ESTATE; }
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (kernel == 7) {

@@ -24,7 +24,8 @@ class SparkMIError(RuntimeError):
 class LLMCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "vocab_size", "hidden_size", "num_layers", "num_heads", "num_kv_heads", "head_dim",
-        "intermediate_size", "max_slots", "max_positions", "kv_dtype", "use_graph")] + [("rms_eps", C.c_float)]
+        "intermediate_size", "max_slots", "max_positions", "kv_dtype", "use_graph")] + [("rms_eps", C.c_float),
+                                                                                        ("kv_page_tokens", C.c_int32), ("kv_pages", C.c_int32)]
 
 
 class VocCfg(C.Structure):
@@ -77,6 +78,7 @@ SYMBOLS = {
     "smi_llm_status": (_I, [_VP, _P(C.c_int32), _P(C.c_int32), _VP]),
     "smi_llm_forward_logits": (_I, [_VP, _P(C.c_int64), _I, _VP, _VP]),
     "smi_llm_steps": (_I, [_VP]),
+    "smi_llm_kv_pages": (_I, [_VP, _P(C.c_int32), _P(C.c_int32)]),
     "smi_llm_time_kernel": (_I, [_VP, _I, _I, _I, _P(C.c_float), _VP]),
     "smi_llm_debug_stamps": (_I, [_VP, _I, _I, _P(C.c_double)]),
     "smi_voc_arena_count": (_I, [_P(VocCfg)]),

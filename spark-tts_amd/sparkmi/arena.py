@@ -63,6 +63,20 @@ def rope_pair_perm(n_heads: int, head_dim: int = 64) -> np.ndarray:
     return (np.arange(n_heads)[:, None] * head_dim + within[None, :]).reshape(-1)
 
 
+def o_proj_col_perm(n_heads: int, head_dim: int = 64) -> np.ndarray:
+    """Column (input-feature) order of W_o in the arena: 32-column k tiles head-interleaved -- tile (half * n_heads + head)
+    holds dims 32 * half .. 32 * half + 31 of `head` -- so that the o_proj kernel's k-tile -> wave map (tile mod n_heads)
+    hands each wave one head: the per-head partial sums the fused one-row attention kernel produces itself."""
+    if head_dim != 64:
+        raise ValueError("head_dim must be 64")
+    src = np.empty(n_heads * head_dim, dtype=np.int64)
+    for half in range(2):
+        for h in range(n_heads):
+            t = half * n_heads + h
+            src[t * 32: (t + 1) * 32] = h * head_dim + half * 32 + np.arange(32)
+    return src
+
+
 def rope_table(cfg: LLMConfig, max_positions: int) -> np.ndarray:
     """(cos, sin) [max_positions][head_dim/2] float32, computed with the same torch ops as
     transformers' Qwen2RotaryEmbedding (modeling_qwen2.py:81-102) so the bits match the oracle."""
@@ -75,12 +89,13 @@ def rope_table(cfg: LLMConfig, max_positions: int) -> np.ndarray:
 
 
 def llm_cfg_struct(cfg: LLMConfig, max_slots: int, max_positions: int, kv_dtype: str,
-                   use_graph: bool) -> _lib.LLMCfg:
+                   use_graph: bool, kv_page_tokens: int = 0, kv_pages: int = 0) -> _lib.LLMCfg:
     return _lib.LLMCfg(
         vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_layers=cfg.num_hidden_layers,
         num_heads=cfg.num_attention_heads, num_kv_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
         intermediate_size=cfg.intermediate_size, max_slots=max_slots, max_positions=max_positions,
-        kv_dtype={"bf16": 0, "f32": 1}[kv_dtype], use_graph=int(use_graph), rms_eps=cfg.rms_norm_eps)
+        kv_dtype={"bf16": 0, "f32": 1}[kv_dtype], use_graph=int(use_graph), rms_eps=cfg.rms_norm_eps,
+        kv_page_tokens=int(kv_page_tokens), kv_pages=int(kv_pages))
 
 
 def pack_llm_arena(cfg: LLMConfig, weights: Mapping[str, np.ndarray], cs: _lib.LLMCfg,
@@ -107,6 +122,7 @@ def pack_llm_arena(cfg: LLMConfig, weights: Mapping[str, np.ndarray], cs: _lib.L
     f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
     pq = rope_pair_perm(cfg.num_attention_heads, cfg.head_dim)
     pk = rope_pair_perm(cfg.num_key_value_heads, cfg.head_dim)
+    po = o_proj_col_perm(cfg.num_attention_heads, cfg.head_dim)
     for i in range(cfg.num_hidden_layers):
         p = f"model.layers.{i}."
         wq, wk, wv = (f32(weights[p + f"self_attn.{n}_proj.weight"]) for n in "qkv")
@@ -114,7 +130,7 @@ def pack_llm_arena(cfg: LLMConfig, weights: Mapping[str, np.ndarray], cs: _lib.L
         put(_lib.LLM_LN1, i, f32(weights[p + "input_layernorm.weight"]))
         put(_lib.LLM_WQKV, i, pack_tiles(np.concatenate([wq[pq], wk[pk], wv], axis=0), rep, p + "self_attn.qkv"))
         put(_lib.LLM_BQKV, i, np.concatenate([bq[pq], bk[pk], bv]))
-        put(_lib.LLM_WO, i, pack_tiles(f32(weights[p + "self_attn.o_proj.weight"]), rep, p + "self_attn.o_proj"))
+        put(_lib.LLM_WO, i, pack_tiles(f32(weights[p + "self_attn.o_proj.weight"])[:, po], rep, p + "self_attn.o_proj"))
         put(_lib.LLM_LN2, i, f32(weights[p + "post_attention_layernorm.weight"]))
         g, u = f32(weights[p + "mlp.gate_proj.weight"]), f32(weights[p + "mlp.up_proj.weight"])
         gu = np.empty((2 * g.shape[0], g.shape[1]), np.float32)

@@ -46,9 +46,12 @@ class SparkLLM:
     def __init__(self, cfg: LLMConfig, weights: Mapping[str, np.ndarray],
                  device: Union[str, torch.device] = "cuda:0", max_slots: int = 1,
                  max_positions: int = 4096, kv_dtype: str = "bf16", use_graph: bool = True,
-                 arena: Optional[torch.Tensor] = None, eos_token_ids: EosLike = None):
+                 arena: Optional[torch.Tensor] = None, eos_token_ids: EosLike = None,
+                 kv_page_tokens: int = 0, kv_pages: int = 0):
         """``eos_token_ids``: the model's default stop ids (``generation_config.json``; see
-        ``eos_ids_from_generation_config``).  ``generate()`` falls back to them when the caller passes none, like HF."""
+        ``eos_ids_from_generation_config``).  ``generate()`` falls back to them when the caller passes none, like HF.
+        ``kv_page_tokens`` / ``kv_pages``: paged KV cache -- a pool of ``kv_pages`` pages of ``kv_page_tokens`` tokens
+        shared by the ``max_slots`` sequences instead of ``max_positions`` reserved tokens per slot (sparkmi.h)."""
         cfg.validate()
         self.cfg = cfg
         if eos_token_ids is None and cfg.eos_token_id is not None:
@@ -61,7 +64,7 @@ class SparkLLM:
         torch.cuda.set_device(self.device)
         _lib.require_gfx950()
         self.max_slots, self.max_positions = max_slots, max_positions
-        self._cs = llm_cfg_struct(cfg, max_slots, max_positions, kv_dtype, use_graph)
+        self._cs = llm_cfg_struct(cfg, max_slots, max_positions, kv_dtype, use_graph, kv_page_tokens, kv_pages)
         if arena is None:
             host = pack_llm_arena(cfg, weights, self._cs)
             arena = torch.from_numpy(host).to(self.device)
@@ -232,6 +235,12 @@ class SparkLLM:
         _lib.check(self._lib.smi_llm_slot_tokens(self._h, int(slot), out.ctypes.data_as(C.POINTER(C.c_int64)), cap, C.byref(n),
                                                  C.byref(fin), self._stream()), "smi_llm_slot_tokens")
         return out[: n.value].tolist(), bool(fin.value)
+
+    def kv_pages(self):
+        """(pages in the pool, pages free) of a paged KV cache; (0, 0) when the cache is not paged."""
+        tot, free = C.c_int32(0), C.c_int32(0)
+        _lib.check(self._lib.smi_llm_kv_pages(self._h, C.byref(tot), C.byref(free)), "smi_llm_kv_pages")
+        return tot.value, free.value
 
     def status(self):
         """(tokens emitted, finished flag) per KV slot, as two int32 arrays of SMI_MAX_ROWS -- one device round trip."""

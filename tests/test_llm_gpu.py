@@ -403,3 +403,53 @@ def test_sampled_tokens_do_not_depend_on_batch_composition(tiny):
     llm.set_sampling(True, 0.9, 40, 0.95, seed=78)
     other = dict(llm.serve(iter(reqs), max_live=4, decode_stride=3))
     assert any(other[i] != crowd[i] for i, *_ in reqs)
+
+
+def test_paged_kv_cache_serves_more_sequences_than_it_could_reserve(tiny):
+    """Paged KV (the functional analogue of TensorRT-LLM's paged KV under in-flight batching, run.sh:50-65): a pool of
+    pages shared by the slots instead of max_positions reserved per slot.  Tokens equal the contiguous B = 1 runs; the
+    pool is far smaller than slots x max_positions; pages return at retire; a short pool refuses cleanly."""
+    from sparkmi._lib import SparkMIError
+    cfg, syn = tiny
+    rng = np.random.Generator(np.random.PCG64(404))
+    reqs = []
+    for i in range(10):
+        prompt = rng.integers(0, cfg.vocab_size, size=int(rng.integers(2, 90))).tolist()
+        reqs.append((i, prompt, int(rng.integers(5, 60)), None))
+    single = _llm(cfg, syn, max_slots=1, max_positions=256)
+    want = {i: single.generate_ids([p], n)[0] for i, p, n, _ in reqs}
+    # 8 slots x 256 positions would reserve 2048 tokens; the pool holds 40 pages x 16 = 640
+    for kv in ("bf16", "f32"):
+        llm = _llm(cfg, syn, max_slots=8, max_positions=256, kv_dtype=kv, kv_page_tokens=16, kv_pages=40)
+        if kv == "f32":
+            single32 = _llm(cfg, syn, max_slots=1, max_positions=256, kv_dtype="f32")
+            want = {i: single32.generate_ids([p], n)[0] for i, p, n, _ in reqs}
+        assert llm.kv_pages() == (40, 40)
+        got = dict(llm.serve(iter(reqs), max_live=5, decode_stride=4))
+        for i, p, n, _ in reqs:
+            assert got[i][:n] == want[i], f"request {i} ({kv})"
+        assert llm.kv_pages() == (40, 40)                     # everything retired: every page is back
+    # plain (static-batch) generation on a paged engine, ragged prompts, two m-tiles worth of rows
+    llm = _llm(cfg, syn, max_slots=8, max_positions=256, kv_page_tokens=32, kv_pages=24)
+    prompts = [r[1] for r in reqs[:6]]
+    single = _llm(cfg, syn, max_slots=1, max_positions=256)
+    assert llm.generate_ids(prompts, 30) == [single.generate_ids([p], 30)[0] for p in prompts]
+    tot, free = llm.kv_pages()
+    assert tot == 24 and 0 < free < 24
+    ids = np.asarray(prompts[3] + [1, 2, 3])
+    assert torch.equal(llm.forward_logits(ids), _llm(cfg, syn, max_positions=256).forward_logits(ids))
+    # a pool that cannot hold the request refuses it and changes nothing
+    small = _llm(cfg, syn, max_slots=4, max_positions=256, kv_page_tokens=16, kv_pages=6)
+    small.session_begin(None)
+    a, = small.admit([list(range(1, 60))])                    # 59 tokens -> 4 pages
+    with pytest.raises(SparkMIError, match="pool exhausted"):
+        small.admit([list(range(1, 70))])                     # 5 more pages: only 2 free
+    assert small.kv_pages() == (6, 2)
+    small.decode(5)                                           # 64 positions: still 4 pages
+    with pytest.raises(SparkMIError, match="pool exhausted"):
+        small.decode(40)                                      # would need 7 pages
+    assert small.slot_tokens(a, 64)[0] == _llm(cfg, syn, max_positions=256).generate_ids([list(range(1, 60))], 6)[0]
+    small.retire(a)
+    assert small.kv_pages() == (6, 6)
+    with pytest.raises(SparkMIError):
+        _llm(cfg, syn, max_positions=250, kv_page_tokens=16, kv_pages=8)      # page size must divide max_positions
