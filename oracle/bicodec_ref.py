@@ -123,6 +123,16 @@ class BiCodecDetokRef:
         y = F.conv1d(y, _t(sd, p + ".3.weight"), _t(sd, p + ".3.bias"))
         return x + y
 
+    def _decoder_block(self, x: torch.Tensor, b: str, k: int, s: int) -> torch.Tensor:
+        """encoder_decoder/wave_generator.py:29-53: Snake -> ConvTranspose1d(k, stride s, padding (k - s) // 2) -> three
+        ResidualUnits (dilations 1, 3, 9)."""
+        sd = self.sd
+        x = snake(x, _t(sd, b + ".0.alpha"))
+        x = F.conv_transpose1d(x, _t(sd, b + ".1.weight"), _t(sd, b + ".1.bias"), stride=s, padding=(k - s) // 2)
+        for r, dil in enumerate((1, 3, 9)):
+            x = self._res_unit(x, f"{b}.{r + 2}.block", dil)
+        return x
+
     def wave_generator(self, x: torch.Tensor, stages: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
         """encoder_decoder/wave_generator.py:56-88."""
         sd, cfg = self.sd, self.cfg
@@ -130,12 +140,7 @@ class BiCodecDetokRef:
         if stages is not None:
             stages.append(x)
         for i, (k, s) in enumerate(zip(cfg.dec_kernel_sizes, cfg.dec_rates)):
-            b = f"decoder.model.{i + 1}.block"
-            x = snake(x, _t(sd, b + ".0.alpha"))
-            x = F.conv_transpose1d(x, _t(sd, b + ".1.weight"), _t(sd, b + ".1.bias"),
-                                   stride=s, padding=(k - s) // 2)
-            for r, dil in enumerate((1, 3, 9)):
-                x = self._res_unit(x, f"{b}.{r + 2}.block", dil)
+            x = self._decoder_block(x, f"decoder.model.{i + 1}.block", k, s)
             if stages is not None:
                 stages.append(x)
         n = len(cfg.dec_rates)

@@ -146,6 +146,106 @@ def gen_ops(seed=0):
     print("[ops] snake / SamplingBlock(ratio 1) / FSQ implicit codebook stored")
 
 
+def _randomize(mod, g):
+    """Seeded non-trivial parameters for a reference layer: every tensor ~ N(0, 0.1), gains (Snake alpha, layer scale,
+    weight-norm g, LayerNorm weight) ~ 1 + N(0, 0.2)."""
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            r = torch.randn(p.shape, generator=g)
+            if n.endswith(("alpha", "gamma", "weight_g")) or ("norm" in n and n.endswith("weight")):
+                p.copy_(1.0 + 0.2 * r)
+            else:
+                p.copy_(0.1 * r)
+
+
+def _folded_state(mod):
+    """state_dict after remove_weight_norm (bicodec.py:213-221), as numpy."""
+    def _rm(m):
+        try:
+            torch.nn.utils.remove_weight_norm(m)
+        except ValueError:
+            pass
+    mod.apply(_rm)
+    return {k: v.detach().numpy().copy() for k, v in mod.state_dict().items()}
+
+
+def gen_ops_layers(seed=0):
+    """SURVEY 8c's per-op fixtures, straight from the reference's layer classes at reduced dims (parameters, input, output):
+    ResidualUnit (dilations 1 / 3 / 9), DecoderBlock for each (k, s) of the 0.5B decoder, ConvNeXtBlock with LayerNorm and
+    with AdaLayerNorm -- and, from transformers (the LLM's arithmetic), RMSNorm, RoPE, one GQA attention step and the
+    SwiGLU MLP.  tests/test_oracle_ops.py checks the oracle's functions against them one by one."""
+    from sparktts.modules.blocks.layers import ResidualUnit
+    from sparktts.modules.encoder_decoder.wave_generator import DecoderBlock
+    from sparktts.modules.blocks.vocos import ConvNeXtBlock
+    out = {}
+    g = torch.Generator().manual_seed(seed + 100)
+
+    def put(prefix, sd):
+        for k, v in sd.items():
+            out[f"{prefix}/{k}"] = v
+
+    with torch.no_grad():
+        for dil in (1, 3, 9):
+            m = ResidualUnit(dim=24, dilation=dil).eval()
+            _randomize(m, g)
+            x = torch.randn(2, 24, 61, generator=g)
+            y = m(x)
+            put(f"resunit{dil}", _folded_state(m))
+            out[f"resunit{dil}.x"], out[f"resunit{dil}.y"] = x.numpy(), y.numpy()
+        for k, s in ((16, 8), (11, 5), (8, 4), (4, 2)):
+            m = DecoderBlock(input_dim=32, output_dim=16, kernel_size=k, stride=s).eval()
+            _randomize(m, g)
+            x = torch.randn(2, 32, 13, generator=g)
+            y = m(x)
+            put(f"decblock{k}_{s}", _folded_state(m))
+            out[f"decblock{k}_{s}.x"], out[f"decblock{k}_{s}.y"] = x.numpy(), y.numpy()
+        for tag, cond_dim in (("ln", None), ("adaln", 20)):
+            m = ConvNeXtBlock(dim=48, intermediate_dim=112, layer_scale_init_value=1.0, condition_dim=cond_dim).eval()
+            _randomize(m, g)
+            x = torch.randn(2, 48, 29, generator=g)
+            cond = torch.randn(2, 20, generator=g) if cond_dim else None
+            y = m(x, cond)
+            put(f"convnext_{tag}", _folded_state(m))
+            out[f"convnext_{tag}.x"], out[f"convnext_{tag}.y"] = x.numpy(), y.numpy()
+            if cond is not None:
+                out[f"convnext_{tag}.cond"] = cond.numpy()
+        # ---- LLM ops from transformers' Qwen2 classes
+        from transformers import Qwen2Config
+        from transformers.models.qwen2 import modeling_qwen2 as MQ
+        hc = Qwen2Config(vocab_size=64, hidden_size=128, intermediate_size=224, num_hidden_layers=1, num_attention_heads=4,
+                         num_key_value_heads=2, rms_norm_eps=1e-6, rope_theta=1000000.0, max_position_embeddings=512,
+                         attn_implementation="eager")
+        norm = MQ.Qwen2RMSNorm(128, eps=1e-6)
+        _randomize(norm, g)
+        x = torch.randn(1, 7, 128, generator=g)
+        out["rmsnorm.w"], out["rmsnorm.x"], out["rmsnorm.y"] = norm.weight.detach().numpy().copy(), x[0].numpy(), norm(x)[0].numpy()
+        rot = MQ.Qwen2RotaryEmbedding(config=hc)
+        pos = torch.tensor([[3, 4, 5, 130, 131]])
+        q = torch.randn(1, 4, 5, 32, generator=g)
+        kx = torch.randn(1, 2, 5, 32, generator=g)
+        cos, sin = rot(q, pos)
+        qr, kr = MQ.apply_rotary_pos_emb(q, kx, cos, sin)
+        out["rope.pos"], out["rope.q"], out["rope.k"] = pos[0].numpy(), q[0].numpy(), kx[0].numpy()
+        out["rope.q_rot"], out["rope.k_rot"] = qr[0].numpy(), kr[0].numpy()
+        # one decode step of GQA attention: 1 query position (index 9) against 10 cached keys, 4 query / 2 kv heads
+        qa = torch.randn(1, 4, 1, 32, generator=g)
+        ka, va = torch.randn(1, 2, 10, 32, generator=g), torch.randn(1, 2, 10, 32, generator=g)
+
+        class _M:   # what eager_attention_forward reads from the module
+            num_key_value_groups = 2
+            training = False
+        ao, _ = MQ.eager_attention_forward(_M(), qa, ka, va, attention_mask=None, scaling=32 ** -0.5, dropout=0.0)
+        out["attn.q"], out["attn.k"], out["attn.v"], out["attn.y"] = qa[0].numpy(), ka[0].numpy(), va[0].numpy(), ao[0].numpy()
+        mlp = MQ.Qwen2MLP(hc)
+        _randomize(mlp, g)
+        xm = torch.randn(3, 128, generator=g)
+        out["mlp.x"], out["mlp.y"] = xm.numpy(), mlp(xm).numpy()
+        for k2, v2 in mlp.state_dict().items():
+            out[f"mlp/{k2}"] = v2.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "ops_layers.npz"), **out)
+    print(f"[ops_layers] {len(out)} arrays: ResidualUnit x3, DecoderBlock x4, ConvNeXtBlock x2, RMSNorm, RoPE, GQA step, SwiGLU")
+
+
 def hf_model(cfg: C.LLMConfig, syn: W.SyntheticLLM):
     from transformers import Qwen2Config, Qwen2ForCausalLM
     hc = Qwen2Config(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
@@ -239,6 +339,8 @@ if __name__ == "__main__":
     want = lambda k: not a.only or k in a.only.split(",")  # noqa: E731
     if want("ops"):
         gen_ops()
+    if want("ops_layers"):
+        gen_ops_layers()
     if want("prompts"):
         gen_prompts()
     if want("voc"):
