@@ -168,14 +168,21 @@ typedef struct smi_voc_cfg {
   int32_t dec_rates[8], dec_ksizes[8];
   int32_t max_batch;         /* utterances per forward */
   int32_t max_frames;        /* semantic frames per utterance */
+  /* 0 (default): the dense conv / linear stack runs on the bf16 matrix pipe with both operands split into two bf16 planes
+   * (w x ~= w_hi x_hi + w_hi x_mid + w_mid x_hi, fp32 accumulate): 5e-5 max-abs from the fp32 waveform at the 0.5B shape,
+   * north_star's bound being 1e-3.  1: every contraction on the exact-fp32 matrix pipe (verification mode, 1/16 of the rate).
+   * The arena packing of the affected weights differs (smi_voc_arena_entry reports the kind). */
+  int32_t exact_fp32;
 } smi_voc_cfg;
 
 /* The vocoder arena is a flat f32 buffer of tensors in the order smi_voc_arena_entry enumerates
  * (name = the reference state_dict key after remove_weight_norm, or a derived packed tensor). */
 int smi_voc_arena_count(const smi_voc_cfg* cfg);
 /* info: int32[6] = {packing kind (0 raw f32 copy, 1 Conv1d/Linear weight [Cout][Cin][K], 2 ConvTranspose1d
- * weight [Cin][Cout][K]), Cout, Cin, K, stride, padding}.  Packed conv weights are laid out
- * [phase][cout_tile:32][tap][cin_group:8][lane:64][4] = v_mfma_f32_32x32x2_f32 A operands (sparkmi/bicodec.py). */
+ * weight [Cin][Cout][K], 3 / 4 the same two as bf16 planes), Cout, Cin, K, stride, padding}.  Kinds 1 / 2 are laid out
+ * [phase][cout_tile:32][tap][cin_group:8][lane:64][4 f32] = v_mfma_f32_32x32x2_f32 A operands; kinds 3 / 4
+ * [phase][cout_tile:32][tap][cin_step:16][plane:2 (hi, mid)][lane:64][8 bf16] = v_mfma_f32_32x32x16_bf16 A operands,
+ * lane l holding row l & 31, channels 8 (l >> 5) .. + 7 of the step (sparkmi/bicodec.py: pack_conv / pack_conv_b). */
 int smi_voc_arena_entry(const smi_voc_cfg* cfg, int index, char* name, int name_cap,
                         size_t* offset, size_t* bytes, int32_t* info);
 size_t smi_voc_arena_bytes(const smi_voc_cfg* cfg);

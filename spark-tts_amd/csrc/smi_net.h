@@ -14,7 +14,7 @@
 namespace {
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2, ACT_RELU = 3, ACT_SIGMOID = 4 };
-enum { PACK_RAW = 0, PACK_CONV = 1, PACK_CONVT = 2 };
+enum { PACK_RAW = 0, PACK_CONV = 1, PACK_CONVT = 2, PACK_CONV_B = 3, PACK_CONVT_B = 4 };   // _B: two bf16 planes (hi, mid) for k_convb
 constexpr int kMaxTaps = 8;     // taps per phase
 constexpr int kMaxPhases = 8;   // ConvTranspose1d stride
 constexpr int kChunk = 32;      // input channels staged per LDS chunk
@@ -49,6 +49,63 @@ __device__ __forceinline__ float snake_f(float x, float a) {
   return x + (1.0f / (a + 1e-9f)) * (s * s);
 }
 __device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// Shared tail of the conv kernels: (KS) fixed-order reduction of the four waves' partial tiles through LDS, then bias,
+// per-utterance bias, activation, layer scale, residual, tanh, the 3x of SamplingBlock(ratio 1), and the two outputs
+// (raw and Snake'd).  acc follows the 32x32 MFMA D layout: register r of lane l is row (r & 3) + 8 (r >> 2) + 4 (l >> 5),
+// column l & 31.
+template <int QB, bool KS>
+__device__ __forceinline__ void conv_finish(const ConvP& p, f32x16 (&acc)[QB], float* lds, int ct, bool live, int b, int phase,
+                                            int q0, int olen, int lane, int wave) {
+  if (KS) {
+    // fixed-order reduction of the four waves' partial tiles, then each wave finishes 4 of the 16 rows-groups
+    __syncthreads();
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lds[((wave * QB + qb) * 16 + r) * 64 + lane] = acc[qb][r];
+    __syncthreads();
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = wave * 4 + rr;
+        float s = lds[((0 * QB + qb) * 16 + r) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) s += lds[((w * QB + qb) * 16 + r) * 64 + lane];
+        acc[qb][rr] = s;
+      }
+  }
+  if (!live) return;
+
+  const long long yboff = (long long)b * p.yb;
+  const int nreg = KS ? 4 : 16;
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int q = q0 + qb * 32 + (lane & 31);
+    if (q >= olen) continue;
+    const int t = q * p.S + phase;
+#pragma unroll
+    for (int rr = 0; rr < nreg; ++rr) {
+      const int r = KS ? wave * 4 + rr : rr;
+      const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (co >= p.Cout) continue;
+      float y = acc[qb][rr];
+      if (p.bias) y += p.bias[co];
+      if (p.bbias) y += p.bbias[(long long)b * p.Cout + co];
+      if (p.act == ACT_GELU) y = gelu_f(y);
+      if (p.act == ACT_RELU) y = fmaxf(y, 0.f);
+      if (p.gamma) y = p.gamma[co] * y;
+      if (p.beta) y = y + p.beta[co];
+      const long long o = yboff + (long long)co * p.ystride + t;
+      if (p.R) y = p.R[o] + y;
+      if (p.act == ACT_TANH) y = tanhf(y);
+      if (p.out_scale != 1.0f) y = (y + y) + y;  // SamplingBlock(ratio 1): x + x + x
+      if (p.Y) p.Y[o] = y;
+      if (p.Ys) p.Ys[o] = snake_f(y, p.alpha[co]);
+    }
+  }
+}
 
 // QB: 32-wide time sub-tiles per wave.  KS: waves split the input channels of ONE 32-row output
 // tile (large C, short T) instead of owning a 32-row output tile each.  CHG: a staged chunk holds
@@ -192,54 +249,140 @@ __global__ __launch_bounds__(256) void k_conv(ConvP p) {
   }
 
   }
-  if (KS) {
-    // fixed-order reduction of the four waves' partial tiles, then each wave finishes 4 of the 16 rows-groups
-    __syncthreads();
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) lds[((wave * QB + qb) * 16 + r) * 64 + lane] = acc[qb][r];
-    __syncthreads();
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int r = wave * 4 + rr;
-        float s = lds[((0 * QB + qb) * 16 + r) * 64 + lane];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) s += lds[((w * QB + qb) * 16 + r) * 64 + lane];
-        acc[qb][rr] = s;
-      }
-  }
-  if (!live) return;
+  conv_finish<QB, KS>(p, acc, lds, ct, live, b, phase, q0, olen, lane, wave);
+}
 
-  const long long yboff = (long long)b * p.yb;
-  const int nreg = KS ? 4 : 16;
+
+// ------------------------------------------------------------------------------------------
+// k_convb: the same implicit GEMM on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the rate of the exact-fp32
+// MFMA) with fp32 accuracy kept by a 2-plane split of BOTH operands: x = x_hi + x_mid (+ 2^-16 |x|), w likewise, and
+//   w x ~= w_hi x_hi + w_hi x_mid + w_mid x_hi          (three products; the dropped terms are ~2^-17 relative)
+// accumulated in fp32.  On the 0.5B vocoder this moves the waveform by 5e-5 max-abs against the fp32 path (CPU emulation
+// and GPU test; north_star allows 1e-3).  Weights are split at pack time (two bf16 planes in A-operand order:
+// [ct][tap][16-channel step][plane][lane][8 bf16], lane l = row l & 31, channels 8 (l >> 5) ..+7 of the step);
+// activations are split while a chunk is staged: the thread that loaded eight consecutive channels of one time column packs
+// them into one 16-byte B-operand piece per plane, LDS image [plane][octet][column][8 bf16].
+// QB / KS / CHG / NC as k_conv (four waves; KS needs CHG >= 2 so that a wave owns whole 16-channel steps).
+// ------------------------------------------------------------------------------------------
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {   // round-to-nearest-even pair -> packed bf16 (v_cvt_pk_bf16_f32)
+  const bf16x2v h = __builtin_convertvector((f32x2v){a, b}, bf16x2v);
+  return __builtin_bit_cast(uint32_t, h);
+}
+// eight fp32 -> hi plane and mid plane (x - hi, rounded again), 8 bf16 each
+__device__ __forceinline__ void split2x8(const float (&v)[8], uint4& hi, uint4& mid) {
+  uint32_t h[4], m[4];
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    const int q = q0 + qb * 32 + (lane & 31);
-    if (q >= olen) continue;
-    const int t = q * p.S + phase;
+  for (int i = 0; i < 4; ++i) {
+    h[i] = pk_bf16(v[2 * i], v[2 * i + 1]);
+    const float ra = v[2 * i] - __uint_as_float(h[i] << 16), rb = v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u);
+    m[i] = pk_bf16(ra, rb);
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  mid = make_uint4(m[0], m[1], m[2], m[3]);
+}
+
+template <int QB, bool KS, int CHG, int NC>
+__global__ __launch_bounds__(256) void k_convb(ConvP p) {
+  static_assert(!KS || CHG % 2 == 0, "channel-split waves own whole 16-channel steps");
+  constexpr int kCh = 32 * CHG;        // channels per staged chunk (four waves x CHG octets)
+  constexpr int NOCT = 4 * CHG;        // octets per chunk
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  uint4* lds16 = (uint4*)lds;          // [2 planes][NOCT][xw]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int QT = QB * 32;
+  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  const int b = bz / p.S, phase = bz - b * p.S;
+  const int q0 = bx * QT;
+  const int len = p.lens[b];
+  const int olen = p.olens ? p.olens[b] : len;
+  if (q0 >= olen) return;
+  const int ct = KS ? by : by * 4 + wave;
+  const bool live = ct * 32 < p.Cout;
+  const int ntap = p.ntaps[phase];
+  const int ksteps = (p.Cin + 15) >> 4;                 // 16-channel steps of the packed weights
+  const float* Xb = p.X + (long long)b * p.xb;
+  const uint4* Wp = (const uint4*)(p.W + p.wphase[phase]) + (long long)ct * ntap * ksteps * 128;
+
+  f32x16 acc[QB];
 #pragma unroll
-    for (int rr = 0; rr < nreg; ++rr) {
-      const int r = KS ? wave * 4 + rr : rr;
-      const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (co >= p.Cout) continue;
-      float y = acc[qb][rr];
-      if (p.bias) y += p.bias[co];
-      if (p.bbias) y += p.bbias[(long long)b * p.Cout + co];
-      if (p.act == ACT_GELU) y = gelu_f(y);
-      if (p.act == ACT_RELU) y = fmaxf(y, 0.f);
-      if (p.gamma) y = p.gamma[co] * y;
-      if (p.beta) y = y + p.beta[co];
-      const long long o = yboff + (long long)co * p.ystride + t;
-      if (p.R) y = p.R[o] + y;
-      if (p.act == ACT_TANH) y = tanhf(y);
-      if (p.out_scale != 1.0f) y = (y + y) + y;  // SamplingBlock(ratio 1): x + x + x
-      if (p.Y) p.Y[o] = y;
-      if (p.Ys) p.Ys[o] = snake_f(y, p.alpha[co]);
+  for (int i = 0; i < QB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int xw = p.xw;
+  constexpr int RW = 8 * CHG;   // rows staged per wave = CHG octets
+  float sreg[RW][NC];
+  auto stage_load = [&](int c0) {
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int ci = c0 + wave * RW + r;
+      const float* xr = Xb + (long long)ci * p.xstride;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        const int col = lane + 64 * k, t = q0 - p.halo_l + col;
+        const bool ok = ci < p.Cin && col < xw && t >= 0 && t < len;
+        sreg[r][k] = ok ? xr[t] : 0.f;
+      }
+    }
+  };
+  auto stage_store = [&]() {   // split + pack: one 16-byte piece per (octet, column, plane)
+#pragma unroll
+    for (int g = 0; g < CHG; ++g)
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = sreg[g * 8 + r][k];
+        uint4 hi, mid;
+        split2x8(v, hi, mid);
+        if (lane + 64 * k < xw) {
+          lds16[(size_t)(wave * CHG + g) * xw + lane + 64 * k] = hi;
+          lds16[(size_t)(NOCT + wave * CHG + g) * xw + lane + 64 * k] = mid;
+        }
+      }
+  };
+  stage_load(0);
+  for (int c0 = 0; c0 < p.CinP; c0 += kCh) {
+    if (c0) { if (KS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads(); }   // previous chunk fully read
+    stage_store();
+    if (KS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads();
+    if (c0 + kCh < p.CinP) stage_load(c0 + kCh);
+    if (live) {
+      // (tap, 16-channel step) steps in order over this wave's steps of the chunk (all 2 CHG of them, or with KS its own
+      // CHG / 2); the NEXT step's two weight planes are requested before this step's MFMAs and fenced there
+      const int sbase = KS ? wave * (CHG / 2) : 0, scap = KS ? CHG / 2 : 2 * CHG;
+      int sl = ksteps - (c0 >> 4) - sbase;            // live steps of this chunk from sbase on
+      sl = sl < scap ? sl : scap;
+      const int nstep = sl > 0 ? ntap * sl : 0;
+      const uint4* Wq = Wp + ((long long)(c0 >> 4) + sbase) * 128 + lane;
+      int tap = 0, g = 0;
+      uint4 wh = sl > 0 ? Wq[0] : Wp[lane], wm = sl > 0 ? Wq[64] : Wp[lane];
+      for (int st = 0; st < nstep; ++st) {
+        int gn = g + 1, tn = tap;
+        if (gn == sl) { gn = 0; ++tn; }
+        if (tn == ntap) { tn = tap; gn = g; }   // last step: re-request the current weights (no branch around the load)
+        const uint4* wnp = Wq + ((long long)tn * ksteps + gn) * 128;
+        const uint4 whn = wnp[0], wmn = wnp[64];
+        __builtin_amdgcn_sched_barrier(0);
+        const int col0 = p.halo_l + p.off[phase][tap] + (lane & 31);
+        const uint4* bp = lds16 + (size_t)(2 * (sbase + g) + (lane >> 5)) * xw + col0;
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, wh), am = __builtin_bit_cast(bf16x8, wm);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[qb * 32]);
+          const bf16x8 bm = __builtin_bit_cast(bf16x8, bp[(size_t)NOCT * xw + qb * 32]);
+          acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[qb], 0, 0, 0);
+          acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[qb], 0, 0, 0);
+          acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[qb], 0, 0, 0);
+        }
+        wh = whn; wm = wmn; g = gn; tap = tn;
+      }
     }
   }
+  conv_finish<QB, KS>(p, acc, lds, ct, live, b, phase, q0, olen, lane, wave);
 }
 
 // Linear layer on one vector per utterance (d-vector projection, AdaLN parameters): y[b][co] =
@@ -428,13 +571,15 @@ inline int pad32(int c) { return (c + 31) / 32 * 32; }
 
 // Conv1d (S = 1): tap j reads x[t + j*dil - pad].  ConvTranspose1d (stride S, padding pad):
 // out[q*S + r] += W[ci][co][j] * x[ci][(q*S + r + pad - j)/S] for j == (r + pad) mod S.
-ConvGeom conv_geom(int Cout, int Cin, int K, int dil, int pad, int S) {
+ConvGeom conv_geom(int Cout, int Cin, int K, int dil, int pad, int S, bool bf = false) {
   ConvGeom g;
   memset(&g, 0, sizeof(g));
   g.S = S;
   long long o = 0;
   int lo = 0, hi = 0;
-  const long long per_tap = (long long)(pad32(Cout) / 32) * (pad8(Cin) / 8) * 256;
+  // fp32 packing: [ct][tap][8-channel group][lane][4 floats]; bf16-split packing: [ct][tap][16-channel step][2 planes][lane][8 bf16]
+  const long long per_tap = bf ? (long long)(pad32(Cout) / 32) * ((Cin + 15) / 16) * 512
+                               : (long long)(pad32(Cout) / 32) * (pad8(Cin) / 8) * 256;
   for (int r = 0; r < S; ++r) {
     g.wphase[r] = o;
     int n = 0;
@@ -457,7 +602,7 @@ struct Launch {
   std::function<void(hipStream_t)> fn;
   std::string name;
   double flops;
-  ConvP cp; int qb; bool ks; int chg; int nwv = 4; bool gemv; dim3 grid; size_t lds;
+  ConvP cp; int qb; bool ks; int chg; int nwv = 4; bool gemv; bool bf = false; dim3 grid; size_t lds;
   LnP lp; int cpt;
   // small kernels keep their args here
   const int64_t* sem; int semstride; const float* cb; int D, cbsize; float* Z; int zstride; long long zb;
@@ -471,6 +616,20 @@ int run_launch(const Launch& L, hipStream_t st) {
     case 0:
       if (L.gemv) {
         hipLaunchKernelGGL(k_gemv1, L.grid, dim3(256), 0, st, L.cp);
+      } else if (L.bf) {            // bf16-split matrix pipe (k_convb): weights packed as two bf16 planes
+#define SMI_CB(QB_, KS_, CHG_, NC_) hipLaunchKernelGGL((k_convb<QB_, KS_, CHG_, NC_>), L.grid, dim3(256), L.lds, st, L.cp)
+        const bool wide = L.cp.xw > 64;
+        if (L.chg == 4) {
+          if (L.ks) { if (L.qb == 1) SMI_CB(1, true, 4, 1); else SMI_CB(2, true, 4, 1); }
+          else { if (L.qb == 1) SMI_CB(1, false, 4, 1); else SMI_CB(2, false, 4, 1); }
+        } else if (L.ks) {
+          if (L.qb == 1) { if (wide) SMI_CB(1, true, 2, 2); else SMI_CB(1, true, 2, 1); }
+          else SMI_CB(2, true, 2, 2);
+        } else {
+          if (L.qb == 1) { if (wide) SMI_CB(1, false, 1, 2); else SMI_CB(1, false, 1, 1); }
+          else SMI_CB(2, false, 1, 2);
+        }
+#undef SMI_CB
       } else if (L.chg == 4) {      // 1-tap layers: 128-channel chunks, narrow rows
         if (L.ks) {
           // measured (profiles/README.md): pays up to about two blocks per CU, costs beyond (fewer waves fit)
@@ -535,11 +694,12 @@ int run_launch(const Launch& L, hipStream_t st) {
 Launch make_conv_w(const std::string& name, const float* W, const float* bias,
                    int Cout, int Cin, int K, int dil, int S, int pad, const float* X, int xstride, long long xb,
                  float* Y, float* Ys, const float* alpha, const float* R, int ystride, long long yb,
-                 const int* lens, int B, int Lmax, int act, int istr = 1, const int* olens = nullptr) {
+                 const int* lens, int B, int Lmax, int act, int istr = 1, const int* olens = nullptr, bool bf = false) {
   // Lmax = padded OUTPUT positions per phase (= input length for stride-1 convs and transposed convs)
+  // bf: the weights are packed as bf16 planes (PACK_CONV_B / PACK_CONVT_B) and the layer runs on k_convb
   Launch L;
-  L.kind = 0; L.name = name;
-  ConvGeom g = conv_geom(Cout, Cin, K, dil, pad, S);
+  L.kind = 0; L.name = name; L.bf = bf;
+  ConvGeom g = conv_geom(Cout, Cin, K, dil, pad, S, bf);
   ConvP& p = L.cp;
   memset(&p, 0, sizeof(p));
   p.X = X; p.W = W; p.bias = bias;
@@ -569,9 +729,10 @@ Launch make_conv_w(const std::string& name, const float* W, const float* bias,
   p.xw = (qt - 1) * istr + 1 + g.halo_l + g.halo_r;
   // three-wave blocks where four would leave a wave (and so a SIMD of each CU) without an output tile; measured at
   // 150 frames: 75.0 -> 73.2 ms at B = 32, 21.0 -> 20.5 at B = 8, but 4.66 -> 4.72 at B = 1, hence the grid-size condition
-  L.nwv = (!L.ks && cot % 3 == 0 && cot % 4 != 0 && blocks_cosplit >= 2048) ? 3 : 4;
+  L.nwv = (!bf && !L.ks && cot % 3 == 0 && cot % 4 != 0 && blocks_cosplit >= 2048) ? 3 : 4;
   L.grid = dim3(nq, L.ks ? cot : (cot + L.nwv - 1) / L.nwv, B * S);
   L.chg = (S == 1 && K == 1 && Cin >= 128 && L.ks) ? 4 : 1;   // K-split 1-tap layers stage 128 channels per chunk
+  if (bf && L.ks && L.chg == 1) L.chg = 2;                     // k_convb: a channel-split wave owns whole 16-channel steps
   L.gemv = false;   // set by the caller for the per-utterance vector projections (use_gemv)
   size_t lds = (size_t)8 * L.nwv * L.chg * p.xw * 4;
   const size_t red = L.ks ? (size_t)4 * qb * 16 * 64 * 4 : 0;

@@ -53,16 +53,24 @@ VocLayout voc_layout(const smi_voc_cfg* c) {
     o += smi_align_up(floats * 4, 256);
   };
   auto raw = [&](const std::string& name, size_t n) { add(name, PACK_RAW, 0, 0, 0, 1, 0, n); };
-  auto conv = [&](const std::string& name, int Cout, int Cin, int K) {
+  // conv: layers of the dense stack -- on the bf16-split matrix pipe (k_convb, two bf16 weight planes) unless the handle is
+  // created with exact_fp32, or the layer is too thin to fill a 16-channel step / 32-row tile; convf: always exact fp32
+  // (the per-utterance GEMVs read the fp32 packing; the 8-channel codebook projection; the one-channel output conv)
+  auto convf = [&](const std::string& name, int Cout, int Cin, int K) {
     add(name, PACK_CONV, Cout, Cin, K, 1, 0, (size_t)conv_geom(Cout, Cin, K, 1, 0, 1).floats);
+  };
+  auto use_bf = [&](int Cout, int Cin) { return !c->exact_fp32 && Cin >= 32 && Cout >= 32; };
+  auto conv = [&](const std::string& name, int Cout, int Cin, int K) {
+    const bool bf = use_bf(Cout, Cin);
+    add(name, bf ? PACK_CONV_B : PACK_CONV, Cout, Cin, K, 1, 0, (size_t)conv_geom(Cout, Cin, K, 1, 0, 1, bf).floats);
   };
   const int D = c->pre_dim, I = c->pre_inter, Cc = c->pre_cond_dim;
   raw("quantizer.codebook.weight", (size_t)c->codebook_size * c->codebook_dim);
-  conv("quantizer.out_project.weight", c->vq_input_dim, c->codebook_dim, 1);
+  convf("quantizer.out_project.weight", c->vq_input_dim, c->codebook_dim, 1);
   raw("quantizer.out_project.bias", c->vq_input_dim);
   raw("speaker_encoder.quantizer.project_out.weight", (size_t)c->spk_latent_dim * c->fsq_dims);
   raw("speaker_encoder.quantizer.project_out.bias", c->spk_latent_dim);
-  conv("speaker_encoder.project.weight", c->spk_out_dim, c->spk_latent_dim * c->spk_token_num, 1);
+  convf("speaker_encoder.project.weight", c->spk_out_dim, c->spk_latent_dim * c->spk_token_num, 1);
   raw("speaker_encoder.project.bias", c->spk_out_dim);
   conv("prenet.linear_pre.weight", D, c->pre_input_channels, 1);
   raw("prenet.linear_pre.bias", D);
@@ -97,7 +105,7 @@ VocLayout voc_layout(const smi_voc_cfg* c) {
   for (int i = 0; i < c->pre_num_down; ++i) vocos("prenet.downsample." + std::to_string(i) + ".1", 2, false);
   vocos("prenet.vocos_backbone", c->pre_layers, true);
   const int nada = 1 + c->pre_layers;
-  conv(adaw, nada * 2 * D, Cc, 1);
+  convf(adaw, nada * 2 * D, Cc, 1);
   raw(adab, (size_t)nada * 2 * D);
   conv("prenet.linear.weight", c->pre_out_channels, D, 1);
   raw("prenet.linear.bias", c->pre_out_channels);
@@ -108,7 +116,8 @@ VocLayout voc_layout(const smi_voc_cfg* c) {
     const int cin = ch >> i, cout = ch >> (i + 1), k = c->dec_ksizes[i], s = c->dec_rates[i];
     const std::string b = "decoder.model." + std::to_string(i + 1) + ".block";
     raw(b + ".0.alpha", cin);
-    add(b + ".1.weight", PACK_CONVT, cout, cin, k, s, (k - s) / 2, (size_t)conv_geom(cout, cin, k, 1, (k - s) / 2, s).floats);
+    add(b + ".1.weight", use_bf(cout, cin) ? PACK_CONVT_B : PACK_CONVT, cout, cin, k, s, (k - s) / 2,
+        (size_t)conv_geom(cout, cin, k, 1, (k - s) / 2, s, use_bf(cout, cin)).floats);
     raw(b + ".1.bias", cout);
     for (int r = 0; r < 3; ++r) {
       const std::string u = b + "." + std::to_string(r + 2) + ".block";
@@ -122,7 +131,7 @@ VocLayout voc_layout(const smi_voc_cfg* c) {
   }
   const int clast = ch >> c->dec_nblocks;
   raw("decoder.model." + std::to_string(c->dec_nblocks + 1) + ".alpha", clast);
-  conv("decoder.model." + std::to_string(c->dec_nblocks + 2) + ".weight", 1, clast, 7);
+  convf("decoder.model." + std::to_string(c->dec_nblocks + 2) + ".weight", 1, clast, 7);
   raw("decoder.model." + std::to_string(c->dec_nblocks + 2) + ".bias", 1);
   L.total = o;
   return L;
@@ -152,13 +161,18 @@ const float* ent(const smi_voc* h, const std::string& name) {
     if (e.name == name) return (const float*)(h->arena + e.offset);
   return nullptr;
 }
+bool ent_is_bf(const smi_voc* h, const std::string& name) {
+  for (const Entry& e : h->lay.e)
+    if (e.name == name) return e.kind == PACK_CONV_B || e.kind == PACK_CONVT_B;
+  return false;
+}
 
 Launch make_conv(const smi_voc* h, const std::string& name, const std::string& wname, const char* bname,
                  int Cout, int Cin, int K, int dil, int S, int pad, const float* X, int xstride, long long xb,
                  float* Y, float* Ys, const float* alpha, const float* R, int ystride, long long yb,
                  const int* lens, int B, int Lmax, int act) {
   return make_conv_w(name, ent(h, wname), bname ? ent(h, bname) : nullptr, Cout, Cin, K, dil, S, pad, X, xstride, xb, Y, Ys,
-                     alpha, R, ystride, yb, lens, B, Lmax, act);
+                     alpha, R, ystride, yb, lens, B, Lmax, act, 1, nullptr, ent_is_bf(h, wname));
 }
 
 }  // namespace
@@ -430,7 +444,7 @@ int smi_voc_forward(smi_voc* h, const int64_t* sem_dev, const int32_t* lens_host
     if (L.kind == 0) {
       SMI_REQUIRE(L.cp.W, "smi_voc_forward: arena entry for %s not found", L.name.c_str());
       SMI_REQUIRE(L.lds <= 64 * 1024, "smi_voc_forward: %s needs %zu bytes of LDS", L.name.c_str(), L.lds);
-      SMI_REQUIRE(L.cp.xw <= 128 && (L.chg == 1 || L.cp.xw <= 64), "smi_voc_forward: %s stages %d columns", L.name.c_str(), L.cp.xw);
+      SMI_REQUIRE(L.cp.xw <= 128 && (L.chg != 4 || L.cp.xw <= 64), "smi_voc_forward: %s stages %d columns", L.name.c_str(), L.cp.xw);
     }
     int rc = run_launch(L, st);
     if (rc) return rc;

@@ -37,7 +37,7 @@ class VocCfg(C.Structure):
             "pre_input_channels", "pre_dim", "pre_inter", "pre_layers", "pre_out_channels",
             "pre_cond_dim", "pre_num_down", "pre_tanh_final", "dec_in", "dec_channels", "dec_nblocks")]
         + [("dec_rates", C.c_int32 * 8), ("dec_ksizes", C.c_int32 * 8)]
-        + [("max_batch", C.c_int32), ("max_frames", C.c_int32)])
+        + [("max_batch", C.c_int32), ("max_frames", C.c_int32), ("exact_fp32", C.c_int32)])
 
 
 class EncCfg(C.Structure):

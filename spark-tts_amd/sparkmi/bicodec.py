@@ -21,10 +21,15 @@ from . import _lib
 from .config import BiCodecConfig, TopConfig
 from .weights import fold_weight_norm, load_bicodec_state
 
-PACK_RAW, PACK_CONV, PACK_CONVT = 0, 1, 2
+PACK_RAW, PACK_CONV, PACK_CONVT, PACK_CONV_B, PACK_CONVT_B = 0, 1, 2, 3, 4
 
 
-def voc_cfg_struct(cfg: BiCodecConfig, max_batch: int, max_frames: int) -> _lib.VocCfg:
+def voc_cfg_struct(cfg: BiCodecConfig, max_batch: int, max_frames: int, exact_fp32: Optional[bool] = None) -> _lib.VocCfg:
+    """``exact_fp32``: every contraction on the exact-fp32 matrix pipe (verification mode) instead of the bf16-split pipe;
+    None reads SPARKMI_VOC_EXACT=1 from the environment."""
+    import os
+    if exact_fp32 is None:
+        exact_fp32 = os.environ.get("SPARKMI_VOC_EXACT") == "1"
     cfg.validate()
     s = _lib.VocCfg(
         vq_input_dim=cfg.vq_input_dim, codebook_size=cfg.codebook_size, codebook_dim=cfg.codebook_dim,
@@ -35,7 +40,7 @@ def voc_cfg_struct(cfg: BiCodecConfig, max_batch: int, max_frames: int) -> _lib.
         pre_cond_dim=cfg.pre_condition_dim or 0, pre_num_down=len(cfg.pre_sample_ratios),
         pre_tanh_final=int(cfg.pre_use_tanh_at_final),
         dec_in=cfg.dec_input_channel, dec_channels=cfg.dec_channels, dec_nblocks=len(cfg.dec_rates),
-        max_batch=max_batch, max_frames=max_frames)
+        max_batch=max_batch, max_frames=max_frames, exact_fp32=int(bool(exact_fp32)))
     for i, v in enumerate(cfg.fsq_levels):
         s.fsq_levels[i] = v
     for i, (r, k) in enumerate(zip(cfg.dec_rates, cfg.dec_kernel_sizes)):
@@ -72,6 +77,32 @@ def pack_conv(w: np.ndarray, kind: int, S: int, pad: int) -> np.ndarray:
     return np.concatenate(out)
 
 
+def pack_conv_b(w: np.ndarray, kind: int, S: int, pad: int) -> np.ndarray:
+    """Weights -> two bf16 planes (hi = bf16(w), mid = bf16(w - hi)) in the A-operand order of v_mfma_f32_32x32x16_bf16:
+    [phase][cout_tile][tap][16-channel step][plane][lane:64][8 bf16], lane l holding A[co = 32*tile + (l & 31)]
+    [ci = 16*step + 8*(l >> 5) + 0..7].  Returned as float32 words (the arena's element type; the bytes are bf16)."""
+    from .weights import bf16_bits_to_f32, f32_to_bf16_bits
+    w = np.asarray(w, dtype=np.float32)
+    if w.ndim == 2:
+        w = w[:, :, None]
+    if kind == PACK_CONVT_B:
+        w = w.transpose(1, 0, 2)          # (Cin, Cout, K) -> (Cout, Cin, K)
+    cout, cin, K = w.shape
+    cop, cip = (cout + 31) // 32 * 32, (cin + 15) // 16 * 16
+    wp = np.zeros((cop, cip, K), np.float32)
+    wp[:cout, :cin] = w
+    hi = f32_to_bf16_bits(wp).reshape(wp.shape)
+    mid = f32_to_bf16_bits(wp - bf16_bits_to_f32(hi).reshape(wp.shape)).reshape(wp.shape)
+    planes = np.stack([hi, mid], axis=0)                      # (2, cop, cip, K) uint16
+    out = []
+    for taps in conv_phases(K, S, pad):
+        a = planes[:, :, :, taps]                             # (2, cop, cip, ntap)
+        a = a.reshape(2, cop // 32, 32, cip // 16, 2, 8, len(taps))   # [plane][ct][row][step][half][e][tap]
+        a = a.transpose(1, 6, 3, 0, 4, 2, 5)                  # [ct][tap][step][plane][half][row][e]
+        out.append(np.ascontiguousarray(a).reshape(-1))       # lane = half*32 + row
+    return np.concatenate(out).view(np.float32)
+
+
 def pack_voc_arena(cfg: BiCodecConfig, folded: Mapping[str, np.ndarray], cs: _lib.VocCfg) -> np.ndarray:
     lib = _lib.lib()
     n = lib.smi_voc_arena_count(C.byref(cs))
@@ -91,7 +122,8 @@ def pack_voc_arena(cfg: BiCodecConfig, folded: Mapping[str, np.ndarray], cs: _li
         else:
             t = np.asarray(folded[key], np.float32)
         kind, cout, cin, K, S, pad = list(info)
-        data = t.reshape(-1) if kind == PACK_RAW else pack_conv(t, kind, S, pad)
+        data = (t.reshape(-1) if kind == PACK_RAW else
+                pack_conv_b(t, kind, S, pad) if kind in (PACK_CONV_B, PACK_CONVT_B) else pack_conv(t, kind, S, pad))
         if data.size * 4 != nb.value:
             raise ValueError(f"{key}: packed {data.size * 4} bytes, library expects {nb.value}")
         arena[off.value // 4: off.value // 4 + data.size] = data
@@ -103,7 +135,10 @@ class BiCodecVocoder:
 
     def __init__(self, cfg: BiCodecConfig, state: Mapping[str, np.ndarray],
                  device: Union[str, torch.device] = "cuda:0", max_batch: int = 1, max_frames: int = 512,
-                 state_is_folded: bool = False, arena: Optional[torch.Tensor] = None):
+                 state_is_folded: bool = False, arena: Optional[torch.Tensor] = None, exact_fp32: Optional[bool] = None):
+        """``exact_fp32``: run every contraction on the exact-fp32 matrix pipe (verification mode); default (None ->
+        SPARKMI_VOC_EXACT) is the bf16-split pipe, 5e-5 max-abs from it on the waveform.  An ``arena`` must have been
+        packed for the same mode."""
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -112,7 +147,8 @@ class BiCodecVocoder:
         torch.cuda.set_device(self.device)
         _lib.require_gfx950()
         self.max_batch, self.max_frames = max_batch, max_frames
-        self._cs = voc_cfg_struct(cfg, max_batch, max_frames)
+        self._cs = voc_cfg_struct(cfg, max_batch, max_frames, exact_fp32)
+        self.exact_fp32 = bool(self._cs.exact_fp32)
         if arena is None:
             folded = state if state_is_folded else fold_weight_norm(dict(state))
             arena = torch.from_numpy(pack_voc_arena(cfg, folded, self._cs)).to(self.device)

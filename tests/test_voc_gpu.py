@@ -134,3 +134,31 @@ def test_full_size_0p5b_against_reference_vectors(golden_dir):
     wav = voc.detokenize(torch.from_numpy(sem), torch.from_numpy(glob), lengths=[150, 23]).cpu().numpy()
     assert np.abs(wav[0] - g["c0_wav"][0]).max() < 3e-4
     assert np.abs(wav[1, :, : 23 * 320] - g["c1_wav"][0]).max() < 3e-4
+
+
+def test_exact_fp32_mode_and_the_bf16_split_pipe_agree(golden_dir, full_voc):
+    """Default: the dense stack runs on the bf16 matrix pipe with both operands split into two bf16 planes (three products,
+    fp32 accumulate).  exact_fp32=True keeps every contraction on the exact-fp32 MFMA (verification mode).  Both against the
+    reference's own vector at the 0.5B shape, and against each other: the split costs < 1e-4 on a waveform in [-1, 1]
+    (north_star allows 1e-3); the exact mode is summation-order noise only."""
+    cfg, sd, _ = full_voc
+    g = np.load(os.path.join(golden_dir, "vocoder_full.npz"))
+    sem, glob = torch.from_numpy(g["c0_semantic"]), torch.from_numpy(g["c0_global"])
+    exact = _voc(cfg, sd, max_batch=1, max_frames=160, exact_fp32=True)
+    fast = _voc(cfg, sd, max_batch=1, max_frames=160, exact_fp32=False)
+    assert exact.exact_fp32 and not fast.exact_fp32
+    we = exact.detokenize(sem, glob).cpu().numpy()
+    wf = fast.detokenize(sem, glob).cpu().numpy()
+    assert np.abs(we - g["c0_wav"]).max() < 3e-5
+    assert np.abs(wf - g["c0_wav"]).max() < 2e-4
+    assert np.abs(wf - we).max() < 2e-4
+    assert np.array_equal(wf, fast.detokenize(sem, glob).cpu().numpy())     # deterministic
+
+
+def test_tiny_exact_fp32_mode_matches_reference_vectors(tiny, golden_dir):
+    cfg, sd, _ = tiny
+    g = np.load(os.path.join(golden_dir, "vocoder_tiny.npz"))
+    voc = _voc(cfg, sd, max_frames=160, exact_fp32=True)
+    for case in range(4):
+        wav = voc.detokenize(torch.from_numpy(g[f"c{case}_semantic"]), torch.from_numpy(g[f"c{case}_global"])).cpu().numpy()
+        assert np.abs(wav - g[f"c{case}_wav"]).max() < WAV_ATOL
