@@ -1945,7 +1945,12 @@ int launch_gemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
   // a tile's k -> wave map does not change.  (Measured at M = 32: gate_up 19.4 -> 13.7 us with N2 = 2, 14.4 with 4;
   // QKV / o_proj / down / lm_head lose with fewer blocks.)
   if (p.M > 16) {
-    if constexpr (N2 > 1) return launch_gemm_kv<2, NTB * N2, NW, 2, 1, PRO, EPI>(L, p, st);   // two k tiles in flight: 13.9 -> 13.6 us at 32 rows, 18.5 -> 17.5 at 64
+    if constexpr (N2 > 1) {
+      // SPARKMI_TUNE2 bit 2048 (A/B): three n tiles per block and ALL of a wave's k tiles in one batch -- every load of the
+      // block leaves at entry (one memory round trip instead of two dependent ones), 203 blocks at one block per CU
+      if (L->tune2 & 2048) return launch_gemm_kv<2, 3, NW, 4, 1, PRO, EPI>(L, p, st);
+      return launch_gemm_kv<2, NTB * N2, NW, 2, 1, PRO, EPI>(L, p, st);   // two k tiles in flight: 13.9 -> 13.6 us at 32 rows, 18.5 -> 17.5 at 64
+    }
     // few n tiles (N = 896 / 1152): 16-row blocks in two block rows put twice the CUs to work and halve the operand
     // bytes per CU (measured at M = 32; SPARKMI_TUNE2 bit 0 keeps 32-row blocks)
     if constexpr (N2 == 0) { if (!(L->tune2 & 1)) return launch_gemm_kv<1, NTB, NW, U, 1, PRO, EPI, H>(L, p, st); }

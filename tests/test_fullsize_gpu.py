@@ -131,7 +131,8 @@ def test_config2_free_running_bf16_kv_graph_to_waveform(full_llm, full_llm_oracl
     assert err < 3e-4, f"waveform max |diff| {err}"       # what exact-product fp32 accumulation gives
 
 
-def test_config3_vocoder_batch_of_32_ragged_rows(full_voc):
+@pytest.mark.parametrize("exact", [False, True])
+def test_config3_vocoder_batch_of_32_ragged_rows(full_voc, exact):
     """configs[2]'s vocoder call: 32 rows of 120..180 frames, padded to the longest (another launch plan than B <= 2:
     tile width, channel split and three-wave blocks are chosen from (B, longest row)).  Every row equals its own
     un-padded run to fp32 re-association and three rows equal the CPU oracle."""
@@ -144,17 +145,21 @@ def test_config3_vocoder_batch_of_32_ragged_rows(full_voc):
     B, T = 32, max(lens)
     sem = rng.integers(0, vcfg.codebook_size, size=(B, T))
     glob = rng.integers(0, 4096, size=(B, 1, vcfg.spk_token_num))
-    voc = BiCodecVocoder(vcfg, sd, "cuda:0", max_batch=B, max_frames=T)
+    # exact: every contraction on the exact-fp32 matrix pipe -- a row differs from its un-padded run by fp32 re-association
+    # only (another tiling of the same sums).  Default (bf16-split pipe): the re-associated low bits also move hi / mid
+    # roundings of later layers' operands, so the two runs differ at the size of the split itself (5e-5 on the waveform).
+    row_tol = 2e-5 if exact else 1e-4
+    voc = BiCodecVocoder(vcfg, sd, "cuda:0", max_batch=B, max_frames=T, exact_fp32=exact)
     wav = voc.detokenize(torch.from_numpy(sem), torch.from_numpy(glob), lengths=lens).cpu().numpy()
     again = voc.detokenize(torch.from_numpy(sem), torch.from_numpy(glob), lengths=lens).cpu().numpy()
     assert np.array_equal(wav, again)
-    one = BiCodecVocoder(vcfg, None, "cuda:0", max_batch=1, max_frames=T, arena=voc.arena)   # the arena layout does not depend on the batch
+    one = BiCodecVocoder(vcfg, None, "cuda:0", max_batch=1, max_frames=T, arena=voc.arena, exact_fp32=exact)   # the arena layout does not depend on the batch
     hop = vcfg.hop
     for b, n in enumerate(lens):
         assert not wav[b, 0, n * hop:].any(), f"row {b}: samples behind its own length"
         solo = one.detokenize(torch.from_numpy(sem[b:b + 1, :n]), torch.from_numpy(glob[b:b + 1])).cpu().numpy()
         d = float(np.abs(wav[b, 0, : n * hop] - solo[0, 0]).max())
-        assert d < 2e-5, f"row {b} ({n} frames) differs from its un-padded run by {d}"
+        assert d < row_tol, f"row {b} ({n} frames) differs from its un-padded run by {d}"
     ref = BiCodecDetokRef(vcfg, folded)
     for b in (5, 17, 30):
         n = lens[b]
