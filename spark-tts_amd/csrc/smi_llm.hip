@@ -1946,9 +1946,11 @@ int launch_gemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
   // QKV / o_proj / down / lm_head lose with fewer blocks.)
   if (p.M > 16) {
     if constexpr (N2 > 1) {
-      // SPARKMI_TUNE2 bit 2048 (A/B): three n tiles per block and ALL of a wave's k tiles in one batch -- every load of the
-      // block leaves at entry (one memory round trip instead of two dependent ones), 203 blocks at one block per CU
-      if (L->tune2 & 2048) return launch_gemm_kv<2, 3, NW, 4, 1, PRO, EPI>(L, p, st);
+      // 17..32 rows: three n tiles per block and ALL of a wave's k tiles in one batch -- every load of the block leaves at
+      // entry (one memory round trip instead of two dependent ones; 233 VGPRs, one 8-wave block per CU, 203 blocks):
+      // gate_up 12.8 -> 10.5 us, batch-32 step 1047 -> 998 us.  Beyond 32 rows (two block rows = 406 blocks, two rounds
+      // at one block per CU) and with SPARKMI_TUNE2 bit 2048 the two-tile, two-batch shape stays.
+      if (p.M <= 32 && !(L->tune2 & 2048)) return launch_gemm_kv<2, 3, NW, 4, 1, PRO, EPI>(L, p, st);
       return launch_gemm_kv<2, NTB * N2, NW, 2, 1, PRO, EPI>(L, p, st);   // two k tiles in flight: 13.9 -> 13.6 us at 32 rows, 18.5 -> 17.5 at 64
     }
     // few n tiles (N = 896 / 1152): 16-row blocks in two block rows put twice the CUs to work and halve the operand
