@@ -1955,7 +1955,11 @@ int launch_gemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
     }
     // few n tiles (N = 896 / 1152): 16-row blocks in two block rows put twice the CUs to work and halve the operand
     // bytes per CU (measured at M = 32; SPARKMI_TUNE2 bit 0 keeps 32-row blocks)
-    if constexpr (N2 == 0) { if (!(L->tune2 & 1)) return launch_gemm_kv<1, NTB, NW, U, 1, PRO, EPI, H>(L, p, st); }
+    // (WB batches of weight tiles requested at entry, as at 16 rows and fewer: down_proj's five batches then wait for L2
+    // operand round trips only, not for five dependent HBM round trips; SPARKMI_TUNE2 bit 4096 keeps WB = 1 for A/B)
+    if constexpr (N2 == 0) {
+      if (!(L->tune2 & 1)) return (L->tune2 & 4096) ? launch_gemm_kv<1, NTB, NW, U, 1, PRO, EPI, H>(L, p, st) : launch_gemm_kv<1, NTB, NW, U, WB, PRO, EPI, H>(L, p, st);
+    }
     return launch_gemm_kv<2, NTB, NW, (NW >= 16 || NTB >= 4 ? 2 : (U > 4 ? 4 : U)), 1, PRO, EPI>(L, p, st);
   }
   return launch_gemm_kv<1, NTB, NW, U, WB, PRO, EPI, H, OCC>(L, p, st);
