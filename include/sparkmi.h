@@ -229,6 +229,10 @@ typedef struct smi_enc_cfg {
   int32_t perc_depth, perc_heads, perc_ff_inner;
   int32_t max_samples;       /* longest prompt wav (samples) */
   int32_t max_ref_samples;   /* longest reference clip (samples) */
+  /* 0 (default): wav2vec2's transformer projections and the BiCodec encoder's ConvNeXt stack run on the bf16-split matrix
+   * pipe (as smi_voc_cfg.exact_fp32 describes); 1: every contraction on the exact-fp32 matrix pipe.  Token ids are arg-max /
+   * rounding decisions: they agree between the two modes wherever the decision margin exceeds the split's 2^-17 noise. */
+  int32_t exact_fp32;
 } smi_enc_cfg;
 
 /* Arena: like the vocoder's (same entry info and conv packing).  Names are the reference / transformers

@@ -343,6 +343,12 @@ EncLayout enc_layout(const smi_enc_cfg* c) {
   auto conv = [&](const std::string& name, int Cout, int Cin, int K) {
     add(name, PACK_CONV, Cout, Cin, K, (size_t)conv_geom(Cout, Cin, K, 1, 0, 1).floats);
   };
+  // convb: the dense stride-1 layers that carry the FLOPs (wav2vec2's transformer projections, the BiCodec encoder's
+  // ConvNeXt stack) -- on the bf16-split matrix pipe (k_convb, smi_net.h) unless the handle asks for exact fp32
+  auto convb = [&](const std::string& name, int Cout, int Cin, int K) {
+    const bool bf = !c->exact_fp32 && Cin >= 32 && Cout >= 32;
+    add(name, bf ? PACK_CONV_B : PACK_CONV, Cout, Cin, K, (size_t)conv_geom(Cout, Cin, K, 1, 0, 1, bf).floats);
+  };
   // ---- wav2vec2
   const int CD = c->w2v_conv_dim, H = c->w2v_hidden, I = c->w2v_inter;
   for (int i = 0; i < c->w2v_nconv; ++i) {
@@ -363,21 +369,21 @@ EncLayout enc_layout(const smi_enc_cfg* c) {
     const std::string p = "w2v.encoder.layers." + std::to_string(l);
     raw(p + ".layer_norm.weight", H);
     raw(p + ".layer_norm.bias", H);
-    conv("cat:" + p + ".attention.q_proj.weight|" + p + ".attention.k_proj.weight|" + p + ".attention.v_proj.weight", 3 * H, H, 1);
+    convb("cat:" + p + ".attention.q_proj.weight|" + p + ".attention.k_proj.weight|" + p + ".attention.v_proj.weight", 3 * H, H, 1);
     raw("cat:" + p + ".attention.q_proj.bias|" + p + ".attention.k_proj.bias|" + p + ".attention.v_proj.bias", (size_t)3 * H);
-    conv(p + ".attention.out_proj.weight", H, H, 1);
+    convb(p + ".attention.out_proj.weight", H, H, 1);
     raw(p + ".attention.out_proj.bias", H);
     raw(p + ".final_layer_norm.weight", H);
     raw(p + ".final_layer_norm.bias", H);
-    conv(p + ".feed_forward.intermediate_dense.weight", I, H, 1);
+    convb(p + ".feed_forward.intermediate_dense.weight", I, H, 1);
     raw(p + ".feed_forward.intermediate_dense.bias", I);
-    conv(p + ".feed_forward.output_dense.weight", H, I, 1);
+    convb(p + ".feed_forward.output_dense.weight", H, I, 1);
     raw(p + ".feed_forward.output_dense.bias", H);
   }
   // ---- BiCodec encoder + quantizer
   const int D = c->enc_dim, EI = c->enc_inter;
   auto vocos = [&](const std::string& p, int cin, int nl) {
-    conv(p + ".embed.weight", D, cin, 7);
+    convb(p + ".embed.weight", D, cin, 7);
     raw(p + ".embed.bias", D);
     raw(p + ".norm.weight", D);
     raw(p + ".norm.bias", D);
@@ -387,9 +393,9 @@ EncLayout enc_layout(const smi_enc_cfg* c) {
       raw(b + ".dwconv.bias", D);
       raw(b + ".norm.weight", D);
       raw(b + ".norm.bias", D);
-      conv(b + ".pwconv1.weight", EI, D, 1);
+      convb(b + ".pwconv1.weight", EI, D, 1);
       raw(b + ".pwconv1.bias", EI);
-      conv(b + ".pwconv2.weight", D, EI, 1);
+      convb(b + ".pwconv2.weight", D, EI, 1);
       raw(b + ".pwconv2.bias", D);
       raw(b + ".gamma", D);
     }
@@ -483,6 +489,11 @@ const float* ent(const smi_enc* h, const std::string& name) {
   for (const Entry& e : h->lay.e)
     if (e.name == name) return (const float*)(h->arena + e.offset);
   return nullptr;
+}
+bool ent_is_bf(const smi_enc* h, const std::string& name) {
+  for (const Entry& e : h->lay.e)
+    if (e.name == name) return e.kind == PACK_CONV_B || e.kind == PACK_CONVT_B;
+  return false;
 }
 
 }  // namespace
@@ -665,7 +676,8 @@ int smi_enc_forward(smi_enc* h, const float* wav_dev, int n_samples, const float
   auto conv = [&](const std::string& name, const std::string& wname, const std::string& bname, int Cout, int Cin, int K, int dil, int pad,
                   const float* X, int xstride, float* Y, const float* R, int ystride, int Tin, int Tout, int act, int istr) -> Launch& {
     P.push_back(make_conv_w(name, ent(h, wname), bname.empty() ? nullptr : ent(h, bname), Cout, Cin, K, dil, 1, pad, X, xstride, 0, Y,
-                            nullptr, nullptr, R, ystride, 0, slot(Tin), 1, Tout, act, istr, Tin == Tout ? nullptr : slot(Tout)));
+                            nullptr, nullptr, R, ystride, 0, slot(Tin), 1, Tout, act, istr, Tin == Tout ? nullptr : slot(Tout),
+                            ent_is_bf(h, wname)));
     return P.back();
   };
   auto mha = [&](const std::string& name, const float* Q, int qs, const float* K, int ks, const float* V, int vs, float* O, int os,

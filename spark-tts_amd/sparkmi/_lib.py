@@ -48,7 +48,7 @@ class EncCfg(C.Structure):
                                             "codebook_size", "codebook_dim", "n_fft", "win_length", "hop_length", "num_mels",
                                             "ecapa_channels", "ecapa_out", "spk_latent", "spk_tokens", "fsq_dims")]
                 + [("fsq_levels", C.c_int32 * 8)]
-                + [(n, C.c_int32) for n in ("perc_depth", "perc_heads", "perc_ff_inner", "max_samples", "max_ref_samples")])
+                + [(n, C.c_int32) for n in ("perc_depth", "perc_heads", "perc_ff_inner", "max_samples", "max_ref_samples", "exact_fp32")])
 
 
 # section ids of enum smi_llm_section

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .bicodec import PACK_RAW, pack_conv
+from .bicodec import PACK_CONV_B, PACK_CONVT_B, PACK_RAW, pack_conv, pack_conv_b
 from .config import BiCodecConfig
 from .config_tok import TokCfg, Wav2Vec2Cfg
 
@@ -126,7 +126,13 @@ def dft_basis(t: TokCfg) -> np.ndarray:
     return np.concatenate([np.cos(ang) * win, -np.sin(ang) * win], axis=0).astype(np.float32)
 
 
-def enc_cfg_struct(w: Wav2Vec2Cfg, t: TokCfg, max_samples: int, max_ref_samples: int) -> _lib.EncCfg:
+def enc_cfg_struct(w: Wav2Vec2Cfg, t: TokCfg, max_samples: int, max_ref_samples: int,
+                   exact_fp32: Optional[bool] = None) -> _lib.EncCfg:
+    """``exact_fp32``: every contraction on the exact-fp32 matrix pipe (verification mode) instead of the bf16-split pipe for
+    the transformer projections and the ConvNeXt stack; None reads SPARKMI_ENC_EXACT=1 from the environment."""
+    import os
+    if exact_fp32 is None:
+        exact_fp32 = os.environ.get("SPARKMI_ENC_EXACT") == "1"
     w.validate()
     t.validate()
     s = _lib.EncCfg(
@@ -138,7 +144,7 @@ def enc_cfg_struct(w: Wav2Vec2Cfg, t: TokCfg, max_samples: int, max_ref_samples:
         codebook_dim=t.codebook_dim, n_fft=t.n_fft, win_length=t.win_length, hop_length=t.hop_length, num_mels=t.num_mels,
         ecapa_channels=t.ecapa_channels, ecapa_out=t.ecapa_out, spk_latent=t.spk_latent_dim, spk_tokens=t.spk_token_num,
         fsq_dims=len(t.fsq_levels), perc_depth=t.perceiver_depth, perc_heads=t.perceiver_heads, perc_ff_inner=t.ff_inner,
-        max_samples=max_samples, max_ref_samples=max_ref_samples)
+        max_samples=max_samples, max_ref_samples=max_ref_samples, exact_fp32=int(bool(exact_fp32)))
     for i, (k, st) in enumerate(zip(w.conv_kernel, w.conv_stride)):
         s.w2v_kernel[i], s.w2v_stride[i] = k, st
     for i, v in enumerate(w.taps):
@@ -186,7 +192,8 @@ def pack_enc_arena(t: TokCfg, w2v_state: Mapping[str, np.ndarray], tok_state_fol
         key = name.value.decode()
         arr = tensor(key)
         kind, cout, cin, K, S, pad = list(info)
-        data = arr.reshape(-1) if kind == PACK_RAW else pack_conv(arr, kind, S, pad)
+        data = (arr.reshape(-1) if kind == PACK_RAW else
+                pack_conv_b(arr, kind, S, pad) if kind in (PACK_CONV_B, PACK_CONVT_B) else pack_conv(arr, kind, S, pad))
         if data.size * 4 != nb.value:
             raise ValueError(f"{key}: packed {data.size * 4} bytes, library expects {nb.value}")
         arena[off.value // 4: off.value // 4 + data.size] = data
@@ -198,7 +205,8 @@ class BiCodecEncoder:
 
     def __init__(self, wcfg: Wav2Vec2Cfg, tcfg: TokCfg, w2v_state: Optional[Mapping[str, np.ndarray]],
                  tok_state_folded: Optional[Mapping[str, np.ndarray]], device: Union[str, torch.device] = "cuda:0",
-                 max_seconds: float = 30.0, ref_seconds: float = 6.0, arena: Optional[torch.Tensor] = None):
+                 max_seconds: float = 30.0, ref_seconds: float = 6.0, arena: Optional[torch.Tensor] = None,
+                 exact_fp32: Optional[bool] = None):
         self.wcfg, self.tcfg = wcfg, tcfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -208,7 +216,8 @@ class BiCodecEncoder:
         _lib.require_gfx950()
         self.max_samples = int(max_seconds * tcfg.sample_rate)
         self.max_ref = int(ref_seconds * tcfg.sample_rate) + tcfg.n_fft
-        self._cs = enc_cfg_struct(wcfg, tcfg, self.max_samples, self.max_ref)
+        self._cs = enc_cfg_struct(wcfg, tcfg, self.max_samples, self.max_ref, exact_fp32)
+        self.exact_fp32 = bool(self._cs.exact_fp32)
         if arena is None:
             arena = torch.from_numpy(pack_enc_arena(tcfg, w2v_state, tok_state_folded, self._cs)).to(self.device)
         self.arena = arena
