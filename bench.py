@@ -322,7 +322,7 @@ def main():
             # prompt encode: (global, semantic) ids of each prompt wav, appended to the text prompt the way
             # process_prompt does (cli/SparkTTS.py:83-104); ids are mapped into the synthetic vocabulary
             t0 = time.perf_counter()
-            toks = [enc.tokenize_arrays(pwavs[i], prefs[i]) for i in range(B)]
+            toks = enc.tokenize_many(pwavs, prefs)       # the B prompts side by side on their own HIP streams
             glob_t = torch.cat([g for g, _ in toks], 0)
             sem_h = [s_.reshape(-1).cpu().numpy() for _, s_ in toks]
             g_h = glob_t.reshape(B, -1).cpu().numpy()

@@ -12,7 +12,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 from pathlib import Path
-from typing import Dict, Mapping, Optional, Tuple, Union
+from typing import Sequence, Dict, Mapping, Optional, Tuple, Union
 
 import numpy as np
 import torch
@@ -257,6 +257,37 @@ class BiCodecEncoder:
                    "smi_enc_forward")
         assert n.value == frames
         return glob, sem
+
+    @torch.no_grad()
+    def tokenize_many(self, wavs: Sequence[np.ndarray], refs: Sequence[np.ndarray], lanes: int = 8):
+        """Several prompts at once: prompt i runs on HIP stream i mod ``lanes`` with its own handle (own scratch; the weight
+        arena is shared).  One encode is ~260 small launches (a 6 s prompt is 299 frames: grids of tens of blocks), so
+        independent encodes fill the chip side by side -- 8 prompts: 68 ms one after the other, 35 ms on 8 streams
+        (tools/enc_streams.py); the ids are those of ``tokenize_arrays``, prompt by prompt.  Returns [(global, semantic)];
+        the current stream waits for all lanes."""
+        n = max(1, min(int(lanes), len(wavs)))
+        if not hasattr(self, "_lanes"):
+            self._lanes = [(self, torch.cuda.Stream(self.device))]
+        while len(self._lanes) < n:
+            sib = BiCodecEncoder(self.wcfg, self.tcfg, None, None, self.device, max_seconds=self.max_samples / self.tcfg.sample_rate,
+                                 ref_seconds=(self.max_ref - self.tcfg.n_fft) / self.tcfg.sample_rate, arena=self.arena,
+                                 exact_fp32=self.exact_fp32)
+            self._lanes.append((sib, torch.cuda.Stream(self.device)))
+        cur = torch.cuda.current_stream(self.device)
+        start = torch.cuda.Event()
+        start.record(cur)
+        out = []
+        for i, (w, r) in enumerate(zip(wavs, refs)):
+            enc, st = self._lanes[i % n]
+            if i < n:
+                st.wait_event(start)
+            with torch.cuda.stream(st):
+                out.append(enc.tokenize_arrays(w, r))
+        for enc, st in self._lanes[:n]:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            cur.wait_event(ev)
+        return out
 
     def debug_stage(self, name: str) -> torch.Tensor:
         out = torch.empty(64 * 1024 * 1024 // 4, dtype=torch.float32, device=self.device)

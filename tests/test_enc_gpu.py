@@ -120,3 +120,19 @@ def test_full_size_xlsr53_against_golden(golden_dir):
     assert sem.shape == g["sem"].shape
     assert (sem == g["sem"]).mean() > 0.97, f"semantic token agreement {(sem == g['sem']).mean()}"
     assert (glob == g["glob"]).mean() > 0.9, f"global token agreement {(glob == g['glob']).mean()}"
+
+
+def test_tokenize_many_on_parallel_streams_equals_one_by_one(tiny):
+    """Independent prompts encoded side by side on their own HIP streams (own handle, shared arena) give exactly the ids of
+    one-by-one calls, whatever the number of lanes and with more prompts than lanes."""
+    enc = tiny[0]
+    rng = np.random.default_rng(9)
+    wavs = [(0.2 * rng.standard_normal(int(16000 * s))).astype(np.float32) for s in (1.0, 2.3, 0.7, 1.9, 1.1)]
+    refs = [get_ref_clip(w.astype(np.float64), 16000, 1.0, 320).astype(np.float32) for w in wavs]
+    one = [enc.tokenize_arrays(w, r) for w, r in zip(wavs, refs)]
+    torch.cuda.synchronize()
+    for lanes in (1, 3, 8):
+        many = enc.tokenize_many(wavs, refs, lanes=lanes)
+        torch.cuda.synchronize()
+        for (g1, s1), (g2, s2) in zip(one, many):
+            assert torch.equal(g1, g2) and torch.equal(s1, s2)
