@@ -113,10 +113,11 @@ struct GemmP {
 };
 constexpr int kMaxOHeads = 16;
 
-// One weight tile piece (16 B per lane).  -DSMI_W_NT builds the A/B variant whose once-read decode weight streams use the
-// non-temporal policy (MI355X_MICROARCH.md, row nt-weights); the default build uses plain loads.
+// One weight tile piece (16 B per lane) of a once-read decode weight stream: non-temporal policy (MI355X_MICROARCH.md, row
+// nt-weights).  Measured as separate builds on one box: decode step 627.9 -> 625.3 us at one row (two alternating pairs);
+// -DSMI_W_PLAIN builds the plain-load variant for A/B (make variant NAME=plain VARFLAGS=-DSMI_W_PLAIN).
 __device__ __forceinline__ uint4 smi_ldw(const uint4* q) {
-#ifdef SMI_W_NT
+#ifndef SMI_W_PLAIN
   typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
   const u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)q);
   return make_uint4(v.x, v.y, v.z, v.w);
