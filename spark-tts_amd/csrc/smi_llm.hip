@@ -944,6 +944,155 @@ __global__ __launch_bounds__(256 * HV) void k_lm(GemmP p, int ngroups, int m0_la
   }
 }
 
+
+// lm_head for 17..32 rows per pass: ONE 4-wave group streams the weights once for both m-tiles.  Rows m0..m0+15 keep their
+// operand triples in registers exactly as in k_lm<1>; rows m0+16..m0+31 keep theirs in LDS (86 KB at K = 896: [k tile][3][4][16][16 B]),
+// read as MFMA B operands straight from there (3 KB of LDS reads per 1 KB weight tile -- far below the LDS rate).  k_lm<2>
+// gave each 16-row group its own four waves, i.e. every weight tile was pulled into registers twice per CU (72 us at 32
+// rows); here it is pulled once.  Same k-tile -> wave map, chains and reduction order per row as k_lm<1>: same logits bits.
+__global__ __launch_bounds__(256) void k_lm32(GemmP p, int ngroups, int m0) {
+  constexpr int NTB = 2, NW = 4, U = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int KT = p.KT, NT = p.NT;
+  const int M = p.M - m0 < 32 ? p.M - m0 : 32;                    // rows of this pass (>= 1)
+  float4* red = (float4*)smem;                                     // [NW][NTB][2][64]
+  float* rarr = (float*)(smem + (size_t)NW * NTB * 2 * 1024);      // [32]
+  float* bestv = rarr + 32;                                        // [NTB][32]
+  int* besti = (int*)(bestv + NTB * 32);
+  uint4* xl = (uint4*)(smem + (size_t)NW * NTB * 2 * 1024 + 32 * 4 + NTB * 32 * 8);   // [KT][3][4][16]
+  const int k8 = lane >> 4, em = lane & 15;
+  const int row0 = m0 + (em < M ? em : M - 1);                     // m-tile 0 row of this lane (clamped)
+  bf16x8 bf[U][3];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    int j = wave + u * NW;
+    j = j < KT ? j : KT - 1;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) bf[u][s] = *(const bf16x8*)(p.XS + xs_off(j, s, k8, row0, p.M));
+  }
+  uint4 w[U][NTB];
+  auto load_w = [&](int g) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int j = wave + u * NW;
+      j = j < KT ? j : KT - 1;
+#pragma unroll
+      for (int nb = 0; nb < NTB; ++nb) {
+        int nt = g * NTB + nb;
+        nt = nt < NT ? nt : NT - 1;
+        w[u][nb] = smi_ldw(&p.W[((size_t)nt * KT + j) * 64 + lane]);
+      }
+    }
+  };
+  int g = blockIdx.x;
+  if (g < ngroups) load_w(g);
+  // m-tile 1's operand pieces -> LDS (rows beyond M repeat the last row; their results are never stored)
+  for (int i = tid; i < KT * 12 * 16; i += 256) {
+    const int r = i & 15, pc = i >> 4;                             // pc = (kt * 3 + s) * 4 + k8
+    int m = m0 + 16 + r;
+    m = m < p.M ? m : p.M - 1;
+    xl[i] = *(const uint4*)(p.XS + ((size_t)pc * p.M + m) * 16);
+  }
+  for (int m = wave; m < M; m += NW) {
+    float v = smi_ss_lane_sum(p.sspart + (size_t)(m0 + m) * p.npart, p.npart, lane);
+    v = smi_wave_sum(v);
+    if (lane == 0) rarr[m] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
+  }
+  for (int i = tid; i < NTB * 32; i += 256) { bestv[i] = -INFINITY; besti[i] = 0x7fffffff; }
+  __syncthreads();
+  const int nb_e = wave & 1, mt_e = wave >> 1;                     // the (n tile, m tile) this wave finishes
+  const int ml = mt_e * 16 + em;                                   // its row (local)
+  const float rn = rarr[ml < M ? ml : 0];
+  for (; g < ngroups; g += gridDim.x) {
+    f32x4 acc[3][NTB][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int a = 0; a < NTB; ++a) { acc[c][a][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[c][a][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = wave + u * NW;
+      if (j < KT) {
+        bf16x8 b1[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) b1[s] = __builtin_bit_cast(bf16x8, xl[((j * 3 + s) * 4 + k8) * 16 + em]);
+#pragma unroll
+        for (int nb = 0; nb < NTB; ++nb) {
+          const bf16x8 a = __builtin_bit_cast(bf16x8, w[u][nb]);
+          acc[2][nb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[u][2], acc[2][nb][0], 0, 0, 0);
+          acc[1][nb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[u][1], acc[1][nb][0], 0, 0, 0);
+          acc[0][nb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[u][0], acc[0][nb][0], 0, 0, 0);
+          acc[2][nb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1[2], acc[2][nb][1], 0, 0, 0);
+          acc[1][nb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1[1], acc[1][nb][1], 0, 0, 0);
+          acc[0][nb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1[0], acc[0][nb][1], 0, 0, 0);
+        }
+      }
+    }
+    const int gn = g + gridDim.x;
+    if (gn < ngroups) load_w(gn);          // overlaps the reduction and the epilogue below
+#pragma unroll
+    for (int nb = 0; nb < NTB; ++nb)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const f32x4 t = (acc[2][nb][mt] + acc[1][nb][mt]) + acc[0][nb][mt];
+        red[((wave * NTB + nb) * 2 + mt) * 64 + lane] = make_float4(t[0], t[1], t[2], t[3]);
+      }
+    __syncthreads();
+    {
+      const int nt = g * NTB + nb_e;
+      if (nt < NT) {
+        float4 s = red[((0 * NTB + nb_e) * 2 + mt_e) * 64 + lane];
+#pragma unroll
+        for (int wv = 1; wv < NW; ++wv) {
+          const float4 t = red[((wv * NTB + nb_e) * 2 + mt_e) * 64 + lane];
+          s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        s.x *= rn; s.y *= rn; s.z *= rn; s.w *= rn;
+        const int n = nt * 16 + 4 * (lane >> 4);
+        const bool valid = ml < M;
+        if (valid && p.Y) {
+          float* y = p.Y + (size_t)(m0 + ml) * p.V + n;
+          if (n + 0 < p.V) y[0] = s.x;
+          if (n + 1 < p.V) y[1] = s.y;
+          if (n + 2 < p.V) y[2] = s.z;
+          if (n + 3 < p.V) y[3] = s.w;
+        }
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.V && sv[r] > bv) { bv = sv[r]; bi = n + r; }
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+          const float ov = __shfl_xor(bv, o, 64);
+          const int oi = __shfl_xor(bi, o, 64);
+          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane < 16 && valid) {
+          const float cv = bestv[nb_e * 32 + ml];
+          const int ci = besti[nb_e * 32 + ml];
+          if (bv > cv || (bv == cv && bi < ci)) { bestv[nb_e * 32 + ml] = bv; besti[nb_e * 32 + ml] = bi; }
+        }
+      }
+    }
+    __syncthreads();   // red is rewritten by the next group
+  }
+  if (tid < M) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int nb = 0; nb < NTB; ++nb) {
+      const float ov = bestv[nb * 32 + tid];
+      const int oi = besti[nb * 32 + tid];
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    p.pval[(size_t)(m0 + tid) * gridDim.x + blockIdx.x] = bv;
+    p.pidx[(size_t)(m0 + tid) * gridDim.x + blockIdx.x] = bi;
+  }
+}
+
 struct AttnP {
   const float* q;      // [M][q_dim]
   const void* kcache;  // layer base
@@ -2140,9 +2289,14 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
         if (M <= 16) {
           hipLaunchKernelGGL(k_lm<1>, dim3(L->lm_blocks), dim3(256), lds, st, p, ngroups, 0);
           SMI_LAUNCH_CHECK();
-        } else {              // two groups per block (32 rows per pass), one 8-wave block per CU
+        } else {              // 32 rows per pass: one 4-wave block per CU, the second m-tile's operands in LDS (k_lm32);
+                              // SPARKMI_TUNE2 bit 8192: the two-group kernel (k_lm<2>) for A/B
+          const size_t lds32 = (size_t)4 * 2 * 2 * 1024 + 32 * 4 + 2 * 32 * 8 + (size_t)L->KTh * 12 * 16 * 16;
           for (int m0 = 0; m0 < M; m0 += 32) {
-            hipLaunchKernelGGL(k_lm<2>, dim3(lm_blocks_for(L, M)), dim3(512), 2 * lds, st, p, ngroups, m0);
+            if (!(L->tune2 & 8192) && lds32 <= 150 * 1024)
+              hipLaunchKernelGGL(k_lm32, dim3(lm_blocks_for(L, M)), dim3(256), lds32, st, p, ngroups, m0);
+            else
+              hipLaunchKernelGGL(k_lm<2>, dim3(lm_blocks_for(L, M)), dim3(512), 2 * lds, st, p, ngroups, m0);
             SMI_LAUNCH_CHECK();
           }
         }
@@ -2421,6 +2575,9 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
     smi_llm_destroy(L);
     return SMI_EHIP;
   }
+  // k_lm32 stages 16 rows' operand triples in LDS (86 KB at K = 896): opt in to the large dynamic window here, once per
+  // handle (= per device), outside any stream capture
+  if (hipFuncSetAttribute((const void*)k_lm32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
   if (hipEventCreate(&L->ev0) != hipSuccess || hipEventCreate(&L->ev1) != hipSuccess) {
     smi_set_error("hipEventCreate failed");
     smi_llm_destroy(L);
