@@ -246,6 +246,35 @@ def gen_ops_layers(seed=0):
     print(f"[ops_layers] {len(out)} arrays: ResidualUnit x3, DecoderBlock x4, ConvNeXtBlock x2, RMSNorm, RoPE, GQA step, SwiGLU")
 
 
+def gen_extra(seed=0):
+    """The last two fixtures SURVEY 8c lists: (1) the vocoder on a B = 4 batch through the reference's own modules (tiny
+    config; equal lengths -- the reference has no length masks, a padded row would see its padding), (2) per-layer
+    hidden-state checksums of the tiny LLM from transformers (output_hidden_states)."""
+    out = {}
+    cfg = C.tiny_bicodec()
+    sd = W.bicodec_detok_state(cfg, seed=seed)
+    mods = build_reference_vocoder(cfg, sd)
+    rng = np.random.Generator(np.random.PCG64(4444))
+    sem = rng.integers(0, cfg.codebook_size, size=(4, 19), dtype=np.int64)
+    glob = rng.integers(0, int(np.prod(cfg.fsq_levels)), size=(4, 1, cfg.spk_token_num), dtype=np.int64)
+    with torch.no_grad():
+        wav = reference_detokenize(mods, torch.from_numpy(sem), torch.from_numpy(glob))
+    out["voc4_semantic"], out["voc4_global"], out["voc4_wav"] = sem, glob, wav.numpy()
+    lcfg = C.tiny_llm()
+    syn = W.SyntheticLLM(lcfg, seed=seed)
+    m = hf_model(lcfg, syn)
+    prompt = np.random.Generator(np.random.PCG64(1234)).integers(0, lcfg.vocab_size, size=(21,), dtype=np.int64)
+    with torch.no_grad():
+        o = m(torch.from_numpy(prompt)[None], output_hidden_states=True)
+    hs = o.hidden_states          # embeddings, then the output of every layer (the last one after the final norm in HF >= 4.x)
+    out["llm_prompt"] = prompt
+    out["llm_hidden_sum"] = np.array([float(h.double().sum()) for h in hs])
+    out["llm_hidden_abs"] = np.array([float(h.double().abs().sum()) for h in hs])
+    out["llm_hidden_first"] = np.stack([h[0, -1, :8].numpy() for h in hs])       # 8 values of the last position, per layer
+    np.savez_compressed(os.path.join(HERE, "extra.npz"), **out)
+    print(f"[extra] vocoder B=4 wav{tuple(wav.shape)}; {len(hs)} hidden-state checksums")
+
+
 def hf_model(cfg: C.LLMConfig, syn: W.SyntheticLLM):
     from transformers import Qwen2Config, Qwen2ForCausalLM
     hc = Qwen2Config(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
@@ -341,6 +370,8 @@ if __name__ == "__main__":
         gen_ops()
     if want("ops_layers"):
         gen_ops_layers()
+    if want("extra"):
+        gen_extra()
     if want("prompts"):
         gen_prompts()
     if want("voc"):

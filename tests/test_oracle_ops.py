@@ -98,3 +98,30 @@ def test_swiglu_mlp(g):
     x = torch.from_numpy(g["mlp.x"])
     y = F.linear(F.silu(F.linear(x, w["gate_proj.weight"])) * F.linear(x, w["up_proj.weight"]), w["down_proj.weight"])
     np.testing.assert_allclose(y.numpy(), g["mlp.y"], rtol=0, atol=1e-6)
+
+
+def test_vocoder_batch_of_four_matches_reference(golden_dir):
+    """The reference's own modules on a B = 4 batch (tiny config, equal lengths): the oracle's batch handling."""
+    from sparkmi import config as C, weights as W
+    g = np.load(os.path.join(golden_dir, "extra.npz"))
+    cfg = C.tiny_bicodec()
+    ref = BiCodecDetokRef(cfg, W.fold_weight_norm(W.bicodec_detok_state(cfg)))
+    wav = ref.detokenize(torch.from_numpy(g["voc4_semantic"]), torch.from_numpy(g["voc4_global"]))
+    np.testing.assert_allclose(wav.numpy(), g["voc4_wav"], rtol=0, atol=2e-6)
+
+
+def test_llm_hidden_states_per_layer_match_transformers(golden_dir):
+    """Per-layer hidden-state checksums of the tiny LLM from transformers (output_hidden_states): localises a mismatch to a layer."""
+    from sparkmi import config as C, weights as W
+    g = np.load(os.path.join(golden_dir, "extra.npz"))
+    cfg = C.tiny_llm()
+    ref = Qwen2Ref(cfg, W.SyntheticLLM(cfg))
+    logits, hid = ref.forward(g["llm_prompt"], return_hidden=True)
+    emb = ref.embed[torch.as_tensor(g["llm_prompt"])]
+    states = [emb] + hid
+    assert len(states) == len(g["llm_hidden_sum"])
+    for i, h in enumerate(states):
+        if i == len(states) - 1:        # transformers reports the LAST state after the final RMSNorm
+            h = ref.rmsnorm(h, ref.final_norm)
+        assert abs(float(h.double().abs().sum()) - g["llm_hidden_abs"][i]) < 1e-5 * g["llm_hidden_abs"][i], f"layer {i}"
+        np.testing.assert_allclose(h[-1, :8].numpy(), g["llm_hidden_first"][i], rtol=0, atol=2e-5, err_msg=f"layer {i}")
