@@ -520,8 +520,6 @@ def main():
             res["roofline"] = dict(res["roofline_step"])
         if not a.no_cpu_baseline and world == 1:
             log("gpu side done; timing the CPU oracle")
-            c1 = cfg3_inputs(0, 0, 1, 1)   # (keeps the helper imported in one place)
-            del c1
             cprompt = np.random.Generator(np.random.PCG64(1234)).integers(0, llm_cfg.vocab_size, size=128).tolist()
             cglob = np.random.Generator(np.random.PCG64(1235)).integers(0, 4096, size=ntok_glob)
             res["cpu_baseline"] = cpu_baseline(llm_cfg, voc_cfg, cprompt, cglob, a.cpu_tokens, a.cpu_runs)

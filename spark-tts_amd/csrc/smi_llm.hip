@@ -1985,6 +1985,7 @@ struct smi_llm {
   int prefetch;  // same-XCD L2 prefetch by helper blocks (SPARKMI_NO_PREFETCH=1 turns it off)
   int tune2;     // SPARKMI_TUNE2 bit mask (diagnostics)
   int pgemm_min_rows;   // prompt rows from which the prefill GEMM replaces row-grouped decode GEMMs (SPARKMI_PGEMM_MIN_ROWS)
+  int gu1_rows;         // rows up to which gate_up runs its one-batch, three-tile shape (SPARKMI_GU1_ROWS; default 32)
   hipGraphExec_t graph; int graph_B, graph_seg, graph_ident;
   hipEvent_t ev0, ev1;
   // host staging
@@ -2100,7 +2101,7 @@ int launch_gemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
       // entry (one memory round trip instead of two dependent ones; 233 VGPRs, one 8-wave block per CU, 203 blocks):
       // gate_up 12.8 -> 10.5 us, batch-32 step 1047 -> 998 us.  Beyond 32 rows (two block rows = 406 blocks, two rounds
       // at one block per CU) and with SPARKMI_TUNE2 bit 2048 the two-tile, two-batch shape stays.
-      if (p.M <= 32 && !(L->tune2 & 2048)) return launch_gemm_kv<2, 3, NW, 4, 1, PRO, EPI>(L, p, st);
+      if (p.M <= L->gu1_rows && !(L->tune2 & 2048)) return launch_gemm_kv<2, 3, NW, 4, 1, PRO, EPI>(L, p, st);
       return launch_gemm_kv<2, NTB * N2, NW, 2, 1, PRO, EPI>(L, p, st);   // two k tiles in flight: 13.9 -> 13.6 us at 32 rows, 18.5 -> 17.5 at 64
     }
     // few n tiles (N = 896 / 1152): 16-row blocks in two block rows put twice the CUs to work and halve the operand
@@ -2510,6 +2511,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
               L->NTh % kFuseQB == 0 && L->NTh / kFuseQB <= kAttnWaves * kFuseOT && L->KTh * 8 <= 256;
   { const char* e = getenv("SPARKMI_TUNE2"); L->tune2 = e ? atoi(e) : 0; }
   { const char* e = getenv("SPARKMI_PGEMM_MIN_ROWS"); L->pgemm_min_rows = e ? atoi(e) : 3072; }
+  { const char* e = getenv("SPARKMI_GU1_ROWS"); L->gu1_rows = e ? atoi(e) : 32; }
   L->graph = nullptr; L->graph_B = 0; L->graph_seg = 1; L->graph_ident = 1; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->ctl = nullptr; L->admit_seq = 0; memset(&L->hctl, 0, sizeof(L->hctl));
   L->session = 0; L->identity_slots = 1; L->attn_seg = 1; L->apart = nullptr; L->apart_floats = 0; memset(L->slot_busy, 0, sizeof(L->slot_busy)); memset(L->slot_len, 0, sizeof(L->slot_len));
   const size_t esz = cfg->kv_dtype ? 4 : 2;

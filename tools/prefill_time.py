@@ -25,6 +25,9 @@ for B, P in ((1, 128), (1, 64), (1, 400), (4, 128), (8, 128), (16, 128), (32, 12
     res.append((B, P, round(min(ts), 2), tok[0][0]))
 print(os.environ.get("MODE"), res)
 ''' % ROOT
-for mode, env in (("grouped", {"SPARKMI_PGEMM_MIN_ROWS": "100000"}), ("pgemm", {"SPARKMI_PGEMM_MIN_ROWS": "0"}), ("chunks", {"SPARKMI_PREFILL_CHUNKS": "1"})):
+modes = (("grouped", {"SPARKMI_PGEMM_MIN_ROWS": "100000"}), ("pgemm", {"SPARKMI_PGEMM_MIN_ROWS": "0"}), ("chunks", {"SPARKMI_PREFILL_CHUNKS": "1"}))
+if len(sys.argv) > 1 and sys.argv[1] == "gu1":   # gate_up's one-batch shape beyond 32 rows (row-grouped prefill)
+    modes = tuple((f"grouped gu1<={r}", {"SPARKMI_PGEMM_MIN_ROWS": "100000", "SPARKMI_GU1_ROWS": str(r)}) for r in (32, 128, 100000))
+for mode, env in modes:
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MODE=mode, **env), capture_output=True, text=True)
     print(r.stdout.strip() or r.stderr[-1500:], flush=True)
