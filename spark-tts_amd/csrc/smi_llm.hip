@@ -2784,7 +2784,11 @@ int smi_llm_admit(smi_llm* L, const int64_t* ids, const int32_t* lens, int n, in
   for (int b = 0; b < n; ++b) L->hctl.seqid[slots[b]] = L->admit_seq++;
   SMI_HIP(hipMemcpyAsync(L->ctl, &L->hctl, sizeof(Ctl), hipMemcpyHostToDevice, st));
   size_t tail = 0;
-  if ((rc = prefill_prompts(L, ids, lens, n, P_max, slots, &tail, st))) return rc;
+  if ((rc = prefill_prompts(L, ids, lens, n, P_max, slots, &tail, st))) {
+    if (L->paged)
+      for (int b = 0; b < n; ++b) pages_release(L, slots[b]);   // nothing was admitted: the pages go back
+    return rc;
+  }
   // first token of the new sequences: one step over the new rows alone
   int32_t zeros[kMaxRows] = {0};
   for (int b = 0; b < n; ++b) {

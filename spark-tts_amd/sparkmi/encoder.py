@@ -282,7 +282,10 @@ class BiCodecEncoder:
             if i < n:
                 st.wait_event(start)
             with torch.cuda.stream(st):
-                out.append(enc.tokenize_arrays(w, r))
+                g, sm = enc.tokenize_arrays(w, r)
+            g.record_stream(cur)      # produced on the lane's stream, consumed on the caller's: keep the allocator from
+            sm.record_stream(cur)     # handing the blocks to a later lane-stream allocation while the caller still reads them
+            out.append((g, sm))
         for enc, st in self._lanes[:n]:
             ev = torch.cuda.Event()
             ev.record(st)
