@@ -297,8 +297,14 @@ class BiCodecTokenizer:
 
     def tokenize_batch(self, batch) -> Tuple[torch.Tensor, torch.Tensor]:
         """audio_tokenizer.py:102-117 for a list of equally long prompts: {"wav": [...], "ref_wav": (B, L)}."""
-        g, s = zip(*[self._encoder().tokenize_arrays(np.asarray(w), np.asarray(r)) for w, r in zip(batch["wav"], batch["ref_wav"])])
+        g, s = zip(*self._encoder().tokenize_many([np.asarray(w) for w in batch["wav"]], [np.asarray(r) for r in batch["ref_wav"]]))
         return torch.cat(g, 0), torch.cat(s, 0)
+
+    def tokenize_many(self, audio_paths: Sequence[str]):
+        """Several prompt files at once: [(global ids (1, 1, Ntok), semantic ids (1, T_i))], each equal to ``tokenize(path)``;
+        the encodes run side by side on parallel HIP streams (``BiCodecEncoder.tokenize_many``)."""
+        wavs, refs = zip(*[self.process_audio(p) for p in audio_paths])
+        return self._encoder().tokenize_many(list(wavs), [r.numpy() for r in refs])
 
     def detokenize(self, global_tokens: torch.Tensor, semantic_tokens: torch.Tensor) -> np.ndarray:
         """(B, Ntok) global ids, (B, T) semantic ids -> waveform: (hop*T,) for B == 1 else (B, hop*T)."""

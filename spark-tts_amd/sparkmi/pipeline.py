@@ -137,6 +137,14 @@ class SparkTTS:
         if len(requests) > self._max_batch:
             raise ValueError(f"{len(requests)} requests > max_batch={self._max_batch}")
         prompts, globals_ = [], []
+        # voice-clone requests that come with prompt FILES: all their prompt encodes run side by side (parallel HIP streams)
+        need = [i for i, r in enumerate(requests)
+                if r.get("gender") is None and r.get("prompt_tokens") is None and r.get("prompt_speech_path") is not None]
+        if len(need) > 1:
+            toks = self.audio_tokenizer.tokenize_many([requests[i]["prompt_speech_path"] for i in need])
+            requests = [dict(r) for r in requests]
+            for i, t in zip(need, toks):
+                requests[i]["prompt_tokens"] = t
         for r in requests:
             if r.get("gender") is not None:
                 prompts.append(self.process_prompt_control(r["gender"], r.get("pitch"), r.get("speed"), r["text"]))

@@ -220,3 +220,29 @@ def test_serve_in_flight_batching_equals_inference(model_dir):
             assert got[i].shape == w.shape and np.array_equal(got[i], w), f"request {i}"
             checked += 1
     assert checked >= 3
+
+
+def test_batch_of_voice_clone_requests_with_prompt_files(model_dir, tmp_path):
+    """Two clone requests that bring prompt FILES: inference_batch encodes both prompts side by side (parallel HIP streams,
+    BiCodecEncoder.tokenize_many) and must give exactly the single-request results."""
+    from sparkmi.pipeline import SparkTTS
+    d, (lcfg, vcfg) = model_dir
+    paths = []
+    for i, (f0, secs) in enumerate(((150.0, 1.3), (210.0, 2.1))):
+        t = np.arange(int(16000 * secs)) / 16000.0
+        x = 0.3 * np.sin(2 * np.pi * f0 * t) * (0.5 + 0.5 * np.sin(2 * np.pi * 2.0 * t)) + 0.01 * np.random.default_rng(i).standard_normal(len(t))
+        p = tmp_path / f"prompt{i}.wav"
+        _write_wav(p, x)
+        paths.append(str(p))
+    tts = SparkTTS(d, torch.device("cuda:0"), max_batch=2, max_positions=1024, max_frames=256)
+    reqs = [dict(text="First speaker.", prompt_speech_path=paths[0], prompt_text="one"),
+            dict(text="Second speaker, a little longer.", prompt_speech_path=paths[1], prompt_text=None)]
+    many = tts.audio_tokenizer.tokenize_many(paths)
+    for p, (g, s_) in zip(paths, many):
+        g1, s1 = tts.audio_tokenizer.tokenize(p)
+        assert torch.equal(g, g1) and torch.equal(s_, s1)
+    batch = tts.inference_batch(reqs, do_sample=False, max_new_tokens=30)
+    for r, w in zip(reqs, batch):
+        one = tts.inference(r["text"], prompt_speech_path=r["prompt_speech_path"], prompt_text=r["prompt_text"], do_sample=False,
+                            max_new_tokens=30)
+        assert np.array_equal(one, w)
