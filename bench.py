@@ -195,6 +195,7 @@ def spawn_ranks(n: int) -> int:
 
 def main():
     a = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # before the first HIP call: RCCL needs dmabuf IPC on this pool
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
