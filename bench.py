@@ -363,8 +363,10 @@ def main():
         "metric": "audio samples/sec (whole node), Spark-TTS-0.5B greedy", "value": value, "unit": "audio samples/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1000.0 * el / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 weights + KV, fp32 activations/accumulate (LLM); fp32 (vocoder)" if a.kv == "bf16"
-                 else "bf16 weights, fp32 KV/activations (LLM); fp32 (vocoder)",
+        "dtype": ("bf16 weights + KV, fp32 activations/accumulate (LLM); " if a.kv == "bf16"
+                  else "bf16 weights, fp32 KV/activations (LLM); ") +
+                 ("fp32 (vocoder, exact-fp32 matrix pipe)" if voc.exact_fp32
+                  else "vocoder: fp32 operands split into 2 bf16 planes, 3 products on the bf16 matrix pipe, fp32 accumulate"),
         "data": "synthetic (seeded prompts and weights; no checkpoint or dataset offline)",
         "config": {"workload": f"Spark-TTS-0.5B, batch={B} greedy, {shape} (BASELINE.json configs[{cfg_idx}])",
                    **({"voice_clone": f"each utterance encodes a {a.prompt_seconds:.1f} s prompt wav on the GPU first (BASELINE.json configs[4])"} if a.clone else {}),
