@@ -481,6 +481,23 @@ struct smi_enc {
   std::map<std::string, Stage> stages;      // debug views of the last forward
   int last_frames;
   hipEvent_t ev0, ev1;
+  // One hipGraph per (n_samples, n_ref): the ~260 launches of an encode replayed as one graph launch.  The graph reads the
+  // prompt from / leaves the ids in handle-owned buffers (in_wav, in_ref, out_sem, out_glob), so it does not depend on the
+  // caller's pointers; the length slots are uploaded before every launch (they differ from key to key).
+  struct Graph {
+    hipGraphExec_t exec = nullptr;
+    std::vector<int32_t> lens;
+    std::vector<Launch> prog;
+    std::map<std::string, Stage> stages;
+    int frames = 0;
+    unsigned long long used = 0;
+  };
+  std::map<std::pair<int, int>, Graph> graphs;
+  std::pair<int, int> prog_key{-1, -1};
+  unsigned long long tick = 0;
+  bool use_graph = true;
+  hipStream_t gstream = nullptr;            // graph launches of callers on the null stream (which cannot be captured) run here
+  hipEvent_t gev0 = nullptr, gev1 = nullptr;
 };
 
 namespace {
@@ -591,6 +608,17 @@ int smi_enc_create(const smi_enc_cfg* cfg, const void* arena_dev, size_t arena_b
   want("pg", (size_t)c.perc_ff_inner * c.spk_tokens);
   want("pout", (size_t)c.spk_latent * c.spk_tokens);
   want("fsqb", (size_t)c.spk_tokens * 8);
+  want("in_wav", (size_t)c.max_samples + 64);
+  want("in_ref", (size_t)c.max_ref_samples + 64);
+  want("out_sem", (size_t)2 * T);           // int64 ids
+  want("out_glob", (size_t)c.spk_tokens + 64);
+  {
+    const char* e = getenv("SPARKMI_ENC_GRAPH");
+    h->use_graph = !(e && e[0] == '0');
+  }
+  // more than the default dynamic LDS window for the attention / positional-conv kernels (per device, before any capture)
+  (void)hipFuncSetAttribute((const void*)k_mha, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_posconv, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
   bool ok = true;
   for (auto& kv : h->buf_floats) {
     float* p = nullptr;
@@ -600,7 +628,10 @@ int smi_enc_create(const smi_enc_cfg* cfg, const void* arena_dev, size_t arena_b
   ok = ok && hipMalloc((void**)&h->cbn, (size_t)c.codebook_size * c.codebook_dim * 4) == hipSuccess &&
        hipMalloc((void**)&h->c2, (size_t)c.codebook_size * 4) == hipSuccess &&
        hipMalloc((void**)&h->lens_dev, 64 * 4) == hipSuccess &&
-       hipEventCreate(&h->ev0) == hipSuccess && hipEventCreate(&h->ev1) == hipSuccess;
+       hipEventCreate(&h->ev0) == hipSuccess && hipEventCreate(&h->ev1) == hipSuccess &&
+       hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) == hipSuccess &&
+       hipEventCreateWithFlags(&h->gev0, hipEventDisableTiming) == hipSuccess &&
+       hipEventCreateWithFlags(&h->gev1, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     smi_set_error("smi_enc_create: device allocation failed");
     smi_enc_destroy(h);
@@ -625,18 +656,22 @@ int smi_enc_destroy(smi_enc* h) {
   if (h->lens_dev) (void)hipFree(h->lens_dev);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (auto& kv : h->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+  if (h->gev0) (void)hipEventDestroy(h->gev0);
+  if (h->gev1) (void)hipEventDestroy(h->gev1);
+  if (h->gstream) (void)hipStreamDestroy(h->gstream);
   delete h;
   return SMI_OK;
 }
 
-int smi_enc_forward(smi_enc* h, const float* wav_dev, int n_samples, const float* ref_dev, int n_ref, int64_t* sem_dev,
-                    int32_t* glob_dev, int* n_frames, void* stream) {
-  SMI_REQUIRE(h && wav_dev && ref_dev && sem_dev && glob_dev && n_frames, "smi_enc_forward: null argument");
+}  // extern "C"
+
+namespace {
+
+// The launch sequence of one encode (h->prog), its length slots (h->host_lens) and debug views (h->stages); nothing runs here.
+int enc_build(smi_enc* h, const float* wav_dev, int n_samples, const float* ref_dev, int n_ref, int64_t* sem_dev, int32_t* glob_dev,
+              int* n_frames) {
   const smi_enc_cfg& c = h->cfg;
-  SMI_REQUIRE(n_samples >= 400 && n_samples <= c.max_samples, "smi_enc_forward: n_samples=%d outside 400..%d", n_samples, c.max_samples);
-  SMI_REQUIRE(n_ref > c.n_fft / 2 && n_ref <= c.max_ref_samples, "smi_enc_forward: n_ref=%d outside %d..%d", n_ref, c.n_fft / 2 + 1,
-              c.max_ref_samples);
-  hipStream_t st = (hipStream_t)stream;
   std::vector<Launch>& P = h->prog;
   P.clear();
   h->stages.clear();
@@ -686,8 +721,6 @@ int smi_enc_forward(smi_enc* h, const float* wav_dev, int n_samples, const float
     const size_t lds = (size_t)(512 + 8 * Tk + 64 * 65) * 4;
     const dim3 grid((Tq + 7) / 8, heads);
     closure(name, 4.0 * heads * 64.0 * Tq * Tk, [=](hipStream_t s) {
-      static bool attr = false;
-      if (!attr) { (void)hipFuncSetAttribute((const void*)k_mha, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
       hipLaunchKernelGGL(k_mha, grid, dim3(256), lds, s, m);
     });
   };
@@ -731,8 +764,6 @@ int smi_enc_forward(smi_enc* h, const float* wav_dev, int n_samples, const float
     const int Cg = Hd / c.w2v_pos_groups, K = c.w2v_pos_k;
     const size_t lds = (size_t)Cg * (64 + K - 1) * 4;
     closure("w2v.pos_conv+gelu+res", 2.0 * Hd * Cg * K * T, [=](hipStream_t s) {
-      static bool attr = false;
-      if (!attr) { (void)hipFuncSetAttribute((const void*)k_posconv, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
       hipLaunchKernelGGL(k_posconv, dim3((T + 63) / 64, Hd / 16), dim3(256), lds, s, x, Wp, bp, hbuf, Hd, Cg, K, T, T);
     });
   }
@@ -896,7 +927,6 @@ int smi_enc_forward(smi_enc* h, const float* wav_dev, int n_samples, const float
   }
 
   SMI_REQUIRE(hl.size() <= 64, "smi_enc_forward: too many distinct lengths");
-  SMI_HIP(hipMemcpyAsync(h->lens_dev, hl.data(), hl.size() * 4, hipMemcpyHostToDevice, st));
   for (const Launch& L : P) {
     if (L.kind == 0) {
       SMI_REQUIRE(L.cp.W, "smi_enc_forward: arena entry for %s not found", L.name.c_str());
@@ -904,8 +934,94 @@ int smi_enc_forward(smi_enc* h, const float* wav_dev, int n_samples, const float
       SMI_REQUIRE(L.cp.xw <= 192 && (L.chg == 1 || L.cp.xw <= 64), "smi_enc_forward: %s stages %d columns", L.name.c_str(), L.cp.xw);
     }
     if (L.kind == 1) SMI_REQUIRE(L.lp.w && L.lp.bsh && L.cpt <= 32, "smi_enc_forward: LayerNorm %s: missing weights or too many channels", L.name.c_str());
+  }
+  *n_frames = T;
+  return SMI_OK;
+}
+
+int enc_run(const std::vector<Launch>& P, hipStream_t st) {
+  for (const Launch& L : P) {
     int rc = run_launch(L, st);
     if (rc) return rc;
+  }
+  return SMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smi_enc_forward(smi_enc* h, const float* wav_dev, int n_samples, const float* ref_dev, int n_ref, int64_t* sem_dev,
+                    int32_t* glob_dev, int* n_frames, void* stream) {
+  SMI_REQUIRE(h && wav_dev && ref_dev && sem_dev && glob_dev && n_frames, "smi_enc_forward: null argument");
+  const smi_enc_cfg& c = h->cfg;
+  SMI_REQUIRE(n_samples >= 400 && n_samples <= c.max_samples, "smi_enc_forward: n_samples=%d outside 400..%d", n_samples, c.max_samples);
+  SMI_REQUIRE(n_ref > c.n_fft / 2 && n_ref <= c.max_ref_samples, "smi_enc_forward: n_ref=%d outside %d..%d", n_ref, c.n_fft / 2 + 1,
+              c.max_ref_samples);
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (!h->use_graph) {
+    if ((rc = enc_build(h, wav_dev, n_samples, ref_dev, n_ref, sem_dev, glob_dev, n_frames))) return rc;
+    h->prog_key = {-1, -1};
+    SMI_HIP(hipMemcpyAsync(h->lens_dev, h->host_lens.data(), h->host_lens.size() * 4, hipMemcpyHostToDevice, st));
+    if ((rc = enc_run(h->prog, st))) return rc;
+    h->last_frames = *n_frames;
+    return SMI_OK;
+  }
+  float *in_wav = h->buf.at("in_wav"), *in_ref = h->buf.at("in_ref");
+  int64_t* out_sem = (int64_t*)h->buf.at("out_sem");
+  int32_t* out_glob = (int32_t*)h->buf.at("out_glob");
+  const std::pair<int, int> key(n_samples, n_ref);
+  // the null stream cannot be captured: such callers' encodes run on the handle's own stream, fenced by events on both sides
+  hipStream_t run = st ? st : h->gstream;
+  if (!st) {
+    SMI_HIP(hipEventRecord(h->gev0, st));
+    SMI_HIP(hipStreamWaitEvent(run, h->gev0, 0));
+  }
+  SMI_HIP(hipMemcpyAsync(in_wav, wav_dev, (size_t)n_samples * 4, hipMemcpyDeviceToDevice, run));
+  SMI_HIP(hipMemcpyAsync(in_ref, ref_dev, (size_t)n_ref * 4, hipMemcpyDeviceToDevice, run));
+  auto it = h->graphs.find(key);
+  if (it == h->graphs.end()) {
+    if (h->graphs.size() >= 8) {   // keep the eight most recently used shapes
+      auto old = h->graphs.begin();
+      for (auto j = h->graphs.begin(); j != h->graphs.end(); ++j) if (j->second.used < old->second.used) old = j;
+      SMI_HIP(hipStreamSynchronize(run));
+      if (old->second.exec) (void)hipGraphExecDestroy(old->second.exec);
+      h->graphs.erase(old);
+    }
+    int T = 0;
+    if ((rc = enc_build(h, in_wav, n_samples, in_ref, n_ref, out_sem, out_glob, &T))) return rc;
+    smi_enc::Graph g;
+    g.lens = h->host_lens; g.prog = h->prog; g.stages = h->stages; g.frames = T;
+    SMI_HIP(hipMemcpyAsync(h->lens_dev, g.lens.data(), g.lens.size() * 4, hipMemcpyHostToDevice, run));
+    SMI_HIP(hipStreamSynchronize(run));      // (the pageable source above must be read before g.lens moves into the map)
+    SMI_HIP(hipStreamBeginCapture(run, hipStreamCaptureModeRelaxed));
+    rc = enc_run(g.prog, run);
+    hipGraph_t graph = nullptr;
+    const hipError_t ec = hipStreamEndCapture(run, &graph);
+    if (rc || ec != hipSuccess || !graph) {
+      if (graph) (void)hipGraphDestroy(graph);
+      if (!rc) { smi_set_error("smi_enc_forward: stream capture failed: %s", hipGetErrorString(ec)); rc = SMI_EHIP; }
+      return rc;
+    }
+    const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) { smi_set_error("smi_enc_forward: hipGraphInstantiate: %s", hipGetErrorString(ei)); return SMI_EHIP; }
+    h->prog_key = key;
+    it = h->graphs.emplace(key, std::move(g)).first;
+  } else {
+    if (h->prog_key != key) { h->prog = it->second.prog; h->prog_key = key; }
+    h->stages = it->second.stages;
+    SMI_HIP(hipMemcpyAsync(h->lens_dev, it->second.lens.data(), it->second.lens.size() * 4, hipMemcpyHostToDevice, run));
+  }
+  it->second.used = ++h->tick;
+  SMI_HIP(hipGraphLaunch(it->second.exec, run));
+  const int T = it->second.frames;
+  SMI_HIP(hipMemcpyAsync(sem_dev, out_sem, (size_t)T * 8, hipMemcpyDeviceToDevice, run));
+  SMI_HIP(hipMemcpyAsync(glob_dev, out_glob, (size_t)c.spk_tokens * 4, hipMemcpyDeviceToDevice, run));
+  if (!st) {
+    SMI_HIP(hipEventRecord(h->gev1, run));
+    SMI_HIP(hipStreamWaitEvent(st, h->gev1, 0));
   }
   h->last_frames = T;
   *n_frames = T;

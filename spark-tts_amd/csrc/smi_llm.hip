@@ -630,20 +630,176 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
 // 128 rows and an operand piece once per 128 output columns.  One accumulator per (tile, m-tile),
 // terms in the order lo, mid, hi per k tile: a row's result does not depend on M or on the batch.
 // ------------------------------------------------------------------------------------------
-template <int PRO, int EPI, int KVF32, int NTW = 2>
+// WR = 2: the waves form a 2 x 2 grid (row half x column half) -- a wave reads only its 64 rows' pieces from LDS (half the LDS
+// bytes per MFMA of WR = 1, where every wave reads all 128 rows) and each weight tile is requested by the two waves of a column half.
+// One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to LDS bytes [lds_dst + 16 * lane) (lds_dst
+// wave-uniform).  Inline asm, M0 written in the statement that reads it: hipcc waits vmcnt(0) in front of every ds_read while an
+// LDS-DMA it knows of (the builtin) is pending; these it does not see, the counted waits are written by hand.
+__device__ __forceinline__ void smi_glds16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ void smi_keep4(const uint4& v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }   // (ablation builds: keeps a value live)
+
+// RING >= 3: both operands of a k tile arrive by LDS-DMA (global_load_lds_dwordx4, no staging registers) in a ring of RING slots,
+// RING - 1 tiles requested ahead of the one being multiplied; a counted vmcnt + one raw barrier per k tile (the loads of the
+// tiles ahead stay in flight across it).  The register-staged form (RING = 0) waits a whole L2 / HBM round trip per k tile.
+// XMAP (few column blocks per row block: QKV, o_proj, down): the launch is one-dimensional and a block's (column, row)
+// block comes from its position in its XCD's share of the grid (blocks go to XCD id mod 8), so that the column blocks of a row
+// block run on one XCD side by side: an operand piece then comes from the Infinity Cache once and from that XCD's L2 for the
+// others (as launched, x fastest, the 6-7 column blocks of a row block sat on 6-7 different XCDs and every operand byte
+// was served at the Infinity-Cache rate: down_proj 7.3 TB/s of L2 -> LDS traffic; a workgroup reads ~33 GB/s from there, ~70 from L2).
+template <int PRO, int EPI, int KVF32, int NTW = 2, int WR = 1, int RING = 0, int XMAP = 0>
 __global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
   constexpr int MTB = 8, ROWS = MTB * 16, PIECES = 3 * 4 * ROWS;   // 1536 16-byte pieces per k tile; NTW weight tiles per wave
+  constexpr int MTW = MTB / WR, NWC = 4 / WR;                      // m-tiles per wave, waves across the block's columns
+  constexpr int CT = NWC * NTW;                                    // weight tiles per block
+  constexpr int SLOT = PIECES + CT * 64;                           // RING: 16-byte pieces per ring slot (operand image, then weight tiles)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint4* Bs = (uint4*)smem;                              // [2][PIECES]
-  float* rarr = (float*)(smem + (size_t)2 * PIECES * 16);  // [ROWS]
+  uint4* Bs = (uint4*)smem;                              // [2][PIECES], or [RING][SLOT]
+  float* rarr = (float*)(smem + (size_t)(RING ? RING * SLOT : 2 * PIECES) * 16);  // [ROWS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int KT = p.KT, M = p.M, NT = p.NT;
-  const int m0 = blockIdx.y * ROWS;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if constexpr (XMAP) {   // bijective for any grid size: XCD c owns a contiguous range of (row block, column block) pairs, column fastest
+    const int gx = (NT + CT - 1) / CT, nb = gridDim.x, q = nb >> 3, r = nb & 7, c = bx & 7;
+    const int v = (c < r ? c * (q + 1) : r * (q + 1) + (c - r) * q) + (bx >> 3);
+    by = v / gx;
+    bx = v - by * gx;
+  }
+  const int m0 = by * ROWS;
   const int k8 = lane >> 4, em = lane & 15;
+  const int wr = wave % WR, wc = wave / WR, mt0 = wr * MTW;
   int nts[NTW];
 #pragma unroll
-  for (int i = 0; i < NTW; ++i) { const int nt = ((int)blockIdx.x * 4 + wave) * NTW + i; nts[i] = nt < NT ? nt : NT - 1; }
+  for (int i = 0; i < NTW; ++i) { const int nt = (bx * NWC + wc) * NTW + i; nts[i] = nt < NT ? nt : NT - 1; }
 
+  f32x4 acc[NTW][MTW];
+#pragma unroll
+  for (int a = 0; a < NTW; ++a)
+#pragma unroll
+    for (int b = 0; b < MTW; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if constexpr (RING != 0) {
+    static_assert(RING >= 3 && CT % 4 == 0, "ring form: a wave-instruction moves one weight tile, four per pass of the block");
+    constexpr int GA = CT / 4, G = 6 + GA;               // LDS-DMA instructions per thread and k tile
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t lbase = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)smem);
+    int brow = m0 + (tid & (ROWS - 1));
+    brow = brow < M ? brow : M - 1;
+    const unsigned char* bsrc = p.XS + ((size_t)(tid >> 7) * M + brow) * 16;   // piece i of k tile kt: + ((kt * 12 + 2 i) * M) * 16
+    const uint4* asrc[GA];
+#pragma unroll
+    for (int a = 0; a < GA; ++a) {
+      const int nt = bx * CT + 4 * a + wv;
+      asrc[a] = p.W + (size_t)(nt < NT ? nt : NT - 1) * KT * 64 + lane;
+    }
+    auto issue = [&](int kt, int slot) {                 // tile kt (clamped: the extra requests of the last iterations keep the count uniform) -> ring slot
+      const int kc = kt < KT ? kt : KT - 1;
+      const uint32_t d = lbase + (uint32_t)(slot * SLOT + wv * 64) * 16;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) smi_glds16(bsrc + ((size_t)(kc * 12 + 2 * i) * M) * 16, d + 256 * 16 * i);
+#pragma unroll
+      for (int a = 0; a < GA; ++a) smi_glds16(asrc[a] + (size_t)kc * 64, d + (uint32_t)(PIECES + 4 * a * 64) * 16);
+    };
+#pragma unroll
+    for (int t = 0; t < RING - 1; ++t) issue(t, t);
+    if (PRO == PRO_NORM) {
+      // a wave's 32 rows, eight at a time with their loads in flight together (one row after the other: 32 dependent L2
+      // round trips, ~50 us in front of the k loop); per row the order of smi_ss_lane_sum + smi_wave_sum
+      const int np = p.npart, last = np - 1;
+      if (np <= 256) {
+        int idx[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) idx[q] = lane + 64 * q < np ? lane + 64 * q : last;
+        for (int r0 = wave * 32; r0 < wave * 32 + 32; r0 += 8) {
+          float a[8][4];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            int m = m0 + r0 + j;
+            m = m < M ? m : M - 1;
+            const float* sp = p.sspart + (size_t)m * np;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[j][q] = sp[idx[q]];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v += lane + 64 * q < np ? a[j][q] : 0.f;
+            v = smi_wave_sum(v);
+            if (lane == 0) rarr[r0 + j] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
+          }
+        }
+      } else {
+        for (int r = wave * 32; r < wave * 32 + 32; ++r) {
+          int m = m0 + r;
+          m = m < M ? m : M - 1;
+          float v = smi_ss_lane_sum(p.sspart + (size_t)m * np, np, lane);
+          v = smi_wave_sum(v);
+          if (lane == 0) rarr[r] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
+        }
+      }
+    }
+    // Fragment registers of two k tiles: tile kt + 1's are read from LDS while tile kt's feed the MFMAs (every wave of the block
+    // reads at the same time -- right behind the barrier -- so without the second set the LDS phase and the MFMA phase of
+    // an iteration add up instead of overlapping: measured 2060 cycles per k tile for 768 of MFMAs).
+    struct Frag { uint4 a[NTW]; uint4 b[MTW][3]; };
+    Frag f0, f1;
+    auto fread = [&](Frag& f, int slot) {
+      const uint4* Bb = Bs + (size_t)slot * SLOT;
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) f.a[i] = Bb[PIECES + (wc * NTW + i) * 64 + lane];
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) f.b[mt][s] = Bb[(s * 4 + k8) * ROWS + (mt0 + mt) * 16 + em];
+    };
+    auto fmma = [&](const Frag& f) {
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) {
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, f.b[mt][0]), b1 = __builtin_bit_cast(bf16x8, f.b[mt][1]), b2 = __builtin_bit_cast(bf16x8, f.b[mt][2]);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+          const bf16x8 a = __builtin_bit_cast(bf16x8, f.a[i]);
+          acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2, acc[i][mt], 0, 0, 0);
+          acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[i][mt], 0, 0, 0);
+          acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[i][mt], 0, 0, 0);
+        }
+      }
+    };
+    // Iteration kt: read tile kt + 1's fragments (slot rn: landed before the last barrier), request tile kt + RING - 1 into
+    // the slot of tile kt - 1 (its reads were waited for before the last barrier), multiply tile kt.  Then: this thread's
+    // part of tile kt + 2 has landed (counted vmcnt: the RING - 3 tiles behind it stay in flight across the raw barrier; a
+    // __syncthreads would drain them), this wave's LDS reads are done (lgkmcnt(0)), barrier.
+#define SMI_PG_SYNC() asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((RING - 3) * G) : "memory")
+#ifndef SMI_PG_ABL
+#define SMI_PG_ABL 0   // timing-only builds (tools/pg_ablate.sh): 1 no MFMAs, 2 no LDS-DMA in the loop, 4 no epilogue, 8 no fragment reads
+#endif
+#define SMI_PG_STEP(cur_, nxt_, kt_) do { \
+      if (!(SMI_PG_ABL & 8)) fread(nxt_, rn); \
+      if (!(SMI_PG_ABL & 2)) issue((kt_) + RING - 1, ws); \
+      if (!(SMI_PG_ABL & 1)) fmma(cur_); else { _Pragma("unroll") for (int i_ = 0; i_ < NTW; ++i_) smi_keep4((cur_).a[i_]); _Pragma("unroll") for (int m_ = 0; m_ < MTW; ++m_) { smi_keep4((cur_).b[m_][0]); smi_keep4((cur_).b[m_][1]); smi_keep4((cur_).b[m_][2]); } } \
+      SMI_PG_SYNC(); \
+      rn = rn + 1 == RING ? 0 : rn + 1; \
+      ws = ws + 1 == RING ? 0 : ws + 1; \
+    } while (0)
+    if (SMI_PG_ABL & 8) { f0 = Frag{}; f1 = Frag{}; }
+    SMI_PG_SYNC();                                        // tiles 0 and 1 (rarr: the fence below)
+    __syncthreads();
+    fread(f0, 0);
+    int rn = 1, ws = RING - 1;
+    for (int kt = 0; kt < KT; kt += 2) {
+      SMI_PG_STEP(f0, f1, kt);
+      if (kt + 1 < KT) SMI_PG_STEP(f1, f0, kt + 1);
+      else f0 = f1;                                       // (odd KT: the loop ends here; keeps the two paths' live sets alike)
+    }
+#undef SMI_PG_STEP
+#undef SMI_PG_SYNC
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped extra requests: nothing may still write LDS when the block ends
+  } else {
   // The six staged pieces are named registers, not an array: as `uint4 sreg[6]` the compiler left them in scratch
   // memory (ScratchSize 112), which put a wait for the global loads right behind their issue -- in front of the k
   // tile's MFMAs instead of behind them.
@@ -667,11 +823,6 @@ __global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
       if (lane == 0) rarr[r] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
     }
   }
-  f32x4 acc[NTW][MTB];
-#pragma unroll
-  for (int a = 0; a < NTW; ++a)
-#pragma unroll
-    for (int b = 0; b < MTB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   stage_store(0);
   __syncthreads();
   // Weight tiles run two k tiles ahead of the MFMAs (HBM / L2 latency hidden behind 96 MFMAs per wave).  Three
@@ -687,10 +838,10 @@ __global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
     const uint4* Bb = Bs + (kq_ & 1) * PIECES; \
     /* operand pieces of m-tile mt + 1 are read from LDS while the MFMAs of m-tile mt run */ \
     uint4 bq[2][3]; \
-    _Pragma("unroll") for (int s = 0; s < 3; ++s) bq[0][s] = Bb[(s * 4 + k8) * ROWS + em]; \
-    _Pragma("unroll") for (int mt = 0; mt < MTB; ++mt) { \
-      if (mt + 1 < MTB) { \
-        _Pragma("unroll") for (int s = 0; s < 3; ++s) bq[(mt + 1) & 1][s] = Bb[(s * 4 + k8) * ROWS + (mt + 1) * 16 + em]; \
+    _Pragma("unroll") for (int s = 0; s < 3; ++s) bq[0][s] = Bb[(s * 4 + k8) * ROWS + mt0 * 16 + em]; \
+    _Pragma("unroll") for (int mt = 0; mt < MTW; ++mt) { \
+      if (mt + 1 < MTW) { \
+        _Pragma("unroll") for (int s = 0; s < 3; ++s) bq[(mt + 1) & 1][s] = Bb[(s * 4 + k8) * ROWS + (mt0 + mt + 1) * 16 + em]; \
       } \
       const bf16x8 b0 = __builtin_bit_cast(bf16x8, bq[mt & 1][0]), b1 = __builtin_bit_cast(bf16x8, bq[mt & 1][1]), \
                    b2 = __builtin_bit_cast(bf16x8, bq[mt & 1][2]); \
@@ -717,20 +868,30 @@ __global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
 #undef wload
 #undef stage_load
 #undef stage_store
+  }   // RING == 0
+#ifdef SMI_PG_ABL
+  if (RING != 0 && (SMI_PG_ABL & 4)) {
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) asm volatile("" ::"v"(acc[i][mt]));
+    return;
+  }
+#endif
   // ---- epilogue (same arithmetic as k_gemm's)
   const int N = NT * 16;
 #pragma unroll
   for (int i = 0; i < NTW; ++i) {
-    const int nt = ((int)blockIdx.x * 4 + wave) * NTW + i;
+    const int nt = (bx * NWC + wc) * NTW + i;
     if (nt >= NT) continue;   // wave-uniform
     const int n = nt * 16 + 4 * (lane >> 4);
 #pragma unroll
-    for (int mt = 0; mt < MTB; ++mt) {
-      const int m = m0 + mt * 16 + em;
+    for (int mt = 0; mt < MTW; ++mt) {
+      const int m = m0 + (mt0 + mt) * 16 + em;
       const bool valid = m < M;
       float4 s = make_float4(acc[i][mt][0], acc[i][mt][1], acc[i][mt][2], acc[i][mt][3]);
       if (PRO == PRO_NORM) {
-        const float r = rarr[mt * 16 + em];
+        const float r = rarr[(mt0 + mt) * 16 + em];
         s.x *= r; s.y *= r; s.z *= r; s.w *= r;
       }
       if (EPI == EPI_RESID) {
@@ -2335,12 +2496,26 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
 }
 
 // One prefill GEMM over M rows (any M) with k_pgemm; `which` as in launch_one (GEMM kernels only).
-template <int PRO, int EPI, int NTW = 2>
+template <int PRO, int EPI, int NTW = 2, int WR = 1, int RING = 0, int XMAP = 0>
 int launch_pgemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
-  const dim3 grid((p.NT + 4 * NTW - 1) / (4 * NTW), (p.M + 127) / 128);
-  const size_t lds = (size_t)2 * 1536 * 16 + 128 * 4;
-  if (L->cfg.kv_dtype) hipLaunchKernelGGL((k_pgemm<PRO, EPI, 1, NTW>), grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((k_pgemm<PRO, EPI, 0, NTW>), grid, dim3(256), lds, st, p);
+  constexpr int cols = (4 / WR) * NTW;   // weight tiles per block
+  const dim3 grid2((p.NT + cols - 1) / cols, (p.M + 127) / 128);
+  const dim3 grid = XMAP ? dim3(grid2.x * grid2.y) : grid2;
+  const size_t lds = (RING ? (size_t)RING * (1536 + cols * 64) : (size_t)2 * 1536) * 16 + 128 * 4;
+  if (lds > 64 * 1024) {   // opt in once per instantiation and device (as in launch_gemm_kv)
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    SMI_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev >= 0 && dev < 64 && !done[dev]) {
+      SMI_HIP(hipFuncSetAttribute((const void*)k_pgemm<PRO, EPI, 1, NTW, WR, RING, XMAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      SMI_HIP(hipFuncSetAttribute((const void*)k_pgemm<PRO, EPI, 0, NTW, WR, RING, XMAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      done[dev] = true;
+    }
+  }
+  if (L->cfg.kv_dtype) hipLaunchKernelGGL((k_pgemm<PRO, EPI, 1, NTW, WR, RING, XMAP>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((k_pgemm<PRO, EPI, 0, NTW, WR, RING, XMAP>), grid, dim3(256), lds, st, p);
   SMI_LAUNCH_CHECK();
   return SMI_OK;
 }
@@ -2363,7 +2538,7 @@ int launch_layers_big(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
     p.Y = L->bq; p.bias = (const float*)sec(L, SMI_LLM_BQKV, l); p.rope = (const float2*)sec(L, SMI_LLM_ROPE, 0);
     p.kcache = kv_layer(L, L->kcache, l); p.vcache = kv_layer(L, L->vcache, l);
     p.q_dim = L->Q; p.kv_dim = L->KV; p.n_kv = c.num_kv_heads; p.max_pos = c.max_positions; p.km = kv_map(L);
-    if ((rc = grouped ? launch_gemm<1, 16, 2, 1, PRO_NORM, EPI_QKV>(L, p, st) : launch_pgemm<PRO_NORM, EPI_QKV>(L, p, st))) return rc;
+    if ((rc = grouped ? launch_gemm<1, 16, 2, 1, PRO_NORM, EPI_QKV>(L, p, st) : ((L->tune2 & 16384) ? launch_pgemm<PRO_NORM, EPI_QKV>(L, p, st) : launch_pgemm<PRO_NORM, EPI_QKV, 6, 2, 3, 1>(L, p, st)))) return rc;
     if (l == c.num_layers - 1) break;
     // attention
     AttnP a;
@@ -2385,20 +2560,20 @@ int launch_layers_big(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
     o.M = M; o.rows = rows; o.eps = c.rms_eps; o.sspart = L->bss; o.npart = npart;
     o.W = (const uint4*)sec(L, SMI_LLM_WO, l); o.NT = L->NTh; o.KT = L->KTq; o.XS = L->bxs_attn; o.Y = L->bh;
     o.XSout = L->bxs_h; o.gamma_next = (const float*)sec(L, SMI_LLM_LN2, l); o.ssout = L->bss;
-    if ((rc = grouped ? launch_oproj(L, o, M, st) : launch_pgemm<PRO_PLAIN, EPI_RESID>(L, o, st))) return rc;
+    if ((rc = grouped ? launch_oproj(L, o, M, st) : ((L->tune2 & 16384) ? launch_pgemm<PRO_PLAIN, EPI_RESID>(L, o, st) : launch_pgemm<PRO_PLAIN, EPI_RESID, 4, 2, 4, 1>(L, o, st)))) return rc;
     // gate_up
     GemmP g;
     memset(&g, 0, sizeof(g));
     g.M = M; g.rows = rows; g.eps = c.rms_eps; g.sspart = L->bss; g.npart = npart;
     g.W = (const uint4*)sec(L, SMI_LLM_WGU, l); g.NT = L->NTgu; g.KT = L->KTh; g.XS = L->bxs_h; g.XSout = L->bxs_act;
-    if ((rc = grouped ? launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_SWIGLU, 1, 2>(L, g, st) : ((L->tune2 & 512) ? launch_pgemm<PRO_NORM, EPI_SWIGLU>(L, g, st) : launch_pgemm<PRO_NORM, EPI_SWIGLU, 4>(L, g, st)))) return rc;
+    if ((rc = grouped ? launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_SWIGLU, 1, 2>(L, g, st) : ((L->tune2 & 512) ? launch_pgemm<PRO_NORM, EPI_SWIGLU>(L, g, st) : (L->tune2 & 16384) ? launch_pgemm<PRO_NORM, EPI_SWIGLU, 4>(L, g, st) : (L->tune2 & 32768) ? launch_pgemm<PRO_NORM, EPI_SWIGLU, 8, 2, 3, 1>(L, g, st) : launch_pgemm<PRO_NORM, EPI_SWIGLU, 8, 2, 3>(L, g, st)))) return rc;
     // down
     GemmP d;
     memset(&d, 0, sizeof(d));
     d.M = M; d.rows = rows; d.eps = c.rms_eps; d.sspart = L->bss; d.npart = npart;
     d.W = (const uint4*)sec(L, SMI_LLM_WD, l); d.NT = L->NTh; d.KT = L->KTi; d.XS = L->bxs_act; d.Y = L->bh;
     d.XSout = L->bxs_h; d.ssout = L->bss; d.gamma_next = (const float*)sec(L, SMI_LLM_LN1, l + 1);
-    if ((rc = grouped ? launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID>(L, d, st) : launch_pgemm<PRO_PLAIN, EPI_RESID>(L, d, st))) return rc;
+    if ((rc = grouped ? launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID>(L, d, st) : ((L->tune2 & 16384) ? launch_pgemm<PRO_PLAIN, EPI_RESID>(L, d, st) : launch_pgemm<PRO_PLAIN, EPI_RESID, 4, 2, 4, 1>(L, d, st)))) return rc;
   }
   return SMI_OK;
 }

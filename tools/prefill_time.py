@@ -11,10 +11,11 @@ from sparkmi import config as Cf, weights as W
 from sparkmi.llm import SparkLLM
 from sparkmi.arena import llm_cfg_struct, pack_llm_arena
 cfg = Cf.spark_0p5b_llm()
-arena = torch.from_numpy(pack_llm_arena(cfg, W.SyntheticLLM(cfg), llm_cfg_struct(cfg, 1, 512, "bf16", True))).to("cuda:0")
+arena = torch.from_numpy(pack_llm_arena(cfg, W.SyntheticLLM(cfg), llm_cfg_struct(cfg, 1, 1024, "bf16", True))).to("cuda:0")
 res = []
-for B, P in ((1, 128), (1, 64), (1, 400), (4, 128), (8, 128), (16, 128), (32, 128)):
-    llm = SparkLLM(cfg, None, "cuda:0", max_slots=B, max_positions=512, arena=arena)
+sizes = [tuple(int(v) for v in x.split("x")) for x in os.environ.get("PF_SIZES", "1x128,1x64,1x400,4x128,8x128,16x128,32x128").split(",")]
+for B, P in sizes:
+    llm = SparkLLM(cfg, None, "cuda:0", max_slots=B, max_positions=1024, arena=arena)
     prompts = [np.random.Generator(np.random.PCG64(1 + b)).integers(0, cfg.vocab_size, size=P).tolist() for b in range(B)]
     ts = []
     for it in range(4):
@@ -26,6 +27,9 @@ for B, P in ((1, 128), (1, 64), (1, 400), (4, 128), (8, 128), (16, 128), (32, 12
 print(os.environ.get("MODE"), res)
 ''' % ROOT
 modes = (("grouped", {"SPARKMI_PGEMM_MIN_ROWS": "100000"}), ("pgemm", {"SPARKMI_PGEMM_MIN_ROWS": "0"}), ("chunks", {"SPARKMI_PREFILL_CHUNKS": "1"}))
+if len(sys.argv) > 1 and sys.argv[1] == "pg2":   # k_pgemm with the 2 x 2 wave grid vs the 1 x 4 one (SPARKMI_TUNE2 bit 16384), forced at every size
+    os.environ.setdefault("PF_SIZES", "1x128,1x460,4x128,8x460,32x128")
+    modes = (("pgemm 2x2", {"SPARKMI_PGEMM_MIN_ROWS": "0"}), ("pgemm 1x4", {"SPARKMI_PGEMM_MIN_ROWS": "0", "SPARKMI_TUNE2": "16384"}), ("default", {}))
 if len(sys.argv) > 1 and sys.argv[1] == "gu1":   # gate_up's one-batch shape beyond 32 rows (row-grouped prefill)
     modes = tuple((f"grouped gu1<={r}", {"SPARKMI_PGEMM_MIN_ROWS": "100000", "SPARKMI_GU1_ROWS": str(r)}) for r in (32, 128, 100000))
 for mode, env in modes:
