@@ -83,6 +83,9 @@ typedef struct smi_llm_cfg {
  *   WO columns (the attention output it multiplies): 32-column k tiles head-interleaved -- tile (half * num_heads + head)
  *             holds dims 32*half .. 32*half+31 of that head (sparkmi/arena.py: o_proj_col_perm);
  *   GATE_UP rows: gate and up interleaved (g0,u0,g1,u1,...);
+ *   WD (down_proj) tiles: the 64 pieces of a tile are stored row-part-major [q:4][k8:4][r:4][8] (row n = 4q + r) instead
+ *             of [k8:4][n:16][8]: the row-split down_proj kernels (4 or 8 rows of a tile per block) then read whole
+ *             128-byte lines (sparkmi/arena.py: pack_tiles(row_parts=True));
  *   LM_HEAD: vocab padded up to a multiple of 16 rows with zeros (also the embedding table);
  *   norms/bias: f32;  ROPE: float2 (cos,sin) [max_positions][head_dim/2].                      */
 enum smi_llm_section {

@@ -110,7 +110,12 @@ struct GemmP {
   const float* gam;      // [K] this RMSNorm's weight
   float* h2out;          // [K] block 0 leaves h + o_proj here (the residual down_proj adds to)
   const float* Yin;      // RESID: residual row source when it is not Y itself (null: Y)
+  int wperm;             // weight tiles stored row-part-major [q:4][k8:4][r:4][8] (W_down): lane (k8, n = 4q + r) owns piece q*16 + k8*4 + r
 };
+// piece index of `lane` inside a 1 KiB weight tile (see GemmP::wperm)
+__device__ __forceinline__ int smi_wlane(int lane, int wperm) {
+  return wperm ? ((lane & 12) << 2) + ((lane >> 4) << 2) + (lane & 3) : lane;
+}
 constexpr int kMaxOHeads = 16;
 
 // One weight tile piece (16 B per lane) of a once-read decode weight stream: non-temporal policy (MI355X_MICROARCH.md, row
@@ -217,6 +222,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
   int mrow[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) { const int m = mbase + mt * 16 + (lane & 15); mrow[mt] = m < M ? m : M - 1; }
+  const int wl = (H > 1 || EPI == EPI_RESID) ? smi_wlane(lane, p.wperm) : lane;
   auto load_w = [&](uint4 (&dst)[U][NTB], int j0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
       for (int nb = 0; nb < NTB; ++nb) {
         int nt = nt0 + nb;
         nt = nt < NT ? nt : NT - 1;
-        dst[u][nb] = wact ? smi_ldw(&p.W[((size_t)nt * KT + j) * 64 + lane]) : make_uint4(0u, 0u, 0u, 0u);
+        dst[u][nb] = wact ? smi_ldw(&p.W[((size_t)nt * KT + j) * 64 + wl]) : make_uint4(0u, 0u, 0u, 0u);
       }
     }
   };
@@ -694,7 +700,7 @@ __global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
 #pragma unroll
     for (int a = 0; a < GA; ++a) {
       const int nt = bx * CT + 4 * a + wv;
-      asrc[a] = p.W + (size_t)(nt < NT ? nt : NT - 1) * KT * 64 + lane;
+      asrc[a] = p.W + (size_t)(nt < NT ? nt : NT - 1) * KT * 64 + smi_wlane(lane, p.wperm);
     }
     auto issue = [&](int kt, int slot) {                 // tile kt (clamped: the extra requests of the last iterations keep the count uniform) -> ring slot
       const int kc = kt < KT ? kt : KT - 1;
@@ -829,7 +835,8 @@ __global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
   // register sets take the roles (in use, next, in flight) in turn -- the k loop is unrolled by three so that no
   // set is ever copied: with `wA = wB; wB = wC` at the loop end the compiler waited for the loads it had just issued.
   uint4 w0[NTW], w1[NTW], w2[NTW];
-#define wload(w_, kt_) do { const int kc_ = (kt_) < KT ? (kt_) : KT - 1; _Pragma("unroll") for (int i = 0; i < NTW; ++i) (w_)[i] = p.W[((size_t)nts[i] * KT + kc_) * 64 + lane]; } while (0)
+  const int wl_ = smi_wlane(lane, p.wperm);
+#define wload(w_, kt_) do { const int kc_ = (kt_) < KT ? (kt_) : KT - 1; _Pragma("unroll") for (int i = 0; i < NTW; ++i) (w_)[i] = p.W[((size_t)nts[i] * KT + kc_) * 64 + wl_]; } while (0)
 #define ktile(kt_, wuse_, wld_) do { \
     const int kq_ = (kt_); \
     wload(wld_, kq_ + 2); \
@@ -2146,6 +2153,7 @@ struct smi_llm {
   int prefetch;  // same-XCD L2 prefetch by helper blocks (SPARKMI_NO_PREFETCH=1 turns it off)
   int tune2;     // SPARKMI_TUNE2 bit mask (diagnostics)
   int pgemm_min_rows;   // prompt rows from which the prefill GEMM replaces row-grouped decode GEMMs (SPARKMI_PGEMM_MIN_ROWS)
+  int wd_parts;         // W_down tiles are stored row-part-major (include/sparkmi.h; SPARKMI_WD_PLAIN=1, read by the packer too: plain tile order, for A/B)
   int gu1_rows;         // rows up to which gate_up runs its one-batch, three-tile shape (SPARKMI_GU1_ROWS; default 32)
   hipGraphExec_t graph; int graph_B, graph_seg, graph_ident;
   hipEvent_t ev0, ev1;
@@ -2262,6 +2270,7 @@ int launch_gemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
       // entry (one memory round trip instead of two dependent ones; 233 VGPRs, one 8-wave block per CU, 203 blocks):
       // gate_up 12.8 -> 10.5 us, batch-32 step 1047 -> 998 us.  Beyond 32 rows (two block rows = 406 blocks, two rounds
       // at one block per CU) and with SPARKMI_TUNE2 bit 2048 the two-tile, two-batch shape stays.
+      // (five n tiles per block in two batches -- 244 blocks, one round: 13.3 us against 10.3, step 947 -> 1017: not a rounds problem)
       if (p.M <= L->gu1_rows && !(L->tune2 & 2048)) return launch_gemm_kv<2, 3, NW, 4, 1, PRO, EPI>(L, p, st);
       return launch_gemm_kv<2, NTB * N2, NW, 2, 1, PRO, EPI>(L, p, st);   // two k tiles in flight: 13.9 -> 13.6 us at 32 rows, 18.5 -> 17.5 at 64
     }
@@ -2419,7 +2428,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
           return launch_gemm<1, 8, 2, 2, PRO_NORM, EPI_SWIGLU, 1, 2, 6>(L, p, st);
       }
     case KD:   // h += Wd act; emits the next layer's input-norm operand (or the final norm's)
-      p.W = (const uint4*)sec(L, SMI_LLM_WD, layer); p.NT = L->NTh; p.KT = L->KTi;
+      p.W = (const uint4*)sec(L, SMI_LLM_WD, layer); p.NT = L->NTh; p.KT = L->KTi; p.wperm = L->wd_parts;
       p.XS = L->xs_act; p.Y = L->h;
       if (fused) p.Yin = L->h2;   // h + o_proj, left there by gate_up's block 0
       p.XSout = L->xs_h; p.ssout = L->sspart;
@@ -2571,7 +2580,7 @@ int launch_layers_big(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
     GemmP d;
     memset(&d, 0, sizeof(d));
     d.M = M; d.rows = rows; d.eps = c.rms_eps; d.sspart = L->bss; d.npart = npart;
-    d.W = (const uint4*)sec(L, SMI_LLM_WD, l); d.NT = L->NTh; d.KT = L->KTi; d.XS = L->bxs_act; d.Y = L->bh;
+    d.W = (const uint4*)sec(L, SMI_LLM_WD, l); d.NT = L->NTh; d.KT = L->KTi; d.XS = L->bxs_act; d.Y = L->bh; d.wperm = L->wd_parts;
     d.XSout = L->bxs_h; d.ssout = L->bss; d.gamma_next = (const float*)sec(L, SMI_LLM_LN1, l + 1);
     if ((rc = grouped ? launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID>(L, d, st) : ((L->tune2 & 16384) ? launch_pgemm<PRO_PLAIN, EPI_RESID>(L, d, st) : launch_pgemm<PRO_PLAIN, EPI_RESID, 4, 2, 4, 1>(L, d, st)))) return rc;
   }
@@ -2687,6 +2696,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   { const char* e = getenv("SPARKMI_TUNE2"); L->tune2 = e ? atoi(e) : 0; }
   { const char* e = getenv("SPARKMI_PGEMM_MIN_ROWS"); L->pgemm_min_rows = e ? atoi(e) : 3072; }
   { const char* e = getenv("SPARKMI_GU1_ROWS"); L->gu1_rows = e ? atoi(e) : 32; }
+  { const char* e = getenv("SPARKMI_WD_PLAIN"); L->wd_parts = !(e && e[0] && e[0] != '0'); }
   L->graph = nullptr; L->graph_B = 0; L->graph_seg = 1; L->graph_ident = 1; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->ctl = nullptr; L->admit_seq = 0; memset(&L->hctl, 0, sizeof(L->hctl));
   L->session = 0; L->identity_slots = 1; L->attn_seg = 1; L->apart = nullptr; L->apart_floats = 0; memset(L->slot_busy, 0, sizeof(L->slot_busy)); memset(L->slot_len, 0, sizeof(L->slot_len));
   const size_t esz = cfg->kv_dtype ? 4 : 2;

@@ -11,6 +11,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Mapping
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -40,8 +42,17 @@ class Bf16RoundingReport:
                 self.max_rel, self.worst = err, name
 
 
-def pack_tiles(w: np.ndarray, report: "Bf16RoundingReport" = None, name: str = "") -> np.ndarray:
-    """[N, K] fp32 -> uint16 bf16 bits in MFMA A-operand tile order; N padded to 16 with zeros."""
+def wd_row_parts() -> bool:
+    """W_down tile order (include/sparkmi.h): row-part-major unless SPARKMI_WD_PLAIN=1 (A/B; the library reads the same variable)."""
+    e = os.environ.get("SPARKMI_WD_PLAIN", "")
+    return not (e and e != "0")
+
+
+def pack_tiles(w: np.ndarray, report: "Bf16RoundingReport" = None, name: str = "", row_parts: bool = False) -> np.ndarray:
+    """[N, K] fp32 -> uint16 bf16 bits in MFMA A-operand tile order; N padded to 16 with zeros.
+    row_parts (W_down): inside a tile the 16-byte pieces are ordered [row part q:4][k8:4][row r:4] instead of [k8:4][n:16]
+    (n = 4q + r), so the 4 (or 8) rows that one block of the row-split down_proj kernels loads are 256 (512) contiguous
+    bytes -- whole 128-byte lines that no other block touches -- instead of four 64-byte half lines."""
     n, k = w.shape
     if k % 32:
         raise ValueError(f"K={k} must be a multiple of 32")
@@ -51,7 +62,10 @@ def pack_tiles(w: np.ndarray, report: "Bf16RoundingReport" = None, name: str = "
         report.add(name, w, bits)
     if npad != n:
         bits = np.concatenate([bits, np.zeros((npad - n, k), np.uint16)], axis=0)
-    t = bits.reshape(npad // 16, 16, k // 32, 4, 8).transpose(0, 2, 3, 1, 4)
+    if row_parts:
+        t = bits.reshape(npad // 16, 4, 4, k // 32, 4, 8).transpose(0, 3, 1, 4, 2, 5)   # [nt][q][r][kt][k8][8] -> [nt][kt][q][k8][r][8]
+    else:
+        t = bits.reshape(npad // 16, 16, k // 32, 4, 8).transpose(0, 2, 3, 1, 4)
     return np.ascontiguousarray(t).reshape(-1)
 
 
@@ -136,7 +150,7 @@ def pack_llm_arena(cfg: LLMConfig, weights: Mapping[str, np.ndarray], cs: _lib.L
         gu = np.empty((2 * g.shape[0], g.shape[1]), np.float32)
         gu[0::2], gu[1::2] = g, u
         put(_lib.LLM_WGU, i, pack_tiles(gu, rep, p + "mlp.gate_up"))
-        put(_lib.LLM_WD, i, pack_tiles(f32(weights[p + "mlp.down_proj.weight"]), rep, p + "mlp.down_proj"))
+        put(_lib.LLM_WD, i, pack_tiles(f32(weights[p + "mlp.down_proj.weight"]), rep, p + "mlp.down_proj", row_parts=wd_row_parts()))
     put(_lib.LLM_FINAL_NORM, 0, f32(weights["model.norm.weight"]))
     head = "model.embed_tokens.weight" if cfg.tie_word_embeddings else "lm_head.weight"
     if not cfg.tie_word_embeddings:

@@ -77,6 +77,18 @@ def test_pack_tiles_layout():
     assert not t[1, :, :, 4:, :].any()   # rows 20..31 are zero padding
 
 
+def test_pack_tiles_row_part_order_is_a_permutation_of_the_tile():
+    """W_down's tile order (include/sparkmi.h): piece (k8, n = 4q + r) of the plain order sits at q*16 + k8*4 + r."""
+    rng = np.random.default_rng(1)
+    w = W.round_bf16(rng.standard_normal((32, 96)).astype(np.float32))
+    plain = arena.pack_tiles(w).reshape(2, 3, 64, 8)            # [n_tile][k_tile][piece][8]
+    parts = arena.pack_tiles(w, row_parts=True).reshape(2, 3, 64, 8)
+    for lane in range(64):
+        k8, n = lane >> 4, lane & 15
+        np.testing.assert_array_equal(parts[:, :, (n >> 2) * 16 + k8 * 4 + (n & 3)], plain[:, :, lane])
+        assert (n >> 2) * 16 + k8 * 4 + (n & 3) == ((lane & 12) << 2) + ((lane >> 4) << 2) + (lane & 3)   # the kernels' smi_wlane
+
+
 def test_rope_pair_perm():
     p = arena.rope_pair_perm(2, 64)
     assert p[:6].tolist() == [0, 32, 1, 33, 2, 34] and p[64:68].tolist() == [64, 96, 65, 97]
