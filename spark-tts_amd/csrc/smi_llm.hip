@@ -657,15 +657,19 @@ __device__ __forceinline__ void smi_keep4(const uint4& v) { asm volatile("" ::"v
 // block run on one XCD side by side: an operand piece then comes from the Infinity Cache once and from that XCD's L2 for the
 // others (as launched, x fastest, the 6-7 column blocks of a row block sat on 6-7 different XCDs and every operand byte
 // was served at the Infinity-Cache rate: down_proj 7.3 TB/s of L2 -> LDS traffic; a workgroup reads ~33 GB/s from there, ~70 from L2).
-template <int PRO, int EPI, int KVF32, int NTW = 2, int WR = 1, int RING = 0, int XMAP = 0>
-__global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
+// TWO (RING = 2): two blocks per CU -- 80 KiB of LDS and at most 256 registers each -- instead of one with a deeper ring: one
+// block's prologue, epilogue and barrier stalls are covered by the other's MFMAs (gate_up: 2432 blocks of 128 x 256 in 9.5 rounds,
+// 10 us of un-overlapped prologue + epilogue per round at one block per CU).  One fragment set, the ring's other slot one k
+// tile ahead, and the RMSNorm factors are computed after the k loop into the ring's memory (no LDS left for them beside it).
+template <int PRO, int EPI, int KVF32, int NTW = 2, int WR = 1, int RING = 0, int XMAP = 0, int TWO = 0>
+__global__ __launch_bounds__(256, TWO ? 2 : 1) void k_pgemm(GemmP p) {
   constexpr int MTB = 8, ROWS = MTB * 16, PIECES = 3 * 4 * ROWS;   // 1536 16-byte pieces per k tile; NTW weight tiles per wave
   constexpr int MTW = MTB / WR, NWC = 4 / WR;                      // m-tiles per wave, waves across the block's columns
   constexpr int CT = NWC * NTW;                                    // weight tiles per block
   constexpr int SLOT = PIECES + CT * 64;                           // RING: 16-byte pieces per ring slot (operand image, then weight tiles)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* Bs = (uint4*)smem;                              // [2][PIECES], or [RING][SLOT]
-  float* rarr = (float*)(smem + (size_t)(RING ? RING * SLOT : 2 * PIECES) * 16);  // [ROWS]
+  float* rarr = TWO ? (float*)smem : (float*)(smem + (size_t)(RING ? RING * SLOT : 2 * PIECES) * 16);  // [ROWS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int KT = p.KT, M = p.M, NT = p.NT;
   int bx = blockIdx.x, by = blockIdx.y;
@@ -688,7 +692,7 @@ __global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
 #pragma unroll
     for (int b = 0; b < MTW; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if constexpr (RING != 0) {
-    static_assert(RING >= 3 && CT % 4 == 0, "ring form: a wave-instruction moves one weight tile, four per pass of the block");
+    static_assert((TWO ? RING == 2 : RING >= 3) && CT % 4 == 0, "ring form: a wave-instruction moves one weight tile, four per pass of the block");
     constexpr int GA = CT / 4, G = 6 + GA;               // LDS-DMA instructions per thread and k tile
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -712,11 +716,27 @@ __global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
     };
 #pragma unroll
     for (int t = 0; t < RING - 1; ++t) issue(t, t);
-    if (PRO == PRO_NORM) {
-      // a wave's 32 rows, eight at a time with their loads in flight together (one row after the other: 32 dependent L2
-      // round trips, ~50 us in front of the k loop); per row the order of smi_ss_lane_sum + smi_wave_sum
+    // RMSNorm factors of the block's rows.  A wave takes 32 rows with all their loads in flight together (one row after the
+    // other: 32 dependent L2 round trips, ~50 us in front of the k loop); per row the order of smi_ss_lane_sum + smi_wave_sum.
+    auto norm_factors = [&]() {
       const int np = p.npart, last = np - 1;
-      if (np <= 256) {
+      if (np <= 64) {                                     // (the prefill GEMM's own RESID epilogue: one partial per n tile)
+        float a[32];
+        const int i0 = lane < np ? lane : last;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+          int m = m0 + wave * 32 + j;
+          m = m < M ? m : M - 1;
+          a[j] = p.sspart[(size_t)m * np + i0];
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+          float v = 0.f;
+          v += lane < np ? a[j] : 0.f;
+          v = smi_wave_sum(v);
+          if (lane == 0) rarr[wave * 32 + j] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
+        }
+      } else if (np <= 256) {
         int idx[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) idx[q] = lane + 64 * q < np ? lane + 64 * q : last;
@@ -748,7 +768,8 @@ __global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
           if (lane == 0) rarr[r] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
         }
       }
-    }
+    };
+    if (PRO == PRO_NORM && !TWO) norm_factors();
     // Fragment registers of two k tiles: tile kt + 1's are read from LDS while tile kt's feed the MFMAs (every wave of the block
     // reads at the same time -- right behind the barrier -- so without the second set the LDS phase and the MFMA phase of
     // an iteration add up instead of overlapping: measured 2060 cycles per k tile for 768 of MFMAs).
@@ -793,6 +814,20 @@ __global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
       ws = ws + 1 == RING ? 0 : ws + 1; \
     } while (0)
     if (SMI_PG_ABL & 8) { f0 = Frag{}; f1 = Frag{}; }
+    if constexpr (TWO) {
+      // tile kt from slot kt & 1 while tile kt + 1 arrives in the other slot (free: its reads were waited for before the last barrier)
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // tile 0
+      for (int kt = 0; kt < KT; ++kt) {
+        issue(kt + 1, (kt + 1) & 1);
+        fread(f0, kt & 1);
+        fmma(f0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+      if (PRO == PRO_NORM) {                               // the ring is idle now (every request landed, every read done): its memory takes the factors
+        norm_factors();
+        __syncthreads();
+      }
+    } else {
     SMI_PG_SYNC();                                        // tiles 0 and 1 (rarr: the fence below)
     __syncthreads();
     fread(f0, 0);
@@ -802,9 +837,10 @@ __global__ __launch_bounds__(256) void k_pgemm(GemmP p) {
       if (kt + 1 < KT) SMI_PG_STEP(f1, f0, kt + 1);
       else f0 = f1;                                       // (odd KT: the loop ends here; keeps the two paths' live sets alike)
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped extra requests: nothing may still write LDS when the block ends
+    }
 #undef SMI_PG_STEP
 #undef SMI_PG_SYNC
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped extra requests: nothing may still write LDS when the block ends
   } else {
   // The six staged pieces are named registers, not an array: as `uint4 sreg[6]` the compiler left them in scratch
   // memory (ScratchSize 112), which put a wait for the global loads right behind their issue -- in front of the k
@@ -2153,6 +2189,7 @@ struct smi_llm {
   int prefetch;  // same-XCD L2 prefetch by helper blocks (SPARKMI_NO_PREFETCH=1 turns it off)
   int tune2;     // SPARKMI_TUNE2 bit mask (diagnostics)
   int pgemm_min_rows;   // prompt rows from which the prefill GEMM replaces row-grouped decode GEMMs (SPARKMI_PGEMM_MIN_ROWS)
+  int pg_min[4];        // ... per kernel (QKV, o_proj, gate_up, down; SPARKMI_PGEMM_MIN_QKV / _O / _GU / _D override the common value)
   int wd_parts;         // W_down tiles are stored row-part-major (include/sparkmi.h; SPARKMI_WD_PLAIN=1, read by the packer too: plain tile order, for A/B)
   int gu1_rows;         // rows up to which gate_up runs its one-batch, three-tile shape (SPARKMI_GU1_ROWS; default 32)
   hipGraphExec_t graph; int graph_B, graph_seg, graph_ident;
@@ -2505,12 +2542,12 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
 }
 
 // One prefill GEMM over M rows (any M) with k_pgemm; `which` as in launch_one (GEMM kernels only).
-template <int PRO, int EPI, int NTW = 2, int WR = 1, int RING = 0, int XMAP = 0>
+template <int PRO, int EPI, int NTW = 2, int WR = 1, int RING = 0, int XMAP = 0, int TWO = 0>
 int launch_pgemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
   constexpr int cols = (4 / WR) * NTW;   // weight tiles per block
   const dim3 grid2((p.NT + cols - 1) / cols, (p.M + 127) / 128);
   const dim3 grid = XMAP ? dim3(grid2.x * grid2.y) : grid2;
-  const size_t lds = (RING ? (size_t)RING * (1536 + cols * 64) : (size_t)2 * 1536) * 16 + 128 * 4;
+  const size_t lds = (RING ? (size_t)RING * (1536 + cols * 64) : (size_t)2 * 1536) * 16 + (TWO ? 0 : 128 * 4);
   if (lds > 64 * 1024) {   // opt in once per instantiation and device (as in launch_gemm_kv)
     static std::mutex mu;
     static bool done[64] = {};
@@ -2518,13 +2555,13 @@ int launch_pgemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
     SMI_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
     if (dev >= 0 && dev < 64 && !done[dev]) {
-      SMI_HIP(hipFuncSetAttribute((const void*)k_pgemm<PRO, EPI, 1, NTW, WR, RING, XMAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      SMI_HIP(hipFuncSetAttribute((const void*)k_pgemm<PRO, EPI, 0, NTW, WR, RING, XMAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      SMI_HIP(hipFuncSetAttribute((const void*)k_pgemm<PRO, EPI, 1, NTW, WR, RING, XMAP, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      SMI_HIP(hipFuncSetAttribute((const void*)k_pgemm<PRO, EPI, 0, NTW, WR, RING, XMAP, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       done[dev] = true;
     }
   }
-  if (L->cfg.kv_dtype) hipLaunchKernelGGL((k_pgemm<PRO, EPI, 1, NTW, WR, RING, XMAP>), grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((k_pgemm<PRO, EPI, 0, NTW, WR, RING, XMAP>), grid, dim3(256), lds, st, p);
+  if (L->cfg.kv_dtype) hipLaunchKernelGGL((k_pgemm<PRO, EPI, 1, NTW, WR, RING, XMAP, TWO>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((k_pgemm<PRO, EPI, 0, NTW, WR, RING, XMAP, TWO>), grid, dim3(256), lds, st, p);
   SMI_LAUNCH_CHECK();
   return SMI_OK;
 }
@@ -2535,19 +2572,21 @@ int launch_pgemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
 // chunks, one launch instead of M / 32); beyond, the LDS-shared prefill GEMM (k_pgemm) takes over.
 int launch_layers_big(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
   const smi_llm_cfg& c = L->cfg;
-  const bool grouped = M < L->pgemm_min_rows;
-  const int npart = grouped ? L->NTh * 4 : L->NTh;
+  // per kernel: row-grouped decode GEMM or the prefill GEMM.  The RESID kernels leave the RMSNorm partials as [rows][NT * 4]
+  // (grouped) or [rows][NT] (prefill GEMM); their consumers are told which.
+  const bool gq = M < L->pg_min[0], go = M < L->pg_min[1], gg = M < L->pg_min[2], gd = M < L->pg_min[3];
+  const int np_from_d = gd ? L->NTh * 4 : L->NTh, np_from_o = go ? L->NTh * 4 : L->NTh;
   int rc;
   for (int l = 0; l < c.num_layers; ++l) {
     GemmP p;
     memset(&p, 0, sizeof(p));
-    p.M = M; p.rows = rows; p.eps = c.rms_eps; p.sspart = L->bss; p.npart = npart;
+    p.M = M; p.rows = rows; p.eps = c.rms_eps; p.sspart = L->bss; p.npart = np_from_d;
     // QKV
     p.W = (const uint4*)sec(L, SMI_LLM_WQKV, l); p.NT = L->NTqkv; p.KT = L->KTh; p.XS = L->bxs_h;
     p.Y = L->bq; p.bias = (const float*)sec(L, SMI_LLM_BQKV, l); p.rope = (const float2*)sec(L, SMI_LLM_ROPE, 0);
     p.kcache = kv_layer(L, L->kcache, l); p.vcache = kv_layer(L, L->vcache, l);
     p.q_dim = L->Q; p.kv_dim = L->KV; p.n_kv = c.num_kv_heads; p.max_pos = c.max_positions; p.km = kv_map(L);
-    if ((rc = grouped ? launch_gemm<1, 16, 2, 1, PRO_NORM, EPI_QKV>(L, p, st) : ((L->tune2 & 16384) ? launch_pgemm<PRO_NORM, EPI_QKV>(L, p, st) : launch_pgemm<PRO_NORM, EPI_QKV, 6, 2, 3, 1>(L, p, st)))) return rc;
+    if ((rc = gq ? launch_gemm<1, 16, 2, 1, PRO_NORM, EPI_QKV>(L, p, st) : ((L->tune2 & 16384) ? launch_pgemm<PRO_NORM, EPI_QKV>(L, p, st) : launch_pgemm<PRO_NORM, EPI_QKV, 6, 2, 3, 1>(L, p, st)))) return rc;
     if (l == c.num_layers - 1) break;
     // attention
     AttnP a;
@@ -2566,23 +2605,23 @@ int launch_layers_big(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
     // o_proj
     GemmP o;
     memset(&o, 0, sizeof(o));
-    o.M = M; o.rows = rows; o.eps = c.rms_eps; o.sspart = L->bss; o.npart = npart;
+    o.M = M; o.rows = rows; o.eps = c.rms_eps; o.sspart = L->bss; o.npart = np_from_d;
     o.W = (const uint4*)sec(L, SMI_LLM_WO, l); o.NT = L->NTh; o.KT = L->KTq; o.XS = L->bxs_attn; o.Y = L->bh;
     o.XSout = L->bxs_h; o.gamma_next = (const float*)sec(L, SMI_LLM_LN2, l); o.ssout = L->bss;
-    if ((rc = grouped ? launch_oproj(L, o, M, st) : ((L->tune2 & 16384) ? launch_pgemm<PRO_PLAIN, EPI_RESID>(L, o, st) : launch_pgemm<PRO_PLAIN, EPI_RESID, 4, 2, 4, 1>(L, o, st)))) return rc;
+    if ((rc = go ? launch_oproj(L, o, M, st) : ((L->tune2 & 16384) ? launch_pgemm<PRO_PLAIN, EPI_RESID>(L, o, st) : launch_pgemm<PRO_PLAIN, EPI_RESID, 4, 2, 4, 1>(L, o, st)))) return rc;
     // gate_up
     GemmP g;
     memset(&g, 0, sizeof(g));
-    g.M = M; g.rows = rows; g.eps = c.rms_eps; g.sspart = L->bss; g.npart = npart;
+    g.M = M; g.rows = rows; g.eps = c.rms_eps; g.sspart = L->bss; g.npart = np_from_o;
     g.W = (const uint4*)sec(L, SMI_LLM_WGU, l); g.NT = L->NTgu; g.KT = L->KTh; g.XS = L->bxs_h; g.XSout = L->bxs_act;
-    if ((rc = grouped ? launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_SWIGLU, 1, 2>(L, g, st) : ((L->tune2 & 512) ? launch_pgemm<PRO_NORM, EPI_SWIGLU>(L, g, st) : (L->tune2 & 16384) ? launch_pgemm<PRO_NORM, EPI_SWIGLU, 4>(L, g, st) : (L->tune2 & 32768) ? launch_pgemm<PRO_NORM, EPI_SWIGLU, 8, 2, 3, 1>(L, g, st) : launch_pgemm<PRO_NORM, EPI_SWIGLU, 8, 2, 3>(L, g, st)))) return rc;
+    if ((rc = gg ? launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_SWIGLU, 1, 2>(L, g, st) : ((L->tune2 & 512) ? launch_pgemm<PRO_NORM, EPI_SWIGLU>(L, g, st) : (L->tune2 & 16384) ? launch_pgemm<PRO_NORM, EPI_SWIGLU, 4>(L, g, st) : (L->tune2 & 32768) ? launch_pgemm<PRO_NORM, EPI_SWIGLU, 8, 2, 3>(L, g, st) : launch_pgemm<PRO_NORM, EPI_SWIGLU, 8, 2, 2, 0, 1>(L, g, st)))) return rc;
     // down
     GemmP d;
     memset(&d, 0, sizeof(d));
-    d.M = M; d.rows = rows; d.eps = c.rms_eps; d.sspart = L->bss; d.npart = npart;
+    d.M = M; d.rows = rows; d.eps = c.rms_eps; d.sspart = L->bss; d.npart = np_from_o;
     d.W = (const uint4*)sec(L, SMI_LLM_WD, l); d.NT = L->NTh; d.KT = L->KTi; d.XS = L->bxs_act; d.Y = L->bh; d.wperm = L->wd_parts;
     d.XSout = L->bxs_h; d.ssout = L->bss; d.gamma_next = (const float*)sec(L, SMI_LLM_LN1, l + 1);
-    if ((rc = grouped ? launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID>(L, d, st) : ((L->tune2 & 16384) ? launch_pgemm<PRO_PLAIN, EPI_RESID>(L, d, st) : launch_pgemm<PRO_PLAIN, EPI_RESID, 4, 2, 4, 1>(L, d, st)))) return rc;
+    if ((rc = gd ? launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID>(L, d, st) : ((L->tune2 & 16384) ? launch_pgemm<PRO_PLAIN, EPI_RESID>(L, d, st) : launch_pgemm<PRO_PLAIN, EPI_RESID, 4, 2, 4, 1>(L, d, st)))) return rc;
   }
   return SMI_OK;
 }
@@ -2694,7 +2733,15 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->fuse_o = !getenv("SPARKMI_NO_FUSE_O") && (cfg->num_heads == 14 || cfg->num_heads == 4) && cfg->num_heads <= kMaxOHeads &&
               L->NTh % kFuseQB == 0 && L->NTh / kFuseQB <= kAttnWaves * kFuseOT && L->KTh * 8 <= 256;
   { const char* e = getenv("SPARKMI_TUNE2"); L->tune2 = e ? atoi(e) : 0; }
-  { const char* e = getenv("SPARKMI_PGEMM_MIN_ROWS"); L->pgemm_min_rows = e ? atoi(e) : 3072; }
+  { const char* e = getenv("SPARKMI_PGEMM_MIN_ROWS"); L->pgemm_min_rows = e ? atoi(e) : 1280; }
+  {
+    const char* names[4] = {"SPARKMI_PGEMM_MIN_QKV", "SPARKMI_PGEMM_MIN_O", "SPARKMI_PGEMM_MIN_GU", "SPARKMI_PGEMM_MIN_D"};
+    // measured crossovers (tools/prefill_time.py mix / mix2, profiles/README.md): gate_up from ~300 rows (its grouped form re-reads
+    // the operand triples once per 32 columns), down_proj from ~900, the two short-K GEMMs from ~1300
+    const int dflt[4] = {1280, 1280, 288, 896};
+    const bool common = getenv("SPARKMI_PGEMM_MIN_ROWS") != nullptr;
+    for (int i = 0; i < 4; ++i) { const char* e = getenv(names[i]); L->pg_min[i] = e ? atoi(e) : common ? L->pgemm_min_rows : dflt[i]; }
+  }
   { const char* e = getenv("SPARKMI_GU1_ROWS"); L->gu1_rows = e ? atoi(e) : 32; }
   { const char* e = getenv("SPARKMI_WD_PLAIN"); L->wd_parts = !(e && e[0] && e[0] != '0'); }
   L->graph = nullptr; L->graph_B = 0; L->graph_seg = 1; L->graph_ident = 1; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->ctl = nullptr; L->admit_seq = 0; memset(&L->hctl, 0, sizeof(L->hctl));
@@ -2847,7 +2894,7 @@ static int prefill_prompts(smi_llm* L, const int64_t* ids, const int32_t* lens, 
       const int M = (int)((total - r0) < kBigRows ? (total - r0) : kBigRows);
       const RowDesc* rows = L->plan + r0;
       hipLaunchKernelGGL(k_embed, dim3((M + 3) / 4), dim3(256), 0, st, (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0), L->KTh, rows, M,
-                         (const float*)sec(L, SMI_LLM_LN1, 0), L->bh, L->bxs_h, L->bss, M < L->pgemm_min_rows ? L->NTh * 4 : L->NTh);
+                         (const float*)sec(L, SMI_LLM_LN1, 0), L->bh, L->bxs_h, L->bss, M < L->pg_min[3] ? L->NTh * 4 : L->NTh);
       SMI_LAUNCH_CHECK();
       if ((rc = launch_layers_big(L, rows, M, st))) return rc;
     }

@@ -203,23 +203,34 @@ def test_full_size_batch_is_bit_identical_to_single_runs(full_llm):
 
 
 def test_prefill_paths_agree(tiny, monkeypatch):
-    """More than 32 prompt rows run as row-grouped decode GEMMs (one launch per layer kernel), from
-    SPARKMI_PGEMM_MIN_ROWS rows on through the prefill GEMM (k_pgemm); both must give the tokens of
-    the 32-row-chunk path and of the oracle."""
+    """More than 32 prompt rows run as row-grouped decode GEMMs (one launch per layer kernel) or through the prefill GEMM
+    (k_pgemm), chosen per kernel by row count (SPARKMI_PGEMM_MIN_ROWS / _QKV / _O / _GU / _D); every mix -- the RESID kernels
+    leave their RMSNorm partials in different layouts for the next kernel -- must give the tokens of the 32-row-chunk path and
+    of the oracle."""
     cfg, syn = tiny
     rng = np.random.Generator(np.random.PCG64(314))
     B = 12
     prompts = [rng.integers(0, cfg.vocab_size, size=int(rng.integers(30, 60))).tolist() for _ in range(B)]
     assert sum(len(p) - 1 for p in prompts) >= 384
-    grouped = _llm(cfg, syn, max_slots=B, max_positions=96).generate_ids(prompts, 16)
-    monkeypatch.setenv("SPARKMI_PGEMM_MIN_ROWS", "0")
-    pgemm = _llm(cfg, syn, max_slots=B, max_positions=96).generate_ids(prompts, 16)
-    monkeypatch.delenv("SPARKMI_PGEMM_MIN_ROWS")
-    monkeypatch.setenv("SPARKMI_PREFILL_CHUNKS", "1")
-    chunked = _llm(cfg, syn, max_slots=B, max_positions=96).generate_ids(prompts, 16)
-    assert grouped == chunked and pgemm == chunked
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = _llm(cfg, syn, max_slots=B, max_positions=96).generate_ids(prompts, 16)
+        for k in env:
+            monkeypatch.delenv(k)
+        return out
+
+    chunked = run({"SPARKMI_PREFILL_CHUNKS": "1"})
+    assert run({"SPARKMI_PGEMM_MIN_ROWS": "100000"}) == chunked          # row-grouped decode GEMMs only
+    assert run({"SPARKMI_PGEMM_MIN_ROWS": "0"}) == chunked               # the prefill GEMM only
+    assert run({"SPARKMI_PGEMM_MIN_ROWS": "0", "SPARKMI_TUNE2": "16384"}) == chunked   # ... in its register-staged form
+    assert run({}) == chunked                                            # the default mix at this row count
+    for one in ("QKV", "O", "GU", "D"):
+        assert run({"SPARKMI_PGEMM_MIN_ROWS": "100000", "SPARKMI_PGEMM_MIN_" + one: "0"}) == chunked, one
+        assert run({"SPARKMI_PGEMM_MIN_ROWS": "0", "SPARKMI_PGEMM_MIN_" + one: "100000"}) == chunked, one
     for b in (0, 5, 11):
-        assert Qwen2Ref(cfg, syn, kv_dtype="bf16").generate_greedy(prompts[b], 16) == grouped[b]
+        assert Qwen2Ref(cfg, syn, kv_dtype="bf16").generate_greedy(prompts[b], 16) == chunked[b]
 
 
 def test_continuous_batching_equals_standalone_runs(tiny):

@@ -30,6 +30,15 @@ modes = (("grouped", {"SPARKMI_PGEMM_MIN_ROWS": "100000"}), ("pgemm", {"SPARKMI_
 if len(sys.argv) > 1 and sys.argv[1] == "pg2":   # k_pgemm with the 2 x 2 wave grid vs the 1 x 4 one (SPARKMI_TUNE2 bit 16384), forced at every size
     os.environ.setdefault("PF_SIZES", "1x128,1x460,4x128,8x460,32x128")
     modes = (("pgemm 2x2", {"SPARKMI_PGEMM_MIN_ROWS": "0"}), ("pgemm 1x4", {"SPARKMI_PGEMM_MIN_ROWS": "0", "SPARKMI_TUNE2": "16384"}), ("default", {}))
+if len(sys.argv) > 1 and sys.argv[1] == "mix":   # which GEMMs go through the prefill GEMM at mid-size prompts
+    os.environ.setdefault("PF_SIZES", "1x128,1x460,4x128,8x128")
+    modes = (("default", {}), ("gate_up", {"SPARKMI_PGEMM_MIN_GU": "0"}), ("gate_up+qkv", {"SPARKMI_PGEMM_MIN_GU": "0", "SPARKMI_PGEMM_MIN_QKV": "0"}),
+             ("gate_up+down", {"SPARKMI_PGEMM_MIN_GU": "0", "SPARKMI_PGEMM_MIN_D": "0"}), ("all", {"SPARKMI_PGEMM_MIN_ROWS": "0"}))
+if len(sys.argv) > 1 and sys.argv[1] == "mix2":
+    os.environ.setdefault("PF_SIZES", "2x128,12x128,16x128,24x128")
+    gd = {"SPARKMI_PGEMM_MIN_GU": "0", "SPARKMI_PGEMM_MIN_D": "0"}
+    modes = (("gate_up", {"SPARKMI_PGEMM_MIN_GU": "0"}), ("gate_up+down", gd), ("gate_up+down+o", dict(gd, SPARKMI_PGEMM_MIN_O="0")),
+             ("gate_up+down+qkv", dict(gd, SPARKMI_PGEMM_MIN_QKV="0")), ("all", {"SPARKMI_PGEMM_MIN_ROWS": "0"}))
 if len(sys.argv) > 1 and sys.argv[1] == "gu1":   # gate_up's one-batch shape beyond 32 rows (row-grouped prefill)
     modes = tuple((f"grouped gu1<={r}", {"SPARKMI_PGEMM_MIN_ROWS": "100000", "SPARKMI_GU1_ROWS": str(r)}) for r in (32, 128, 100000))
 for mode, env in modes:
