@@ -493,6 +493,7 @@ struct smi_enc {
     unsigned long long used = 0;
   };
   std::map<std::pair<int, int>, Graph> graphs;
+  std::map<std::pair<int, int>, int> seen;   // a shape is captured at its second occurrence: traffic whose shapes never repeat runs eagerly
   std::pair<int, int> prog_key{-1, -1};
   unsigned long long tick = 0;
   bool use_graph = true;
@@ -960,7 +961,13 @@ int smi_enc_forward(smi_enc* h, const float* wav_dev, int n_samples, const float
               c.max_ref_samples);
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (!h->use_graph) {
+  const std::pair<int, int> key(n_samples, n_ref);
+  bool eager = !h->use_graph;
+  if (!eager && h->graphs.find(key) == h->graphs.end()) {
+    if (h->seen.size() > 4096) h->seen.clear();
+    eager = h->seen[key]++ == 0;
+  }
+  if (eager) {
     if ((rc = enc_build(h, wav_dev, n_samples, ref_dev, n_ref, sem_dev, glob_dev, n_frames))) return rc;
     h->prog_key = {-1, -1};
     SMI_HIP(hipMemcpyAsync(h->lens_dev, h->host_lens.data(), h->host_lens.size() * 4, hipMemcpyHostToDevice, st));
@@ -971,7 +978,6 @@ int smi_enc_forward(smi_enc* h, const float* wav_dev, int n_samples, const float
   float *in_wav = h->buf.at("in_wav"), *in_ref = h->buf.at("in_ref");
   int64_t* out_sem = (int64_t*)h->buf.at("out_sem");
   int32_t* out_glob = (int32_t*)h->buf.at("out_glob");
-  const std::pair<int, int> key(n_samples, n_ref);
   // the null stream cannot be captured: such callers' encodes run on the handle's own stream, fenced by events on both sides
   hipStream_t run = st ? st : h->gstream;
   if (!st) {

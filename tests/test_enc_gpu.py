@@ -136,3 +136,26 @@ def test_tokenize_many_on_parallel_streams_equals_one_by_one(tiny):
         torch.cuda.synchronize()
         for (g1, s1), (g2, s2) in zip(one, many):
             assert torch.equal(g1, g2) and torch.equal(s1, s2)
+
+
+def test_graph_replay_equals_eager_launches(tiny, monkeypatch):
+    """A (n_samples, n_ref) shape seen twice is captured and replayed as one hipGraph (prompt copied into / ids copied out of
+    handle-owned buffers): other prompts of that shape, and the debug views, must equal the eager launches'."""
+    enc, wcfg, tcfg, _, _ = tiny
+    rng = np.random.default_rng(21)
+    n = 16000 + 321
+    wavs = [(0.15 * rng.standard_normal(n)).astype(np.float32) for _ in range(4)]
+    refs = [get_ref_clip(w.astype(np.float64), 16000, 1.0, tcfg.hop_length).astype(np.float32) for w in wavs]
+    got = [enc.tokenize_arrays(w, r) for w, r in zip(wavs, refs)]             # eager, capture + replay, replay, replay
+    feat_last = enc.debug_stage("feat").cpu().numpy()
+    short = enc.tokenize_arrays(wavs[0][:9000], refs[0])                      # another shape in between
+    again = enc.tokenize_arrays(wavs[1], refs[1])
+    monkeypatch.setenv("SPARKMI_ENC_GRAPH", "0")
+    eager, _, _ = _build(wcfg, tcfg, C.tiny_bicodec(), max_seconds=3.0, ref_seconds=1.0)
+    for (g, s_), w, r in zip(got, wavs, refs):
+        ge, se = eager.tokenize_arrays(w, r)
+        assert torch.equal(g, ge) and torch.equal(s_, se)
+    assert np.array_equal(eager.debug_stage("feat").cpu().numpy(), feat_last)
+    ge, se = eager.tokenize_arrays(wavs[0][:9000], refs[0])
+    assert torch.equal(short[0], ge) and torch.equal(short[1], se)
+    assert torch.equal(again[0], got[1][0]) and torch.equal(again[1], got[1][1])
