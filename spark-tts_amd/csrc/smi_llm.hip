@@ -1679,6 +1679,146 @@ __global__ __launch_bounds__(kAttnWaves * 64) void k_attn_pf(AttnP p) {
   *(uint16_t*)(p.xs_out + ob + 2 * pl2) = (uint16_t)lo;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Prefill attention on the matrix pipes (bf16 KV cache): one wave per (tile of up to 16 consecutive rows of one prompt,
+// head).  k_attn_pf gives every (row, head) its own wave, which re-reads the head's K/V for every row (8 x 460-token prompts:
+// 3 GB of L2 traffic and 210 us per layer, the largest prefill kernel there); here the 16 queries of a tile share each K/V load.
+//   scores, transposed: S^T[key][query] = K (A operand: a key's 8 consecutive dims per lane, straight from the cache row) x
+//     q^T (B operand: the query's dims, fp32 -> exact bf16 triple, three MFMAs lo/mid/hi) -- v_mfma_f32_16x16x32_bf16;
+//   its accumulator layout (lane (g, query): keys 4g .. 4g+3) IS the A operand layout of v_mfma_f32_16x16x4_f32 over those
+//     keys, so P = exp2((S - max) log2 e) feeds P x V in fp32 with no shuffle; V rows are read as they lie (lane (g, n): dims
+//     4n .. 4n+3 of key 4g + t), output column n of tile d standing for dim 4n + d.
+// Two passes over the keys (row maxima, then P and P x V: the scores are recomputed bit for bit), so no running rescale;
+// causal mask key <= query position; per query the sum of P and the division happen once at the end.
+// ------------------------------------------------------------------------------------------
+struct PfTile { int32_t m0, n, slot, pos0; };   // rows m0 .. m0+n-1 are tokens pos0 .. pos0+n-1 of KV slot `slot`
+
+__global__ __launch_bounds__(256) void k_attn_pf2(AttnP p, const PfTile* tiles, int ntiles) {
+  constexpr float NEG = -1e30f;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int task = (int)blockIdx.x * 4 + wave;
+  const int ti = task / p.n_heads, head = task - ti * p.n_heads;
+  if (ti >= ntiles) return;   // wave-uniform; the kernel has no barrier
+  const PfTile t = tiles[ti];
+  const int g = lane >> 4, j = lane & 15;
+  const int kvh = head / p.group;
+  const uint16_t* Kc = (const uint16_t*)p.kcache;
+  const uint16_t* Vc = (const uint16_t*)p.vcache;
+  // q^T operand: query j's dims s*32 + g*8 .. +8, scaled by head_dim^-0.5 (exact), as bf16 triples
+  bf16x8 qh[2], qm[2], ql[2];
+  {
+    const float* qp = p.q + (size_t)(t.m0 + (j < t.n ? j : t.n - 1)) * p.q_dim + head * kHeadDim + g * 8;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const float4 a = *(const float4*)(qp + s2 * 32), b = *(const float4*)(qp + s2 * 32 + 4);
+      const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      uint32_t hi[8], mi[8], lo[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) split3(v[e] * 0.125f, hi[e], mi[e], lo[e]);
+      const uint4 H = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+      const uint4 Mi = make_uint4(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16), mi[4] | (mi[5] << 16), mi[6] | (mi[7] << 16));
+      const uint4 Lo = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+      qh[s2] = __builtin_bit_cast(bf16x8, H); qm[s2] = __builtin_bit_cast(bf16x8, Mi); ql[s2] = __builtin_bit_cast(bf16x8, Lo);
+    }
+  }
+  const int nkeys = t.pos0 + t.n;                 // keys 0 .. nkeys-1; query j sees keys <= pos0 + j
+  const int nblk = (nkeys + 15) >> 4;
+  const int qlast = t.pos0 + j;
+  struct KReg { uint4 a, b; };
+  auto kload = [&](int kb) -> KReg {              // A operand of block kb: this lane holds key kb*16 + j's dims g*8 .. +8 of both halves
+    int key = kb * 16 + j;
+    key = key < nkeys ? key : nkeys - 1;
+    const uint16_t* kp = Kc + kv_row(p.km, t.slot, kvh, p.n_kv, p.max_pos, key) * kHeadDim + g * 8;
+    return KReg{*(const uint4*)kp, *(const uint4*)(kp + 32)};
+  };
+  auto scores = [&](int kb, const KReg& kr) -> f32x4 {   // S^T block: lane (g, query j), register r: key kb*16 + 4g + r
+    const bf16x8 k0 = __builtin_bit_cast(bf16x8, kr.a), k1 = __builtin_bit_cast(bf16x8, kr.b);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, ql[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, ql[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qm[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qm[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qh[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qh[1], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = (kb * 16 + 4 * g + r <= qlast) ? acc[r] : NEG;
+    return acc;
+  };
+  // ---- pass 1: the queries' maxima (the next block's K rows are requested before this block's MFMAs)
+  float mx = NEG;
+  {
+    KReg kc = kload(0);
+    for (int kb = 0; kb < nblk; ++kb) {
+      const KReg kn = kload(kb + 1 < nblk ? kb + 1 : kb);
+      const f32x4 sc = scores(kb, kc);
+      mx = fmaxf(mx, fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
+      kc = kn;
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  // ---- pass 2: P and P x V
+  f32x4 o[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float lsum = 0.f;
+  struct VReg { uint2 v[4]; };
+  auto vload = [&](int kb) -> VReg {
+    VReg r;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      int key = kb * 16 + 4 * g + tt;
+      key = key < nkeys ? key : nkeys - 1;
+      r.v[tt] = *(const uint2*)(Vc + kv_row(p.km, t.slot, kvh, p.n_kv, p.max_pos, key) * kHeadDim + 4 * j);
+    }
+    return r;
+  };
+  KReg kc = kload(0);
+  VReg vc = vload(0);
+  for (int kb = 0; kb < nblk; ++kb) {
+    const int kbn = kb + 1 < nblk ? kb + 1 : kb;
+    const KReg kn = kload(kbn);
+    const VReg vn = vload(kbn);
+    const uint2* vraw = vc.v;
+    const f32x4 sc = scores(kb, kc);
+    float pr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pr[r] = sc[r] > 0.5f * NEG ? exp2f((sc[r] - mx) * LOG2E) : 0.f;
+      lsum += pr[r];
+    }
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const float v0 = __uint_as_float(vraw[tt].x << 16), v1 = __uint_as_float(vraw[tt].x & 0xffff0000u);
+      const float v2 = __uint_as_float(vraw[tt].y << 16), v3 = __uint_as_float(vraw[tt].y & 0xffff0000u);
+      o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[tt], v0, o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[tt], v1, o[1], 0, 0, 0);
+      o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[tt], v2, o[2], 0, 0, 0);
+      o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[tt], v3, o[3], 0, 0, 0);
+    }
+    kc = kn; vc = vn;
+  }
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);               // lane (any g, j): the sum for query j
+  // ---- output: lane (g, n) holds O[query 4g + r][dims 4n .. 4n+3] in o[0..3][r]
+  const size_t pl2 = (size_t)4 * p.M * 16;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qi = 4 * g + r;
+    const float ls = __shfl(lsum, qi, 64);
+    if (qi >= t.n) continue;
+    uint32_t hi[4], mi[4], lo[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) split3(o[d][r] / ls, hi[d], mi[d], lo[d]);
+    const size_t ob = xs_off(o_ktile(head, 4 * j, p.n_heads), 0, (j >> 1) & 3, t.m0 + qi, p.M) + (j & 1) * 8;
+    *(uint2*)(p.xs_out + ob) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+    *(uint2*)(p.xs_out + ob + pl2) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
+    *(uint2*)(p.xs_out + ob + 2 * pl2) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+  }
+}
+
 // Combines a row's context segments in order (a row with one segment reproduces the unsplit result bit for bit:
 // its scale factor is exp2(0) = 1).  One block per row, one thread per (head, dim).
 __global__ __launch_bounds__(1024) void k_attn_merge(AttnP p) {
@@ -2159,6 +2299,11 @@ struct smi_llm {
   int fuse_o;          // config allows the fused o_proj (SPARKMI_NO_FUSE_O=1 turns it off)
   RowDesc* rows;       // live decode rows [kMaxRows]
   RowDesc* plan;       // prefill plan
+  PfTile* pf_tiles;     // prefill attention tiles of the row group in flight (k_attn_pf2)
+  size_t pf_tiles_cap;
+  int pf_ntiles;
+  std::vector<PfTile> host_tiles;
+  int attn_pf2;         // bf16 KV: prefill attention on the matrix pipes (SPARKMI_ATTN_PF2=0: one wave per (row, head))
   size_t plan_cap;     // rows
   float* pval; int* pidx; int lm_blocks, lm_cap;
   int64_t* hist; int32_t *count, *finished, *step;
@@ -2598,7 +2743,10 @@ int launch_layers_big(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
       if ((rc = c.kv_dtype ? launch_attn<1>(L, a, 0, st) : launch_attn<0>(L, a, 0, st))) return rc;
     } else {
       const dim3 ag((unsigned)((M + kAttnWaves - 1) / kAttnWaves), (unsigned)c.num_heads);
-      if (c.kv_dtype) hipLaunchKernelGGL((k_attn_pf<1>), ag, dim3(kAttnWaves * 64), 0, st, a);
+      if (!c.kv_dtype && L->attn_pf2 && L->pf_ntiles > 0 && c.head_dim == 64) {   // bf16 KV: tiles of 16 rows on the matrix pipes
+        const int tasks = L->pf_ntiles * c.num_heads;
+        hipLaunchKernelGGL(k_attn_pf2, dim3((tasks + 3) / 4), dim3(256), 0, st, a, (const PfTile*)L->pf_tiles, L->pf_ntiles);
+      } else if (c.kv_dtype) hipLaunchKernelGGL((k_attn_pf<1>), ag, dim3(kAttnWaves * 64), 0, st, a);
       else hipLaunchKernelGGL((k_attn_pf<0>), ag, dim3(kAttnWaves * 64), 0, st, a);
       SMI_LAUNCH_CHECK();
     }
@@ -2744,6 +2892,8 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   }
   { const char* e = getenv("SPARKMI_GU1_ROWS"); L->gu1_rows = e ? atoi(e) : 32; }
   { const char* e = getenv("SPARKMI_WD_PLAIN"); L->wd_parts = !(e && e[0] && e[0] != '0'); }
+  L->pf_tiles = nullptr; L->pf_tiles_cap = 0; L->pf_ntiles = 0;
+  { const char* e = getenv("SPARKMI_ATTN_PF2"); L->attn_pf2 = !(e && e[0] == '0'); }
   L->graph = nullptr; L->graph_B = 0; L->graph_seg = 1; L->graph_ident = 1; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->ctl = nullptr; L->admit_seq = 0; memset(&L->hctl, 0, sizeof(L->hctl));
   L->session = 0; L->identity_slots = 1; L->attn_seg = 1; L->apart = nullptr; L->apart_floats = 0; memset(L->slot_busy, 0, sizeof(L->slot_busy)); memset(L->slot_len, 0, sizeof(L->slot_len));
   const size_t esz = cfg->kv_dtype ? 4 : 2;
@@ -2824,7 +2974,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
 int smi_llm_destroy(smi_llm* L) {
   if (!L) return SMI_OK;
   if (L->graph) (void)hipGraphExecDestroy(L->graph);
-  void* ptrs[] = {L->h, L->qbuf, L->xs_h, L->xs_attn, L->xs_act, L->sspart, L->part_o, L->h2, L->rows, L->plan, L->pval, L->pidx, L->hist,
+  void* ptrs[] = {L->h, L->qbuf, L->xs_h, L->xs_attn, L->xs_act, L->sspart, L->part_o, L->h2, L->rows, L->plan, L->pf_tiles, L->pval, L->pidx, L->hist,
                   L->count, L->finished, L->step, L->ctl, L->ptab, L->kcache, L->vcache, L->logits, L->tok, L->cand_v, L->cand_i, L->cand_n, L->stamps, L->bh, L->bq, L->bxs_h, L->bxs_attn, L->bxs_act, L->bss, L->apart};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
@@ -2893,6 +3043,29 @@ static int prefill_prompts(smi_llm* L, const int64_t* ids, const int32_t* lens, 
     for (size_t r0 = 0; r0 < total; r0 += kBigRows) {
       const int M = (int)((total - r0) < kBigRows ? (total - r0) : kBigRows);
       const RowDesc* rows = L->plan + r0;
+      // prefill attention tiles of this row group: runs of up to 16 rows that are consecutive tokens of one KV slot
+      L->pf_ntiles = 0;
+      if (!L->cfg.kv_dtype && L->attn_pf2) {
+        std::vector<PfTile>& T = L->host_tiles;
+        T.clear();
+        for (int i = 0; i < M;) {
+          const RowDesc& a0 = L->host_rows[r0 + i];
+          int n = 1;
+          while (n < 16 && i + n < M && L->host_rows[r0 + i + n].slot == a0.slot && L->host_rows[r0 + i + n].pos == a0.pos + n) ++n;
+          T.push_back(PfTile{i, n, a0.slot, a0.pos});
+          i += n;
+        }
+        if (T.size() > L->pf_tiles_cap) {
+          if (L->pf_tiles) (void)hipFree(L->pf_tiles);
+          L->pf_tiles = nullptr; L->pf_tiles_cap = 0;
+          const size_t cap = T.size() + 256;
+          if (hipMalloc((void**)&L->pf_tiles, cap * sizeof(PfTile)) != hipSuccess) { smi_set_error("hipMalloc(prefill attention tiles) failed"); return SMI_ENOMEM; }
+          L->pf_tiles_cap = cap;
+        }
+        // (pageable source: staged before the call returns; host_tiles is rebuilt only by the next group, behind this copy)
+        SMI_HIP(hipMemcpyAsync(L->pf_tiles, T.data(), T.size() * sizeof(PfTile), hipMemcpyHostToDevice, st));
+        L->pf_ntiles = (int)T.size();
+      }
       hipLaunchKernelGGL(k_embed, dim3((M + 3) / 4), dim3(256), 0, st, (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0), L->KTh, rows, M,
                          (const float*)sec(L, SMI_LLM_LN1, 0), L->bh, L->bxs_h, L->bss, M < L->pg_min[3] ? L->NTh * 4 : L->NTh);
       SMI_LAUNCH_CHECK();

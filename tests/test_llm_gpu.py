@@ -226,6 +226,7 @@ def test_prefill_paths_agree(tiny, monkeypatch):
     assert run({"SPARKMI_PGEMM_MIN_ROWS": "0"}) == chunked               # the prefill GEMM only
     assert run({"SPARKMI_PGEMM_MIN_ROWS": "0", "SPARKMI_TUNE2": "16384"}) == chunked   # ... in its register-staged form
     assert run({}) == chunked                                            # the default mix at this row count
+    assert run({"SPARKMI_ATTN_PF2": "0"}) == chunked                     # prefill attention per (row, head) instead of 16-row MFMA tiles
     for one in ("QKV", "O", "GU", "D"):
         assert run({"SPARKMI_PGEMM_MIN_ROWS": "100000", "SPARKMI_PGEMM_MIN_" + one: "0"}) == chunked, one
         assert run({"SPARKMI_PGEMM_MIN_ROWS": "0", "SPARKMI_PGEMM_MIN_" + one: "100000"}) == chunked, one

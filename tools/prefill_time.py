@@ -39,6 +39,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "mix2":
     gd = {"SPARKMI_PGEMM_MIN_GU": "0", "SPARKMI_PGEMM_MIN_D": "0"}
     modes = (("gate_up", {"SPARKMI_PGEMM_MIN_GU": "0"}), ("gate_up+down", gd), ("gate_up+down+o", dict(gd, SPARKMI_PGEMM_MIN_O="0")),
              ("gate_up+down+qkv", dict(gd, SPARKMI_PGEMM_MIN_QKV="0")), ("all", {"SPARKMI_PGEMM_MIN_ROWS": "0"}))
+if len(sys.argv) > 1 and sys.argv[1] == "pf2":   # prefill attention: 16-row tiles on the matrix pipes vs one wave per (row, head)
+    os.environ.setdefault("PF_SIZES", "1x128,1x460,8x460,32x128,1x1000")
+    modes = (("attn tiles (k_attn_pf2)", {}), ("attn per row (k_attn_pf)", {"SPARKMI_ATTN_PF2": "0"}))
 if len(sys.argv) > 1 and sys.argv[1] == "gu1":   # gate_up's one-batch shape beyond 32 rows (row-grouped prefill)
     modes = tuple((f"grouped gu1<={r}", {"SPARKMI_PGEMM_MIN_ROWS": "100000", "SPARKMI_GU1_ROWS": str(r)}) for r in (32, 128, 100000))
 for mode, env in modes:
