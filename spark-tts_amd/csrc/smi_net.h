@@ -78,31 +78,67 @@ __device__ __forceinline__ void conv_finish(const ConvP& p, f32x16 (&acc)[QB], f
   }
   if (!live) return;
 
+  // Epilogue loads first, arithmetic second.  Written element by element (`if (p.bias) y += p.bias[co]; ... if (p.R) y = p.R[o] + y;`)
+  // hipcc branches around every load and waits for it on the spot: up to six dependent round trips per element, ~190
+  // `s_waitcnt vmcnt(0)` per block -- the one-tap layers then ran at 1.3 TB/s of traffic with blocks alive for ~50 us.  Here
+  // every load of eight output rows is unconditional (an absent operand reads a valid dummy address and is dropped by a
+  // select), so they are all in flight together; the arithmetic and its order are unchanged.
   const long long yboff = (long long)b * p.yb;
-  const int nreg = KS ? 4 : 16;
+  constexpr int NREG = KS ? 4 : 16, GRP = KS ? 4 : 8;
+  const bool hb = p.bias != nullptr, hbb = p.bbias != nullptr, hg = p.gamma != nullptr, hbe = p.beta != nullptr, hr = p.R != nullptr,
+             hs = p.Ys != nullptr;
+  const float* dummy = p.X;                       // any readable floats: index < Cout <= the first activation row's size
+  const float* pb = hb ? p.bias : dummy;
+  const float* pbb = hbb ? p.bbias + (long long)b * p.Cout : dummy;
+  const float* pg = hg ? p.gamma : dummy;
+  const float* pbe = hbe ? p.beta : dummy;
+  const float* pa = hs ? p.alpha : dummy;
+  bool qok[QB];
+  int tq[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int q = q0 + qb * 32 + (lane & 31);
-    if (q >= olen) continue;
-    const int t = q * p.S + phase;
+    qok[qb] = q < olen;
+    tq[qb] = (qok[qb] ? q : olen - 1) * p.S + phase;   // (q0 < olen: the block has at least one live column)
+  }
 #pragma unroll
-    for (int rr = 0; rr < nreg; ++rr) {
-      const int r = KS ? wave * 4 + rr : rr;
-      const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (co >= p.Cout) continue;
-      float y = acc[qb][rr];
-      if (p.bias) y += p.bias[co];
-      if (p.bbias) y += p.bbias[(long long)b * p.Cout + co];
-      if (p.act == ACT_GELU) y = gelu_f(y);
-      if (p.act == ACT_RELU) y = fmaxf(y, 0.f);
-      if (p.gamma) y = p.gamma[co] * y;
-      if (p.beta) y = y + p.beta[co];
-      const long long o = yboff + (long long)co * p.ystride + t;
-      if (p.R) y = p.R[o] + y;
-      if (p.act == ACT_TANH) y = tanhf(y);
-      if (p.out_scale != 1.0f) y = (y + y) + y;  // SamplingBlock(ratio 1): x + x + x
-      if (p.Y) p.Y[o] = y;
-      if (p.Ys) p.Ys[o] = snake_f(y, p.alpha[co]);
+  for (int r0 = 0; r0 < NREG; r0 += GRP) {
+    int co[GRP];
+    bool cok[GRP];
+    float bv[GRP], bbv[GRP], gv[GRP], bev[GRP], av[GRP], rv[QB][GRP];
+#pragma unroll
+    for (int i = 0; i < GRP; ++i) {
+      const int r = KS ? wave * 4 + r0 + i : r0 + i;
+      co[i] = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      cok[i] = co[i] < p.Cout;
+      const int cc = cok[i] ? co[i] : p.Cout - 1;
+      bv[i] = pb[cc]; bbv[i] = pbb[cc]; gv[i] = pg[cc]; bev[i] = pbe[cc]; av[i] = pa[cc];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        const float* rp = hr ? p.R + (yboff + (long long)cc * p.ystride + tq[qb]) : dummy;
+        rv[qb][i] = *rp;
+      }
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+      for (int i = 0; i < GRP; ++i) {
+        float y = acc[qb][r0 + i];
+        y = hb ? y + bv[i] : y;
+        y = hbb ? y + bbv[i] : y;
+        if (p.act == ACT_GELU) y = gelu_f(y);
+        if (p.act == ACT_RELU) y = fmaxf(y, 0.f);
+        y = hg ? gv[i] * y : y;
+        y = hbe ? y + bev[i] : y;
+        y = hr ? rv[qb][i] + y : y;
+        if (p.act == ACT_TANH) y = tanhf(y);
+        if (p.out_scale != 1.0f) y = (y + y) + y;  // SamplingBlock(ratio 1): x + x + x
+        if (qok[qb] && cok[i]) {
+          const long long o = yboff + (long long)co[i] * p.ystride + tq[qb];
+          if (p.Y) p.Y[o] = y;
+          if (hs) p.Ys[o] = snake_f(y, av[i]);
+        }
+      }
     }
   }
 }
@@ -385,6 +421,60 @@ __global__ __launch_bounds__(256) void k_convb(ConvP p) {
   conv_finish<QB, KS>(p, acc, lds, ct, live, b, phase, q0, olen, lane, wave);
 }
 
+// Conv1d with ONE output channel (the vocoder's last layer: C -> 1, 7 taps, tanh): y[b][q] = act(bias + sum_ci sum_tap W[ci][tap]
+// x[b][ci][q + off[tap]]).  On the MFMA kernels 31 of a tile's 32 output rows are padding and the layer -- 393 MB of
+// activations at batch 32 -- ran at 0.3 TB/s (1.3 ms); here a thread owns one output sample, rows are read coalesced along time
+// (a sample is re-read by its 7 taps: L1 hits), weights come from LDS (unpacked from the conv layout: lane l, slot j of group g
+// holds W[l & 31][8g + 2j + (l >> 5)]), every load is unconditional (clamped index, masked value).
+template <int NTAP>
+__global__ __launch_bounds__(256) void k_conv_c1(ConvP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];      // [Cin][NTAP]
+  const int tid = threadIdx.x, b = blockIdx.y, q = blockIdx.x * 256 + tid;
+  const int len = p.lens[b], olen = p.olens ? p.olens[b] : len;
+  if ((int)blockIdx.x * 256 >= olen) return;
+  const int groups = p.CinP >> 3;
+  const float* Wf = p.W + p.wphase[0];
+  for (int i = tid; i < p.Cin * NTAP; i += 256) {
+    const int ci = i / NTAP, tap = i - ci * NTAP;
+    lds[i] = Wf[((size_t)(tap * groups + (ci >> 3)) * 64 + (ci & 1) * 32) * 4 + ((ci & 7) >> 1)];
+  }
+  __syncthreads();
+  if (q >= olen) return;
+  int tt[NTAP];
+  bool ok[NTAP];
+#pragma unroll
+  for (int k = 0; k < NTAP; ++k) {
+    const int t = q + p.off[0][k];
+    ok[k] = t >= 0 && t < len;
+    tt[k] = t < 0 ? 0 : (t < len ? t : len - 1);
+  }
+  const float* Xb = p.X + (long long)b * p.xb;
+  float acc = 0.f;
+  for (int c0 = 0; c0 < p.Cin; c0 += 4) {
+    float v[4][NTAP];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ci = c0 + u < p.Cin ? c0 + u : p.Cin - 1;
+      const float* xr = Xb + (long long)ci * p.xstride;
+#pragma unroll
+      for (int k = 0; k < NTAP; ++k) v[u][k] = xr[tt[k]];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (c0 + u < p.Cin) {
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k) acc = fmaf(lds[(c0 + u) * NTAP + k], ok[k] ? v[u][k] : 0.f, acc);
+      }
+    }
+  }
+  float y = acc;
+  if (p.bias) y += p.bias[0];
+  if (p.act == ACT_GELU) y = gelu_f(y);
+  if (p.act == ACT_RELU) y = fmaxf(y, 0.f);
+  if (p.act == ACT_TANH) y = tanhf(y);
+  p.Y[(long long)b * p.yb + q] = y;
+}
+
 // Linear layer on one vector per utterance (d-vector projection, AdaLN parameters): y[b][co] =
 // bias[co] + sum_ci W[co][ci] x[b][ci], fp32, reading the same packed conv weights (lane l, slot j of
 // group g holds W[32*ct + (l&31)][8g + 2j + (l>>5)]).  One block per 32 outputs, waves split K.
@@ -602,7 +692,7 @@ struct Launch {
   std::function<void(hipStream_t)> fn;
   std::string name;
   double flops;
-  ConvP cp; int qb; bool ks; int chg; int nwv = 4; bool gemv; bool bf = false; dim3 grid; size_t lds;
+  ConvP cp; int qb; bool ks; int chg; int nwv = 4; bool gemv; bool bf = false; bool c1 = false; int c1_len = 0; dim3 grid; size_t lds;
   LnP lp; int cpt;
   // small kernels keep their args here
   const int64_t* sem; int semstride; const float* cb; int D, cbsize; float* Z; int zstride; long long zb;
@@ -616,6 +706,8 @@ int run_launch(const Launch& L, hipStream_t st) {
     case 0:
       if (L.gemv) {
         hipLaunchKernelGGL(k_gemv1, L.grid, dim3(256), 0, st, L.cp);
+      } else if (L.c1) {            // one output channel, 7 taps: a thread per output sample (k_conv_c1)
+        hipLaunchKernelGGL((k_conv_c1<7>), dim3((L.c1_len + 255) / 256, L.grid.z), dim3(256), (size_t)L.cp.Cin * 7 * 4, st, L.cp);
       } else if (L.bf) {            // bf16-split matrix pipe (k_convb): weights packed as two bf16 planes
 #define SMI_CB(QB_, KS_, CHG_, NC_) hipLaunchKernelGGL((k_convb<QB_, KS_, CHG_, NC_>), L.grid, dim3(256), L.lds, st, L.cp)
         const bool wide = L.cp.xw > 64;

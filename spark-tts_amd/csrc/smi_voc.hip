@@ -436,6 +436,15 @@ int smi_voc_forward(smi_voc* h, const int64_t* sem_dev, const int32_t* lens_host
     // final conv7 -> tanh, written straight into the caller's waveform buffer [B][hop*T]
     P.push_back(make_conv(h, "decoder.conv_out+tanh", n + ".weight", (n + ".bias").c_str(), 1, clast, 7, 1, 1, 3, s_in, Lcur, bs,
                           wav_dev, nullptr, nullptr, nullptr, Lcur, Lcur, lens_at(c.dec_nblocks), B, Lcur, ACT_TANH));
+    {   // C -> 1: a thread per output sample instead of a 32-row MFMA tile with one live row (SPARKMI_VOC_C1=0: the MFMA kernel)
+      Launch& L = P.back();
+      const char* e = getenv("SPARKMI_VOC_C1");
+      const ConvP& q = L.cp;
+      if (!(e && e[0] == '0') && !L.bf && q.Cout == 1 && q.S == 1 && q.istr == 1 && q.ntaps[0] == 7 && !q.X2 && !q.bbias && !q.gamma &&
+          !q.beta && !q.R && !q.Ys && q.Y && q.out_scale == 1.0f && q.Cin * 7 * 4 <= 48 * 1024) {
+        L.c1 = true; L.c1_len = Lcur;
+      }
+    }
     Launch Z; Z.kind = 4; Z.name = "zero_tail"; Z.flops = 0; Z.wav = wav_dev; Z.wstride = Lcur; Z.lens = len0; Z.hop = hop;
     Z.grid = dim3((Lcur + 255) / 256, B);
     P.push_back(Z);

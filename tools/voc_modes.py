@@ -37,6 +37,6 @@ for exact in (True, False):
             rows.append((ms, nm, fl))
         tot = sum(r[0] for r in rows)
         print(f"  B=32 launches: {len(rows)}, sum {tot:.1f} ms")
-        for ms, nm, fl in sorted(rows, reverse=True)[:12]:
+        for ms, nm, fl in sorted(rows, reverse=True)[:int(os.environ.get("VOC_TOP", "12"))]:
             print(f"   {nm:45s} {ms:7.3f} ms  {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:7.1f} TFLOP/s (fp32-equivalent)")
 print(f"bf16-split vs exact: B=1 max|d| {np.abs(out[True][0] - out[False][0]).max():.3e}, B=32 max|d| {np.abs(out[True][1] - out[False][1]).max():.3e}")
