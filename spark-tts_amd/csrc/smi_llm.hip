@@ -921,8 +921,40 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_pgemm(GemmP p) {
     return;
   }
 #endif
-  // ---- epilogue (same arithmetic as k_gemm's)
+  // ---- epilogue (same arithmetic as k_gemm's).  Its loads first, all together and from clamped addresses: written inside the
+  // `if (valid)` bodies hipcc branched around every load and waited for it on the spot (QKV: 137 `s_waitcnt vmcnt(0)`, three
+  // dependent round trips -- bias, row descriptor, RoPE pair -- for each of the 24 (tile, m-tile) pairs of a wave).
   const int N = NT * 16;
+  int mrow[MTW];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) { const int m = m0 + (mt0 + mt) * 16 + em; mrow[mt] = m < M ? m : M - 1; }
+  int ncol[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) { const int nt = (bx * NWC + wc) * NTW + i; ncol[i] = (nt < NT ? nt : NT - 1) * 16 + 4 * (lane >> 4); }
+  float4 pre_h[EPI == EPI_RESID ? NTW : 1][EPI == EPI_RESID ? MTW : 1], pre_g[EPI != EPI_SWIGLU ? NTW : 1];
+  RowDesc pre_rd[EPI == EPI_QKV ? MTW : 1];
+  float2 pre_c[EPI == EPI_QKV ? NTW : 1][EPI == EPI_QKV ? MTW : 1][2];
+  if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      pre_g[i] = *(const float4*)(p.gamma_next + ncol[i]);
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) pre_h[i][mt] = *(const float4*)(p.Y + (size_t)mrow[mt] * N + ncol[i]);
+    }
+  } else if constexpr (EPI == EPI_QKV) {
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) pre_rd[mt] = p.rows[mrow[mt]];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      pre_g[i] = *(const float4*)(p.bias + ncol[i]);
+      const int i0 = (ncol[i] & 63) >> 1;
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) {
+        pre_c[i][mt][0] = p.rope[(size_t)pre_rd[mt].pos * 32 + i0];
+        pre_c[i][mt][1] = p.rope[(size_t)pre_rd[mt].pos * 32 + i0 + 1];
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < NTW; ++i) {
     const int nt = (bx * NWC + wc) * NTW + i;
@@ -940,11 +972,11 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_pgemm(GemmP p) {
       if (EPI == EPI_RESID) {
         float ssq = 0.f;
         if (valid) {
-          float4 h = *(const float4*)(p.Y + (size_t)m * N + n);
+          float4 h = pre_h[i][mt];
           h.x += s.x; h.y += s.y; h.z += s.z; h.w += s.w;
           *(float4*)(p.Y + (size_t)m * N + n) = h;
           ssq = (h.x * h.x + h.y * h.y) + (h.z * h.z + h.w * h.w);
-          const float4 g = *(const float4*)(p.gamma_next + n);
+          const float4 g = pre_g[i];
           const float t[4] = {g.x * h.x, g.y * h.y, g.z * h.z, g.w * h.w};
           uint32_t hi[4], mi[4], lo[4];
 #pragma unroll
@@ -974,12 +1006,11 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_pgemm(GemmP p) {
         }
       } else if (EPI == EPI_QKV) {
         if (valid) {
-          const float4 b = *(const float4*)(p.bias + n);
+          const float4 b = pre_g[i];
           s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
-          const RowDesc rd = p.rows[m];
+          const RowDesc rd = pre_rd[mt];
           if (n < p.q_dim + p.kv_dim) {
-            const int i0 = (n & 63) >> 1;
-            const float2 c0 = p.rope[(size_t)rd.pos * 32 + i0], c1 = p.rope[(size_t)rd.pos * 32 + i0 + 1];
+            const float2 c0 = pre_c[i][mt][0], c1 = pre_c[i][mt][1];
             float4 r;
             r.x = __fadd_rn(__fmul_rn(s.x, c0.x), __fmul_rn(-s.y, c0.y));
             r.y = __fadd_rn(__fmul_rn(s.y, c0.x), __fmul_rn(s.x, c0.y));
@@ -2336,6 +2367,7 @@ struct smi_llm {
   int pgemm_min_rows;   // prompt rows from which the prefill GEMM replaces row-grouped decode GEMMs (SPARKMI_PGEMM_MIN_ROWS)
   int pg_min[4];        // ... per kernel (QKV, o_proj, gate_up, down; SPARKMI_PGEMM_MIN_QKV / _O / _GU / _D override the common value)
   int wd_parts;         // W_down tiles are stored row-part-major (include/sparkmi.h; SPARKMI_WD_PLAIN=1, read by the packer too: plain tile order, for A/B)
+  int gu1_lo;           // rows from which (up to 16) gate_up runs the one-batch, three-tile shape with one m-tile (SPARKMI_GU1_LO; default 4)
   int gu1_rows;         // rows up to which gate_up runs its one-batch, three-tile shape (SPARKMI_GU1_ROWS; default 32)
   hipGraphExec_t graph; int graph_B, graph_seg, graph_ident;
   hipEvent_t ev0, ev1;
@@ -2464,6 +2496,13 @@ int launch_gemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
       if (!(L->tune2 & 1)) return (L->tune2 & 4096) ? launch_gemm_kv<1, NTB, NW, U, 1, PRO, EPI, H>(L, p, st) : launch_gemm_kv<1, NTB, NW, U, WB, PRO, EPI, H>(L, p, st);
     }
     return launch_gemm_kv<2, NTB, NW, (NW >= 16 || NTB >= 4 ? 2 : (U > 4 ? 4 : U)), 1, PRO, EPI>(L, p, st);
+  }
+  if constexpr (N2 > 1) {
+    // gate_up at gu1_lo..16 rows: three n tiles per block and all of a wave's k tiles in one batch, as at 17..32 rows -- every load
+    // of the block leaves at entry (one memory round trip).  8 rows 8.0 -> 6.9 us (graph step 801 -> 773 us), 16 rows 9.5 -> 7.9
+    // (855 -> 817), 5 rows 763 -> 751, 4 rows 749 -> 742, 2 rows a tie (below 4 rows the operands staged through wave-private LDS
+    // stay); same bits (the k tile -> wave map does not change).  SPARKMI_GU1_LO sets the first row count (A/B).
+    if (p.M >= L->gu1_lo && !(L->tune2 & 131072)) return launch_gemm_kv<1, 3, NW, 4, 1, PRO, EPI>(L, p, st);
   }
   return launch_gemm_kv<1, NTB, NW, U, WB, PRO, EPI, H, OCC>(L, p, st);
 }
@@ -2891,6 +2930,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
     for (int i = 0; i < 4; ++i) { const char* e = getenv(names[i]); L->pg_min[i] = e ? atoi(e) : common ? L->pgemm_min_rows : dflt[i]; }
   }
   { const char* e = getenv("SPARKMI_GU1_ROWS"); L->gu1_rows = e ? atoi(e) : 32; }
+  { const char* e = getenv("SPARKMI_GU1_LO"); L->gu1_lo = e ? atoi(e) : 4; }
   { const char* e = getenv("SPARKMI_WD_PLAIN"); L->wd_parts = !(e && e[0] && e[0] != '0'); }
   L->pf_tiles = nullptr; L->pf_tiles_cap = 0; L->pf_ntiles = 0;
   { const char* e = getenv("SPARKMI_ATTN_PF2"); L->attn_pf2 = !(e && e[0] == '0'); }
