@@ -2421,7 +2421,9 @@ int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
   if (MT == 1 && p.M <= 5) {
     const int tw = (p.KT + NW - 1) / NW;               // k tiles per wave
     const size_t per_wave = (size_t)tw * 12 * p.M * 16;
-    if (per_wave * NW <= 40 * 1024) {
+    // (blocks of 14+ waves are alone on their CU anyway: down_proj's ten k tiles per wave then fit up to 3 rows -- 2 rows: down_proj
+    // 8.7 -> 7.3 us, graph step 718 -> 690 us; at 4 rows (123 KB) a tie, so the cap stays below it.  SPARKMI_TUNE2 bit 524288: 40 KB for all)
+    if (per_wave * NW <= (size_t)((NW >= 14 && !(L->tune2 & 524288)) ? 96 : 40) * 1024) {
       p.ldsb = (int)per_wave;
       int sh = 4;                                       // 16 lanes fetch 12 pieces (M = 1)
       while ((1 << sh) < 12 * p.M) ++sh;
