@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--cpu-tokens", type=int, default=150, help="tokens of the CPU-oracle utterance (SURVEY 8d: the whole configs[1] utterance)")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed CPU-oracle runs (median reported) after one warm-up run")
     ap.add_argument("--uniform", action="store_true", help="--batch > 1 with identical lengths (--prompt-len -> --new-tokens) instead of the ragged configs[2] inputs")
+    ap.add_argument("--static-batch", action="store_true", help="ragged batches decode max(N_i) steps on all rows (no retirement of finished rows)")
     ap.add_argument("--no-config4", action="store_true", help="skip the 256-utterance sharded set (BASELINE configs[3])")
     ap.add_argument("--set-size", type=int, default=256, help="utterances of the configs[3] set")
     ap.add_argument("--clone", action="store_true",
@@ -295,13 +296,19 @@ def main():
     def run_batch(eng, vocoder, pr, wants, glob_dev, timed=False):
         """prefill -> decode max(N_i) - 1 steps -> row i keeps its first N_i tokens -> ragged vocoder batch -> host."""
         nmax = max(wants)
-        eng.prefill(pr, None)
-        if timed:
-            ev[0].record()
-        eng.decode(nmax - 1)
-        if timed:
-            ev[1].record()
-        toks = eng.tokens(nmax)                              # sync + D2H: the host parses ids like the reference
+        if len(pr) > 1 and min(wants) < nmax and not a.static_batch:
+            # ragged budgets: rows are retired as they finish (in-flight batching, SURVEY 8f-4) -- the step runs on the live rows
+            toks = eng.generate_ragged(pr, wants, None, on_prefilled=(lambda: ev[0].record()) if timed else None)
+            if timed:
+                ev[1].record()
+        else:
+            eng.prefill(pr, None)
+            if timed:
+                ev[0].record()
+            eng.decode(nmax - 1)
+            if timed:
+                ev[1].record()
+            toks = eng.tokens(nmax)                              # sync + D2H: the host parses ids like the reference
         sem = torch.zeros((len(pr), nmax), dtype=torch.long)
         for b, t in enumerate(toks):
             sem[b, : wants[b]] = torch.tensor(t[: wants[b]], dtype=torch.long) % voc_cfg.codebook_size
@@ -435,8 +442,13 @@ def main():
         # through all Nmax - 1 decode steps (rows past their own length are the padding of a static batch).
         wb = llm.step_weight_bytes()
         kvb = llm.kv_bytes_per_token()
-        ctx_sum = sum(len(p) + j for p in prompts for j in range(1, Nmax))   # decode step j of a row reads its positions 0..P+j-1
-        step_bytes = wb + kvb * (ctx_sum / (Nmax - 1) + B) + kvb * B          # KV read (cached + own) + KV write
+        # (a ragged batch retires rows at their own length N_i: row i takes part in N_i - 1 of the Nmax - 1 steps; with
+        # --static-batch every row steps through all of them, rows past their length being padding)
+        retiring = B > 1 and min(want) < Nmax and not a.static_batch
+        eff = want if retiring else [Nmax] * B
+        ctx_sum = sum(len(p) + j for p, w in zip(prompts, eff) for j in range(1, w))   # decode step j of a row reads its positions 0..P+j-1
+        row_steps = sum(w - 1 for w in eff)
+        step_bytes = wb + kvb * (ctx_sum + row_steps) / (Nmax - 1) + kvb * row_steps / (Nmax - 1)   # KV read (cached + own) + KV write
         dec_step_ms = res["stage_ms"][f"decode_{Nmax - 1}_steps"] / (Nmax - 1)
         res["roofline_step"] = {
             "bound": "hbm", "achieved": step_bytes / (dec_step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -134,6 +134,12 @@ int smi_llm_session_begin(smi_llm* h, const int64_t* eos_ids_host, int n_eos, vo
 int smi_llm_admit(smi_llm* h, const int64_t* ids_host, const int32_t* lens_host, int n, int P_max, int32_t* slots_out, void* stream);
 int smi_llm_retire(smi_llm* h, int slot, void* stream);
 int smi_llm_slot_tokens(smi_llm* h, int slot, int64_t* out_host, int cap, int32_t* n_out, int32_t* finished, void* stream);
+/* Several sequences leave at once with no host round trip (the device row list is compacted in place), and the tokens of
+ * several slots in one round trip: out_host [n][cap], n_out [n], finished [n].  A retired slot's history stays readable
+ * until a later admission reuses the slot. */
+int smi_llm_retire_many(smi_llm* h, const int32_t* slots, int n, void* stream);
+int smi_llm_slots_tokens(smi_llm* h, const int32_t* slots, int n, int64_t* out_host, int cap, int32_t* n_out, int32_t* finished,
+                         void* stream);
 /* count_host / finished_host [SMI_MAX_ROWS]: tokens emitted and eos flag per KV slot, one round trip. */
 int smi_llm_status(smi_llm* h, int32_t* count_host, int32_t* finished_host, void* stream);
 /* Test/teacher-forcing entry: feeds ids_host[0..S) at positions 0..S-1 of slot 0 (cache reset) and

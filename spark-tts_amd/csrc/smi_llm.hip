@@ -27,6 +27,7 @@
 #include "smi_common.h"
 #include <stdio.h>
 #include <string.h>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -1911,6 +1912,19 @@ __device__ __forceinline__ void embed_row(const uint16_t* Wlm, int KT, int token
   for (int i = lane; i < npart; i += 64) sspart[(size_t)m * npart + i] = i == 0 ? ss : 0.f;
 }
 
+// Drops the rows of the retired KV slots from the live row list, in place and in order (one block; B <= 64 rows).
+__global__ __launch_bounds__(64) void k_rows_drop(RowDesc* rows, int B, unsigned long long drop_slots) {
+  const int i = threadIdx.x;
+  RowDesc rd = RowDesc{0, 0, 0, 0};
+  bool keep = false;
+  if (i < B) { rd = rows[i]; keep = !((drop_slots >> rd.slot) & 1ull); }
+  const unsigned long long m = __ballot(keep);
+  const int dst = __popcll(m & ((1ull << i) - 1ull));
+  __syncthreads();   // (one wave: every row was read before any is overwritten)
+  if (keep) rows[dst] = rd;
+  else if (i < 64) { /* nothing: the tail beyond the new count is never read */ }
+}
+
 __global__ __launch_bounds__(256) void k_embed(const uint16_t* Wlm, int KT, const RowDesc* rows, int M, const float* gamma,
                                                float* h, unsigned char* xs, float* sspart, int npart) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2351,6 +2365,7 @@ struct smi_llm {
   int admit_seq;        // sequences admitted so far in this generation / session (sampler stream ids)
   // continuous batching (smi_llm_session_*): live rows map to arbitrary KV slots
   int session, identity_slots;
+  std::vector<int> live_order;   // session: the KV slot of every live row, in row order (what the device row list holds)
   int attn_seg;                        // context segments per (head, row) of the attention launches being issued (1 = unsplit)
   float* apart; size_t apart_floats;   // segment partials [rows][heads][attn_seg][66]
   int slot_busy[kMaxRows], slot_len[kMaxRows];      // host: slot in use; prompt length + tokens emitted (cache positions used)
@@ -2369,7 +2384,12 @@ struct smi_llm {
   int wd_parts;         // W_down tiles are stored row-part-major (include/sparkmi.h; SPARKMI_WD_PLAIN=1, read by the packer too: plain tile order, for A/B)
   int gu1_lo;           // rows from which (up to 16) gate_up runs the one-batch, three-tile shape with one m-tile (SPARKMI_GU1_LO; default 4)
   int gu1_rows;         // rows up to which gate_up runs its one-batch, three-tile shape (SPARKMI_GU1_ROWS; default 32)
-  hipGraphExec_t graph; int graph_B, graph_seg, graph_ident;
+  hipGraphExec_t graph; int graph_B, graph_seg, graph_ident;   // the step graph in use (owned by graph_cache)
+  // One captured decode step per (row count, context segments, slots-are-rows): in-flight batching changes the row count at
+  // every admission / retirement, and re-capturing the ~100-node step each time cost more than the steps saved.  Everything
+  // else a step reads is device data (row descriptors, stop ids, seed) or fixed at create; the sampler's parameters and the
+  // attention-partials buffer are kernel arguments, so a change of either empties the cache (graphs_flush).
+  std::map<uint32_t, hipGraphExec_t> graph_cache;
   hipEvent_t ev0, ev1;
   // host staging
   std::vector<RowDesc> host_rows;
@@ -2408,6 +2428,11 @@ int pages_ensure(smi_llm* L, const int* slots, const int* tokens, int n, hipStre
   return SMI_OK;
 }
 KvMap kv_map(const smi_llm* L) { return KvMap{L->paged ? L->ptab : nullptr, L->pshift, L->ppslot}; }
+void graphs_flush(smi_llm* L) {
+  for (auto& kv : L->graph_cache) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+  L->graph_cache.clear();
+  L->graph = nullptr;
+}
 
 template <int MT, int NTB, int NW, int U, int WB, int PRO, int EPI, int H = 1, int OCC = 1>
 int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
@@ -2523,6 +2548,7 @@ enum { KQKV = 0, KATTN, KO, KGU, KD, KLM, KFIN };
 
 int ensure_apart(smi_llm* L, size_t floats) {
   if (floats <= L->apart_floats) return SMI_OK;
+  graphs_flush(L);   // captured steps hold the old buffer's address
   if (L->apart) (void)hipFree(L->apart);
   L->apart = nullptr; L->apart_floats = 0;
   if (hipMalloc((void**)&L->apart, floats * 4) != hipSuccess) { smi_set_error("hipMalloc(attention partials, %zu floats) failed", floats); return SMI_ENOMEM; }
@@ -3015,7 +3041,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
 
 int smi_llm_destroy(smi_llm* L) {
   if (!L) return SMI_OK;
-  if (L->graph) (void)hipGraphExecDestroy(L->graph);
+  graphs_flush(L);
   void* ptrs[] = {L->h, L->qbuf, L->xs_h, L->xs_attn, L->xs_act, L->sspart, L->part_o, L->h2, L->rows, L->plan, L->pf_tiles, L->pval, L->pidx, L->hist,
                   L->count, L->finished, L->step, L->ctl, L->ptab, L->kcache, L->vcache, L->logits, L->tok, L->cand_v, L->cand_i, L->cand_n, L->stamps, L->bh, L->bq, L->bxs_h, L->bxs_attn, L->bxs_act, L->bss, L->apart};
   for (void* q : ptrs)
@@ -3041,7 +3067,7 @@ int smi_llm_set_sampling(smi_llm* L, int do_sample, float temperature, int top_k
   L->temperature = temperature; L->top_k = top_k; L->top_p = top_p; L->seed = seed;
   L->hctl.seed = seed;   // uploaded with the next prefill / session_begin too
   SMI_HIP(hipMemcpy(&L->ctl->seed, &seed, sizeof(seed), hipMemcpyHostToDevice));
-  if (changed && L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }
+  if (changed) graphs_flush(L);
   return SMI_OK;
 }
 
@@ -3182,10 +3208,11 @@ int smi_llm_session_begin(smi_llm* L, const int64_t* eos_ids, int n_eos, void* s
   SMI_HIP(hipMemsetAsync(L->finished, 0, kMaxRows * 4, st));
   SMI_HIP(hipMemsetAsync(L->step, 0, 4, st));
   L->B = 0; L->started = 1; L->session = 1; L->identity_slots = 1;
+  L->live_order.clear();
   L->max_len = 0; L->steps_launched = 0;
   memset(L->slot_busy, 0, sizeof(L->slot_busy));
   memset(L->slot_len, 0, sizeof(L->slot_len));
-  if (L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }
+  L->graph = nullptr;
   return SMI_OK;
 }
 
@@ -3194,7 +3221,9 @@ static int session_set_rows(smi_llm* L, const std::vector<RowDesc>& live, hipStr
   L->B = (int)live.size();
   L->identity_slots = 1;
   for (int b = 0; b < L->B; ++b) L->identity_slots &= live[b].slot == b;
-  if (L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }
+  L->live_order.clear();
+  for (int b = 0; b < L->B; ++b) L->live_order.push_back(live[b].slot);
+  L->graph = nullptr;   // (the next decode picks the cached step of the new row count)
   if (L->B == 0) return SMI_OK;
   L->host_rows.assign(kMaxRows, RowDesc{0, 0, 0, 0});
   for (int b = 0; b < L->B; ++b) L->host_rows[b] = live[b];
@@ -3243,7 +3272,7 @@ int smi_llm_admit(smi_llm* L, const int64_t* ids, const int32_t* lens, int n, in
     SMI_HIP(hipMemcpyAsync(L->finished + slots[b], zeros, 4, hipMemcpyHostToDevice, st));
   }
   SMI_HIP(hipMemcpyAsync(L->rows, L->plan + tail, kMaxRows * sizeof(RowDesc), hipMemcpyDeviceToDevice, st));
-  if (L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }
+  L->graph = nullptr;
   const int oldB = L->B;
   L->B = n;
   L->identity_slots = 1;
@@ -3274,6 +3303,58 @@ int smi_llm_retire(smi_llm* L, int slot, void* stream) {
   L->slot_len[slot] = 0;
   if (L->paged) pages_release(L, slot);   // its pages go back to the pool (stale table entries are never read: no live row names the slot)
   return session_set_rows(L, live, st);
+}
+
+// Several sequences leave at once, without a host round trip: the device row list is compacted in place (order kept), the
+// per-row state of the rows that moved is rebuilt from their descriptors (as after any change of the live set), the slots
+// (and their pages) are free again.  Their histories stay readable (smi_llm_slots_tokens) until a later admission reuses a slot.
+int smi_llm_retire_many(smi_llm* L, const int32_t* slots, int n, void* stream) {
+  SMI_REQUIRE(L && slots && n >= 1 && n <= kMaxRows, "smi_llm_retire_many: bad argument");
+  if (!L->started || !L->session) { smi_set_error("smi_llm_retire_many outside a session"); return SMI_ESTATE; }
+  unsigned long long drop = 0;
+  for (int i = 0; i < n; ++i) {
+    SMI_REQUIRE(slots[i] >= 0 && slots[i] < kMaxRows && L->slot_busy[slots[i]] && !((drop >> slots[i]) & 1ull), "smi_llm_retire_many: slot %d is not live (or listed twice)", slots[i]);
+    drop |= 1ull << slots[i];
+  }
+  SMI_REQUIRE((int)L->live_order.size() == L->B, "smi_llm_retire_many: live row list out of step");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_rows_drop, dim3(1), dim3(64), 0, st, L->rows, L->B, drop);
+  SMI_LAUNCH_CHECK();
+  std::vector<int> keep;
+  for (int sl : L->live_order) if (!((drop >> sl) & 1ull)) keep.push_back(sl);
+  for (int i = 0; i < n; ++i) {
+    L->slot_busy[slots[i]] = 0;
+    L->slot_len[slots[i]] = 0;
+    if (L->paged) pages_release(L, slots[i]);
+  }
+  L->live_order = keep;
+  L->B = (int)keep.size();
+  L->identity_slots = 1;
+  for (int b = 0; b < L->B; ++b) L->identity_slots &= keep[b] == b;
+  L->graph = nullptr;
+  if (L->B == 0) return SMI_OK;
+  return launch_embed(L, L->rows, L->B, st);
+}
+
+// Tokens of several slots in one device round trip: out_host [n][cap], n_out[n], finished[n].
+int smi_llm_slots_tokens(smi_llm* L, const int32_t* slots, int n, int64_t* out_host, int cap, int32_t* n_out, int32_t* finished, void* stream) {
+  SMI_REQUIRE(L && slots && out_host && n_out && finished && n >= 1 && n <= kMaxRows && cap >= 1, "smi_llm_slots_tokens: bad argument");
+  for (int i = 0; i < n; ++i) SMI_REQUIRE(slots[i] >= 0 && slots[i] < kMaxRows, "smi_llm_slots_tokens: slot %d out of range", slots[i]);
+  hipStream_t st = (hipStream_t)stream;
+  int32_t cnt[kMaxRows], fin[kMaxRows];
+  SMI_HIP(hipMemcpyAsync(cnt, L->count, kMaxRows * 4, hipMemcpyDeviceToHost, st));
+  SMI_HIP(hipMemcpyAsync(fin, L->finished, kMaxRows * 4, hipMemcpyDeviceToHost, st));
+  int steps = cap < L->max_steps ? cap : L->max_steps;
+  std::vector<int64_t> hist((size_t)steps * kMaxRows);
+  SMI_HIP(hipMemcpyAsync(hist.data(), L->hist, hist.size() * 8, hipMemcpyDeviceToHost, st));
+  SMI_HIP(hipStreamSynchronize(st));
+  for (int i = 0; i < n; ++i) {
+    int k = cnt[slots[i]] < steps ? cnt[slots[i]] : steps;
+    for (int t = 0; t < k; ++t) out_host[(size_t)i * cap + t] = hist[(size_t)t * kMaxRows + slots[i]];
+    n_out[i] = k;
+    finished[i] = fin[slots[i]];
+  }
+  return SMI_OK;
 }
 
 // Tokens a live (or just finished) slot has emitted since it was admitted; *finished: it has produced eos.
@@ -3331,7 +3412,14 @@ int smi_llm_decode(smi_llm* L, int n_steps, void* stream) {
     if (L->attn_seg > 1 && (rc = ensure_apart(L, (size_t)kMaxRows * L->cfg.num_heads * L->attn_seg * 66))) return rc;
   }
   if (L->cfg.use_graph && n_steps > 0 && (!L->graph || L->graph_B != L->B || L->graph_seg != L->attn_seg || L->graph_ident != L->identity_slots)) {
-    if (L->graph) { (void)hipGraphExecDestroy(L->graph); L->graph = nullptr; }
+    const uint32_t key = (uint32_t)L->B | ((uint32_t)L->attn_seg << 8) | ((uint32_t)(L->identity_slots ? 1 : 0) << 24);
+    auto hit = L->graph_cache.find(key);
+    L->graph = hit != L->graph_cache.end() ? hit->second : nullptr;
+    L->graph_B = L->B; L->graph_seg = L->attn_seg; L->graph_ident = L->identity_slots;
+  }
+  if (L->cfg.use_graph && n_steps > 0 && !L->graph) {
+    const uint32_t key = (uint32_t)L->B | ((uint32_t)L->attn_seg << 8) | ((uint32_t)(L->identity_slots ? 1 : 0) << 24);
+    if (L->graph_cache.size() >= 192) graphs_flush(L);
     hipStream_t cs;
     SMI_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     hipGraph_t g = nullptr;
@@ -3348,6 +3436,7 @@ int smi_llm_decode(smi_llm* L, int n_steps, void* stream) {
     (void)hipGetLastError();
     L->graph_B = L->B; L->graph_seg = L->attn_seg; L->graph_ident = L->identity_slots;
     if (!L->graph) { smi_set_error("hipGraph capture of the decode step failed"); return SMI_EHIP; }
+    L->graph_cache[key] = L->graph;
   }
   for (int s = 0; s < n_steps; ++s) {
     if (L->cfg.use_graph) {
@@ -3458,6 +3547,7 @@ int smi_llm_debug_stamps(smi_llm* L, int kernel, int layer, double* out) {
   SMI_REQUIRE(nblk <= 4096, "smi_llm_debug_stamps: grid too large");
   SMI_HIP(hipMemset(L->stamps, 0, (size_t)4096 * 64));
   L->stamps_on = 1;
+  graphs_flush(L);   // (the stamped kernels are other instantiations)
   int rc = launch_one(L, kernel, layer, L->rows, L->B, nullptr, 0);
   L->stamps_on = 0;
   if (rc) return rc;

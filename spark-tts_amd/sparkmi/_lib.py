@@ -75,6 +75,8 @@ SYMBOLS = {
     "smi_llm_admit": (_I, [_VP, _P(C.c_int64), _P(C.c_int32), _I, _I, _P(C.c_int32), _VP]),
     "smi_llm_retire": (_I, [_VP, _I, _VP]),
     "smi_llm_slot_tokens": (_I, [_VP, _I, _P(C.c_int64), _I, _P(C.c_int32), _P(C.c_int32), _VP]),
+    "smi_llm_retire_many": (_I, [_VP, _P(C.c_int32), _I, _VP]),
+    "smi_llm_slots_tokens": (_I, [_VP, _P(C.c_int32), _I, _P(C.c_int64), _I, _P(C.c_int32), _P(C.c_int32), _VP]),
     "smi_llm_status": (_I, [_VP, _P(C.c_int32), _P(C.c_int32), _VP]),
     "smi_llm_forward_logits": (_I, [_VP, _P(C.c_int64), _I, _VP, _VP]),
     "smi_llm_steps": (_I, [_VP]),

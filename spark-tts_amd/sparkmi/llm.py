@@ -228,6 +228,23 @@ class SparkLLM:
     def retire(self, slot: int) -> None:
         _lib.check(self._lib.smi_llm_retire(self._h, int(slot), self._stream()), "smi_llm_retire")
 
+    def retire_many(self, slots: Sequence[int]) -> None:
+        """Several sequences leave at once; no host round trip (the device row list is compacted in place)."""
+        arr = np.asarray(list(slots), dtype=np.int32)
+        _lib.check(self._lib.smi_llm_retire_many(self._h, arr.ctypes.data_as(C.POINTER(C.c_int32)), len(arr), self._stream()),
+                   "smi_llm_retire_many")
+
+    def slots_tokens(self, slots: Sequence[int], cap: int):
+        """[(tokens, finished)] of several slots (live or retired and not yet reused) in one device round trip."""
+        arr = np.asarray(list(slots), dtype=np.int32)
+        out = np.zeros((len(arr), max(cap, 1)), dtype=np.int64)
+        n = np.zeros(len(arr), dtype=np.int32)
+        fin = np.zeros(len(arr), dtype=np.int32)
+        _lib.check(self._lib.smi_llm_slots_tokens(self._h, arr.ctypes.data_as(C.POINTER(C.c_int32)), len(arr),
+                                                  out.ctypes.data_as(C.POINTER(C.c_int64)), max(cap, 1), n.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                  fin.ctypes.data_as(C.POINTER(C.c_int32)), self._stream()), "smi_llm_slots_tokens")
+        return [(out[i, : n[i]].tolist(), bool(fin[i])) for i in range(len(arr))]
+
     def slot_tokens(self, slot: int, cap: int):
         """(tokens emitted so far by the sequence in ``slot``, finished flag)."""
         out = np.zeros(max(cap, 1), dtype=np.int64)
@@ -280,6 +297,47 @@ class SparkLLM:
                     self.retire(slot)
                     del live[slot]
                     yield key, toks
+
+    def generate_ragged(self, prompts: Sequence[Sequence[int]], max_new_tokens: Sequence[int], eos_token_id: EosLike = None,
+                        check_every: int = 16, on_prefilled=None) -> List[List[int]]:
+        """One batch of prompts with PER-ROW token budgets, rows retired as they finish (their budget, or eos): the decode
+        step then runs on the rows still alive instead of padding finished ones to the longest (HF ``generate`` pads; the
+        reference's TensorRT-LLM deployment batches in flight, run.sh:50-65).  Rows are independent in every kernel, so
+        row i's tokens are exactly those of ``generate_ids`` truncated to its budget.  The captured step of every row
+        count is cached in the library, so retiring costs a row-table upload, not a graph capture.  Greedy or the
+        sampler set by ``set_sampling``; ``on_prefilled()`` is called after the prompts' prefill was enqueued."""
+        n = len(prompts)
+        want = [int(w) for w in max_new_tokens]
+        if n != len(want) or n > self.max_slots or min(want) < 1:
+            raise ValueError("generate_ragged: one budget >= 1 per prompt, at most max_slots prompts")
+        if max(len(p) + w for p, w in zip(prompts, want)) > self.max_positions:
+            raise ValueError("generate_ragged: prompt + budget exceeds max_positions")
+        eos = self._eos_list(eos_token_id)
+        self.session_begin(eos or None)
+        slots = self.admit([list(p) for p in prompts])
+        if on_prefilled is not None:
+            on_prefilled()
+        live = {slot: i for i, slot in enumerate(slots)}
+        done = 1                                   # tokens every live row has emitted (the prefill emits the first)
+        while live:
+            fin = None
+            if eos:
+                _, fin = self.status()             # one device round trip
+            leave = [slot for slot, i in live.items() if done >= want[i] or (fin is not None and fin[slot])]
+            if leave:
+                self.retire_many(leave)            # enqueued behind the steps so far: no host round trip
+                for slot in leave:
+                    del live[slot]
+            if not live:
+                break
+            steps = min(want[i] for i in live.values()) - done
+            if eos:
+                steps = min(steps, check_every)
+            self.decode(steps)
+            done += steps
+        # histories are per KV slot and stay until a slot is reused: all rows in one round trip
+        got = self.slots_tokens(slots, max(want))
+        return [t[: want[i]] for i, (t, _) in enumerate(got)]
 
     # ------------------------------------------------------------------ test / bench entries
     def forward_logits(self, ids: Sequence[int]) -> torch.Tensor:

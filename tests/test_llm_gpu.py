@@ -234,6 +234,37 @@ def test_prefill_paths_agree(tiny, monkeypatch):
         assert Qwen2Ref(cfg, syn, kv_dtype="bf16").generate_greedy(prompts[b], 16) == chunked[b]
 
 
+def test_generate_ragged_retires_rows_and_equals_the_static_batch(tiny):
+    """Per-row budgets with rows retired as they finish (the live row count shrinks, each count's captured step comes from the
+    library's cache): row i's tokens are those of the padded static batch truncated to its budget -- greedy, with an eos, on a
+    second call (cache hits), and after a sampling-mode change emptied the cache."""
+    cfg, syn = tiny
+    rng = np.random.Generator(np.random.PCG64(515))
+    B = 11
+    prompts = [rng.integers(0, cfg.vocab_size, size=int(rng.integers(3, 40))).tolist() for _ in range(B)]
+    budgets = [int(v) for v in rng.integers(1, 45, size=B)]
+    budgets[3] = budgets[7] = 19          # two rows leave at the same step
+    budgets[0] = 1                         # leaves right after the prefill
+    llm = _llm(cfg, syn, max_slots=16, max_positions=128)
+    static = llm.generate_ids(prompts, max(budgets))
+    want = [t[:n] for t, n in zip(static, budgets)]
+    assert llm.generate_ragged(prompts, budgets) == want
+    assert llm.generate_ragged(prompts, budgets) == want                  # every row count's step now comes from the cache
+    eos = static[5][10]
+    def cut(t, n):
+        t = t[:n]
+        return t[: t.index(eos) + 1] if eos in t else t
+    assert llm.generate_ragged(prompts, budgets, eos, check_every=3) == [cut(t, n) for t, n in zip(static, budgets)]
+    llm.set_sampling(True, 0.8, 50, 0.95, 1234)                           # sampler parameters are kernel arguments: cache emptied
+    sampled = llm.generate_ragged(prompts, budgets)
+    assert [len(t) for t in sampled] == budgets
+    llm.set_sampling(False)
+    assert llm.generate_ragged(prompts, budgets) == want
+    single = _llm(cfg, syn, max_slots=1, max_positions=128)
+    for i in (2, 6, 10):
+        assert single.generate_ids([prompts[i]], budgets[i])[0] == want[i]
+
+
 def test_continuous_batching_equals_standalone_runs(tiny):
     """Sequences admitted and retired between decode steps (in-flight batching) produce exactly the tokens of
     their own B = 1 runs, whatever else is live and whichever KV slot they land in."""
