@@ -162,7 +162,12 @@ class SparkTTS:
         if room < 1:
             raise ValueError(f"a prompt of {max(len(i) for i in ids)} tokens does not fit max_positions={self._max_positions}")
         max_new_tokens = min(int(max_new_tokens), room)
-        if do_sample:
+        if len(ids) > 1 and self._eos and len(ids) <= self.model.max_slots:
+            # a batch: rows are retired at their own eos (SparkLLM.generate_ragged), so the step runs on the rows still
+            # speaking instead of padding the finished ones to the longest utterance; same tokens per row
+            self.model.set_sampling(bool(do_sample), temperature, int(top_k), float(top_p), seed)
+            new = self.model.generate_ragged(ids, [max_new_tokens] * len(ids), self._eos)
+        elif do_sample:
             new = self.model.generate_ids(ids, max_new_tokens, self._eos, do_sample=True, temperature=temperature,
                                           top_k=int(top_k), top_p=float(top_p), seed=seed)
         else:
