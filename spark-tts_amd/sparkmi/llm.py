@@ -290,13 +290,13 @@ class SparkLLM:
                     live[slot] = (b[0], int(b[2]))
             self.decode(decode_stride)
             cnt, fin = self.status()
-            for slot in list(live):
-                key, max_new = live[slot]
-                if fin[slot] or cnt[slot] >= max_new:
-                    toks, _ = self.slot_tokens(slot, max_new)
-                    self.retire(slot)
-                    del live[slot]
-                    yield key, toks
+            leave = [slot for slot in live if fin[slot] or cnt[slot] >= live[slot][1]]
+            if leave:                      # their tokens in one round trip, their rows dropped on the device
+                got = self.slots_tokens(leave, max(live[slot][1] for slot in leave))
+                self.retire_many(leave)
+                for slot, (toks, _) in zip(leave, got):
+                    key, max_new = live.pop(slot)
+                    yield key, toks[:max_new]
 
     def generate_ragged(self, prompts: Sequence[Sequence[int]], max_new_tokens: Sequence[int], eos_token_id: EosLike = None,
                         check_every: int = 16, on_prefilled=None) -> List[List[int]]:

@@ -1,5 +1,7 @@
 #!/bin/bash
 # Timing-only builds of the ring k_pgemm with parts removed (SMI_PG_ABL bits: 1 MFMAs, 2 in-loop LDS-DMA, 4 epilogue, 8 fragment reads):
+# (bit 2 without bit 8 multiplies never-written LDS -- timing only -- and one such run did not finish within gpurun's silence limit:
+#  combine it with 8, as in 11 and 15)
 #   tools/pg_ablate.sh build 1 2 3 ...   (here: builds spark-tts_amd/sparkmi/ab/libsparkmi_abl<bits>.so)
 #   tools/pg_ablate.sh run BxP 1 2 3 ... (GPU box: per-kernel averages of each build)
 cd "$(dirname "$0")/.." || exit 1
