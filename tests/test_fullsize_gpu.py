@@ -66,6 +66,22 @@ def test_config3_prompts_through_the_prefill_gemm(full_llm, golden_dir, kv):
         assert batched[0] == g["greedy"][:n].tolist()
 
 
+def test_config3_ragged_batch_with_rows_retired_equals_the_padded_batch(full_llm):
+    """What `bench.py --batch 32` runs (configs[2] / [3]): 32 ragged prompts (97..154 ids), per-row token budgets, rows retired on
+    the device as they reach their budget (`SparkLLM.generate_ragged`: admit through the session path, cached step graph per
+    live-row count, `smi_llm_retire_many`).  Every row's tokens are those of the padded static batch truncated to its budget
+    -- bit for bit: rows are independent in every kernel and both paths prefill the same 4000-odd rows through k_pgemm."""
+    cfg, syn, arena = full_llm
+    rng = np.random.Generator(np.random.PCG64(3030))
+    prompts = [rng.integers(0, cfg.vocab_size, size=int(rng.integers(97, 155))).tolist() for _ in range(32)]
+    budgets = [int(v) for v in rng.integers(6, 23, size=32)]
+    llm = _llm(cfg, arena, max_slots=32, kv_dtype="bf16")
+    static = llm.generate_ids(prompts, max(budgets))
+    ragged = llm.generate_ragged(prompts, budgets)
+    assert ragged == [t[:n] for t, n in zip(static, budgets)]
+    assert llm.generate_ragged(prompts, budgets) == ragged          # second call: every step graph comes from the cache
+
+
 def test_config5_clone_length_prompts_through_the_prefill_gemm(full_llm, full_llm_oracle):
     """configs[4]'s prefill shape: 8 voice-clone prompts of ~460 tokens (text + 32 global + ~300 semantic prompt tokens)
     = 3672+ rows -> k_pgemm with ragged lengths; every row equals its B = 1 run and two rows equal the CPU oracle."""
