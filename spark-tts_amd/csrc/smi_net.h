@@ -39,13 +39,17 @@ struct ConvP {
   int halo_l, xw;       // left halo, staged row width (floats)
   int istr;             // input stride of a strided Conv1d (1 otherwise): output q reads x[q * istr + tap]
   float out_scale;
+  int fast_sin;         // Snake with the hardware sine (layers on the bf16-split pipe)
   int ntaps[kMaxPhases];
   int off[kMaxPhases][kMaxTaps];
   long long wphase[kMaxPhases];  // float offset of each phase's weights
 };
 
-__device__ __forceinline__ float snake_f(float x, float a) {
-  const float s = sinf(a * x);
+// fast: the hardware sine (v_sin_f32 on x / 2 pi, ~1e-6 absolute) -- the layers of the bf16-split pipe, whose products already
+// carry 2^-17 relative error; the library sine costs ~2500 of the ~4000 vector instructions a thread of a conv block issues
+// (32 Snake values per thread), which is what bounded the one-tap layers and a third of the 7-tap ones.
+__device__ __forceinline__ float snake_f(float x, float a, bool fast) {
+  const float s = fast ? __sinf(a * x) : sinf(a * x);
   return x + (1.0f / (a + 1e-9f)) * (s * s);
 }
 __device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -87,6 +91,7 @@ __device__ __forceinline__ void conv_finish(const ConvP& p, f32x16 (&acc)[QB], f
   constexpr int NREG = KS ? 4 : 16, GRP = KS ? 4 : 8;
   const bool hb = p.bias != nullptr, hbb = p.bbias != nullptr, hg = p.gamma != nullptr, hbe = p.beta != nullptr, hr = p.R != nullptr,
              hs = p.Ys != nullptr;
+  const bool fsin = p.fast_sin != 0;
   const float* dummy = p.X;                       // any readable floats: index < Cout <= the first activation row's size
   const float* pb = hb ? p.bias : dummy;
   const float* pbb = hbb ? p.bbias + (long long)b * p.Cout : dummy;
@@ -136,7 +141,7 @@ __device__ __forceinline__ void conv_finish(const ConvP& p, f32x16 (&acc)[QB], f
         if (qok[qb] && cok[i]) {
           const long long o = yboff + (long long)co[i] * p.ystride + tq[qb];
           if (p.Y) p.Y[o] = y;
-          if (hs) p.Ys[o] = snake_f(y, av[i]);
+          if (hs) p.Ys[o] = snake_f(y, av[i], fsin);
         }
       }
     }
@@ -799,6 +804,7 @@ Launch make_conv_w(const std::string& name, const float* W, const float* bias,
   p.Cin = Cin; p.CinP = pad8(Cin); p.Cout = Cout; p.S = S; p.act = act;
   p.xstride = xstride; p.ystride = ystride; p.xb = xb; p.yb = yb;
   p.out_scale = 1.0f;
+  { const char* e = getenv("SPARKMI_SNAKE_SINF"); p.fast_sin = bf && !(e && e[0] == '1'); }   // SPARKMI_SNAKE_SINF=1: library sine everywhere (A/B)
   p.istr = istr; p.olens = olens;
   for (int r = 0; r < S; ++r) {
     p.ntaps[r] = g.ntaps[r];
