@@ -325,8 +325,14 @@ __device__ __forceinline__ void split2x8(const float (&v)[8], uint4& hi, uint4& 
   mid = make_uint4(m[0], m[1], m[2], m[3]);
 }
 
+// four waves per SIMD (<= 128 VGPRs; the kernels needed 112-134: no spill at 4, 100-220 bytes of scratch at 5).  PMC said the waves
+// of these kernels are parked at s_waitcnt / s_barrier half of their cycles; a fourth resident wave covers more of that than deeper
+// software pipelining did (A/B as separate builds, one box: vocoder batch 32 31.0 -> 29.8 ms, 8 prompt encodes 27.6 -> 27.2 ms).
+#ifndef SMI_CB_OCC
+#define SMI_CB_OCC 4
+#endif
 template <int QB, bool KS, int CHG, int NC>
-__global__ __launch_bounds__(256) void k_convb(ConvP p) {
+__global__ __launch_bounds__(256, SMI_CB_OCC) void k_convb(ConvP p) {
   static_assert(!KS || CHG % 2 == 0, "channel-split waves own whole 16-channel steps");
   constexpr int kCh = 32 * CHG;        // channels per staged chunk (four waves x CHG octets)
   constexpr int NOCT = 4 * CHG;        // octets per chunk
