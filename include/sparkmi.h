@@ -129,7 +129,13 @@ int smi_llm_get_tokens(smi_llm* h, int64_t* out_host, int32_t* lens_host, int ca
  * prefills n new prompts into free slots (returned in slots_out) and emits their first token without
  * touching the live sequences; smi_llm_decode then steps every live sequence; smi_llm_slot_tokens reads one
  * sequence's tokens so far and whether it has produced eos; smi_llm_retire frees its slot.  A sequence's
- * tokens do not depend on what else is live (rows are independent in every kernel). */
+ * DECODE steps do not depend on what else is live: rows are independent in every decode kernel and every decode path
+ * (row-grouped GEMMs, one-row engine) sums a row in the same order -- bit for bit.  Its PROMPT rows run through the
+ * kernel the call's total prompt rows select (row-grouped GEMMs or the prefill GEMM, smi_llm.hip: pg_min), whose fp32
+ * sums associate differently: with an f32 KV cache the tokens are still identical (tested at full size); with the bf16
+ * cache a last-bit difference can move a K/V element to the neighbouring bf16 value, so a greedy arg-max whose top two
+ * logits are closer than ~1e-2 may resolve differently between two batch compositions (about 1 token in 80 at 0.5B
+ * with synthetic weights; tests/test_fullsize_gpu.py bounds the rate and checks each flip sits on such a tie). */
 int smi_llm_session_begin(smi_llm* h, const int64_t* eos_ids_host, int n_eos, void* stream);
 int smi_llm_admit(smi_llm* h, const int64_t* ids_host, const int32_t* lens_host, int n, int P_max, int32_t* slots_out, void* stream);
 int smi_llm_retire(smi_llm* h, int slot, void* stream);
@@ -152,7 +158,8 @@ int smi_llm_kv_pages(smi_llm* h, int32_t* total, int32_t* free_pages);
 /* Per-kernel timing probe used by bench.py: launches ONLY the named decode-step kernel of `layer`
  * `iters` times on `stream` (inputs are whatever the scratch holds), bracketed by HIP events, and
  * returns the average milliseconds per launch.  kernel: 0 qkv, 1 attn, 2 o_proj, 3 gate_up,
- * 4 down, 5 lm_head, 6 finalize, 7 = the whole decode step (graph or eager as configured).
+ * 4 down, 5 lm_head, 6 finalize, 7 = the whole decode step (graph or eager as configured), 8 = all layers of one step
+ * (one launch of the one-row engine where it applies, else the layer kernels in order; needs a new prefill afterwards).
  * 16 + k (k = 0..4): layer kernel k timed in sequence -- (iters whole layers) minus (the same layers
  * without k) -- so that it finds the L2 state its producers leave, as inside the decode graph. */
 int smi_llm_time_kernel(smi_llm* h, int kernel, int layer, int iters, float* ms_avg, void* stream);
@@ -160,6 +167,32 @@ int smi_llm_time_kernel(smi_llm* h, int kernel, int layer, int iters, float* ms_
  * s_memrealtime phase stamps; out[0..7) = mean over blocks of (stamp i - earliest stamp 0) in microseconds,
  * out[7] = shader clock in MHz (tools/stamps.py).  Needs a started generation. */
 int smi_llm_debug_stamps(smi_llm* h, int kernel, int layer, double* out);
+/* One-row decode engine (csrc/smi_eng.h).  With ONE live sequence in slot 0 (bf16 KV, contiguous cache, contexts up to
+ * 1024 tokens) the layers of a decode step run as one persistent launch -- one workgroup per CU, weights streamed through
+ * LDS rings by LDS-DMA, the five all-to-all edges of a layer handed over inside the launch -- instead of four dependent
+ * launches per layer; the arithmetic (every product, accumulator chain and addition order) is the launch path's, so the
+ * tokens are the same bits.  Built at create when config and device fit (SPARKMI_ENGINE=0: never).
+ *   smi_llm_engine: *enabled = 1 when one-row steps take the engine; info[4] = {CUs, images per wave and layer, LDS bytes,
+ *                   built}; why = a one-line reason / description.
+ *   smi_llm_set_engine: runtime switch between the engine and the launch path (A/B, tests); synchronises the device.
+ *   smi_llm_engine_plan: host-only check of the static work plan for `ncu` CUs (no GPU call): every weight image placed
+ *                   exactly once, stream order = job order; stats[8] = {images per wave max, per wave and phase max, parts per
+ *                   CU and phase max, jobs per wave max, images per CU min, max, LDS bytes, images per layer}.
+ *   smi_llm_engine_stamps: diagnostics, SPARKMI_ENGINE_STAMPS=1: out[2][layers][8] microseconds of the last engine launch
+ *                   (CU 0 and the first head CU, after the hand-offs h, q|k|v, attention, h_mid, act).
+ * A hand-off that does not complete within SPARKMI_ENGINE_TIMEOUT_MS (default 500) ends the launch; the next call that
+ * synchronises (smi_llm_get_tokens / _status / _all_done) returns SMI_EHIP. */
+int smi_llm_engine(smi_llm* h, int32_t* enabled, int32_t* info, char* why, int n);
+int smi_llm_set_engine(smi_llm* h, int on);
+int smi_llm_engine_plan(const smi_llm_cfg* cfg, int ncu, int32_t* stats);
+int smi_llm_engine_stamps(smi_llm* h, double* out, int cap);
+/* Tests: synchronises and copies the residual row (hidden_size floats) of row 0 as the last step left it. */
+int smi_llm_debug_hidden(smi_llm* h, float* out_host, int n);
+/* Tests / debugging: synchronises and copies one scratch buffer as raw bytes.  what: 0 q [q_dim] f32, 1 / 2 / 3 the operand
+ * triples of o_proj / down_proj / the next norm ([K / 32][3][4][16 B] at one row), 4 the residual row, 5 the engine's
+ * granules [2][per buffer] u64 {tag << 32 | f32 bits}, 6 partial sums of squares [hidden / 4], 7 K rows of layer 0, slot 0,
+ * kv head 0 (bf16), 8 h + o_proj of the fused one-row path. */
+int smi_llm_debug_read(smi_llm* h, int what, void* out_host, size_t cap, size_t* got);
 
 /* ------------------------------------------------------------------------------------------
  * Vocoder: BiCodec.detokenize (codebook lookup, d-vector, ConvNeXt prenet, WaveGenerator).

@@ -491,6 +491,7 @@ struct smi_enc {
     std::map<std::string, Stage> stages;
     int frames = 0;
     unsigned long long used = 0;
+    hipStream_t last = nullptr; bool launched = false;   // the stream of its last launch: synchronised before the exec is destroyed
   };
   std::map<std::pair<int, int>, Graph> graphs;
   std::map<std::pair<int, int>, int> seen;   // a shape is captured at its second occurrence: traffic whose shapes never repeat runs eagerly
@@ -657,7 +658,11 @@ int smi_enc_destroy(smi_enc* h) {
   if (h->lens_dev) (void)hipFree(h->lens_dev);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
-  for (auto& kv : h->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+  for (auto& kv : h->graphs)
+    if (kv.second.exec) {
+      if (kv.second.launched) (void)hipStreamSynchronize(kv.second.last);   // an exec is never destroyed while a launch of it may be running
+      (void)hipGraphExecDestroy(kv.second.exec);
+    }
   if (h->gev0) (void)hipEventDestroy(h->gev0);
   if (h->gev1) (void)hipEventDestroy(h->gev1);
   if (h->gstream) (void)hipStreamDestroy(h->gstream);
@@ -992,6 +997,7 @@ int smi_enc_forward(smi_enc* h, const float* wav_dev, int n_samples, const float
       auto old = h->graphs.begin();
       for (auto j = h->graphs.begin(); j != h->graphs.end(); ++j) if (j->second.used < old->second.used) old = j;
       SMI_HIP(hipStreamSynchronize(run));
+      if (old->second.launched && old->second.last != run) SMI_HIP(hipStreamSynchronize(old->second.last));   // it may have last run on another caller's stream
       if (old->second.exec) (void)hipGraphExecDestroy(old->second.exec);
       h->graphs.erase(old);
     }
@@ -1022,6 +1028,7 @@ int smi_enc_forward(smi_enc* h, const float* wav_dev, int n_samples, const float
   }
   it->second.used = ++h->tick;
   SMI_HIP(hipGraphLaunch(it->second.exec, run));
+  it->second.last = run; it->second.launched = true;
   const int T = it->second.frames;
   SMI_HIP(hipMemcpyAsync(sem_dev, out_sem, (size_t)T * 8, hipMemcpyDeviceToDevice, run));
   SMI_HIP(hipMemcpyAsync(glob_dev, out_glob, (size_t)c.spk_tokens * 4, hipMemcpyDeviceToDevice, run));

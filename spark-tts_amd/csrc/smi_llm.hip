@@ -2195,7 +2195,7 @@ struct FinP {
   const int* tok;       // non-null: tokens already chosen by k_sample
   const float* pval;
   const int* pidx;
-  int nblk, M, KT;
+  int nblk, M, KT, V;
   RowDesc* rows;
   int64_t* hist;      // [max_steps][kMaxRows]
   int32_t* count;     // [kMaxRows] tokens counted per sequence
@@ -2253,6 +2253,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinP p) {
     for (int w = 1; w < 4; ++w)
       if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
     if (p.tok) bi = p.tok[m];
+    if ((unsigned)bi >= (unsigned)p.V) bi = 0;   // no finite logit (NaN weights / inputs): a defined token instead of an out-of-range embedding row
     tok_s = bi;
     RowDesc rd = p.rows[m];
     const int step = rd.flags;                 // tokens this row has emitted so far
@@ -2274,6 +2275,11 @@ __global__ __launch_bounds__(256) void k_finalize(FinP p) {
   __syncthreads();
   if (wave == 0) embed_row(p.Wlm, p.KT, tok_s, m, p.M, p.gamma0, p.h, p.xs, p.sspart, p.npart, lane);
 }
+
+}  // namespace
+#include "smi_eng.h"        // the one-row decode engine: all layers of a step in one persistent launch
+#include "smi_eng_host.h"
+namespace {
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -2385,6 +2391,7 @@ struct smi_llm {
   int gu1_lo;           // rows from which (up to 16) gate_up runs the one-batch, three-tile shape with one m-tile (SPARKMI_GU1_LO; default 4)
   int gu1_rows;         // rows up to which gate_up runs its one-batch, three-tile shape (SPARKMI_GU1_ROWS; default 32)
   hipGraphExec_t graph; int graph_B, graph_seg, graph_ident;   // the step graph in use (owned by graph_cache)
+  hipStream_t graph_stream; int graph_launched;                // stream of the last replay (drained before execs are destroyed)
   // One captured decode step per (row count, context segments, slots-are-rows): in-flight batching changes the row count at
   // every admission / retirement, and re-capturing the ~100-node step each time cost more than the steps saved.  Everything
   // else a step reads is device data (row descriptors, stop ids, seed) or fixed at create; the sampler's parameters and the
@@ -2393,6 +2400,8 @@ struct smi_llm {
   hipEvent_t ev0, ev1;
   // host staging
   std::vector<RowDesc> host_rows;
+  EngState eng;         // one-row decode engine (smi_eng.h); eng.enabled = 0: the launch path everywhere
+  int eng_on;           // runtime switch (smi_llm_set_engine; SPARKMI_ENGINE=0 at create)
 };
 
 namespace {
@@ -2429,6 +2438,8 @@ int pages_ensure(smi_llm* L, const int* slots, const int* tokens, int n, hipStre
 }
 KvMap kv_map(const smi_llm* L) { return KvMap{L->paged ? L->ptab : nullptr, L->pshift, L->ppslot}; }
 void graphs_flush(smi_llm* L) {
+  // an exec is never destroyed while a launch of it may still be running: the stream of the last replay drains first
+  if (L->graph_launched) { (void)hipStreamSynchronize(L->graph_stream); L->graph_launched = 0; }
   for (auto& kv : L->graph_cache) if (kv.second) (void)hipGraphExecDestroy(kv.second);
   L->graph_cache.clear();
   L->graph = nullptr;
@@ -2542,6 +2553,128 @@ const unsigned char* sec(const smi_llm* L, int s, int layer) {
 void* kv_layer(const smi_llm* L, void* base, int layer) {
   const size_t esz = L->cfg.kv_dtype ? 4 : 2;
   return (unsigned char*)base + (size_t)layer * L->kv_layer_elems * esz;
+}
+
+// ---- one-row decode engine (smi_eng.h): build at create, launch in place of the 4 x layers launches of a one-row step
+void eng_destroy(smi_llm* L) {
+  EngState& E = L->eng;
+  void* ptrs[] = {E.plan, E.stream, E.gran, E.words, E.stamps};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  E.plan = nullptr; E.stream = nullptr; E.gran = nullptr; E.words = nullptr; E.stamps = nullptr; E.enabled = 0;
+}
+
+// Not an error when the engine does not apply (other KV type, paged cache, odd shapes, small device): `why` says so and the
+// launch path is used.  An allocation failure IS reported.
+int eng_create(smi_llm* L) {
+  EngState& E = L->eng;
+  const smi_llm_cfg& c = L->cfg;
+  E.enabled = 0;
+  auto skip = [&](const char* m) { snprintf(E.why, sizeof(E.why), "%s", m); return SMI_OK; };
+  { const char* e = getenv("SPARKMI_ENGINE"); if (e && e[0] == '0') return skip("SPARKMI_ENGINE=0"); }
+  if (c.kv_dtype != 0) return skip("f32 KV cache");
+  if (L->paged) return skip("paged KV cache");
+  if (L->tune[0] || L->tune[1] || L->tune[2] || L->tune[3]) return skip("SPARKMI_TUNE set");
+  int dev = 0, ncu = 0;
+  SMI_HIP(hipGetDevice(&dev));
+  SMI_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+  { const char* e = getenv("SPARKMI_ENGINE_CUS"); if (e && atoi(e) > 0 && atoi(e) <= ncu) ncu = atoi(e); }
+  EngPlanHost P;
+  char why[128];
+  if (!eng_build_plan(L->H, L->Q, L->KV, L->I, c.num_heads, ncu, P, why, sizeof(why))) return skip(why);
+  const EngLds lds = eng_lds(L->H, P.g.KT[EPH_DOWN], P.g.KT[EPH_QKV] > P.g.KT[EPH_O] ? P.g.KT[EPH_QKV] : P.g.KT[EPH_O]);
+  if (lds.total > 160 * 1024 - 512) return skip("LDS image too large");
+  E.ncu = ncu; E.maxlen = P.maxlen; E.lds = lds.total;
+  E.gran_per_buf = 2 * L->H + (L->Q + 2 * L->KV) + L->Q + L->I;
+  { const char* e = getenv("SPARKMI_ENGINE_TIMEOUT_MS"); const double ms = e ? atof(e) : 500.0; E.timeout_ticks = (unsigned)((ms > 1.0 ? ms : 1.0) * 1e5); }
+  const size_t ncw = (size_t)ncu * kEngWaves;
+  const size_t stream_bytes = (size_t)c.num_layers * ncw * P.maxlen * 1024;
+  uint32_t* desc_dev = nullptr;
+  uint16_t* lens_dev = nullptr;
+  auto oom = [&](const char* what, size_t bytes) {
+    smi_set_error("hipMalloc(engine %s, %zu bytes) failed", what, bytes);
+    if (desc_dev) (void)hipFree(desc_dev);
+    if (lens_dev) (void)hipFree(lens_dev);
+    eng_destroy(L);
+    return SMI_ENOMEM;
+  };
+  if (hipMalloc((void**)&E.plan, P.cu.size() * sizeof(EngCuPlan)) != hipSuccess) return oom("plan", P.cu.size() * sizeof(EngCuPlan));
+  if (hipMalloc((void**)&E.stream, stream_bytes) != hipSuccess) return oom("weight stream", stream_bytes);
+  if (hipMalloc((void**)&E.gran, (size_t)2 * E.gran_per_buf * 8) != hipSuccess) return oom("granules", (size_t)2 * E.gran_per_buf * 8);
+  if (hipMalloc((void**)&E.words, 256) != hipSuccess) return oom("words", 256);
+  if (hipMalloc((void**)&E.stamps, (size_t)2 * c.num_layers * 8 * 8) != hipSuccess) return oom("stamps", (size_t)2 * c.num_layers * 64);
+  if (hipMalloc((void**)&desc_dev, P.desc.size() * 4) != hipSuccess) return oom("descriptors", P.desc.size() * 4);
+  if (hipMalloc((void**)&lens_dev, P.lens.size() * 2) != hipSuccess) return oom("lengths", P.lens.size() * 2);
+  SMI_HIP(hipMemcpy(E.plan, P.cu.data(), P.cu.size() * sizeof(EngCuPlan), hipMemcpyHostToDevice));
+  SMI_HIP(hipMemcpy(desc_dev, P.desc.data(), P.desc.size() * 4, hipMemcpyHostToDevice));
+  SMI_HIP(hipMemcpy(lens_dev, P.lens.data(), P.lens.size() * 2, hipMemcpyHostToDevice));
+  SMI_HIP(hipMemset(E.gran, 0, (size_t)2 * E.gran_per_buf * 8));
+  SMI_HIP(hipMemset(E.words, 0, 256));
+  SMI_HIP(hipMemset(E.stamps, 0, (size_t)2 * c.num_layers * 64));
+  EngPackP pk;
+  memset(&pk, 0, sizeof(pk));
+  pk.desc = desc_dev; pk.lens = lens_dev; pk.maxlen = P.maxlen; pk.ncw = (int)ncw;
+  pk.arena = L->arena; pk.layers_base = L->lay.layers_base; pk.layer_stride = L->lay.layer_stride;
+  const int secs[4] = {SMI_LLM_WQKV, SMI_LLM_WO, SMI_LLM_WGU, SMI_LLM_WD};
+  for (int ph = 0; ph < 4; ++ph) { pk.woff[ph] = L->lay.off[secs[ph]]; pk.KT[ph] = P.g.KT[ph]; pk.NW[ph] = P.g.NW[ph]; pk.wperm[ph] = 0; }
+  pk.wperm[EPH_DOWN] = L->wd_parts;
+  pk.out = (uint4*)E.stream;
+  const size_t imgs = ncw * P.maxlen;
+  hipLaunchKernelGGL(k_eng_pack, dim3((unsigned)((imgs + 3) / 4), (unsigned)c.num_layers), dim3(256), 0, 0, pk);
+  SMI_LAUNCH_CHECK();
+  SMI_HIP(hipDeviceSynchronize());
+  (void)hipFree(desc_dev);
+  (void)hipFree(lens_dev);
+  if (hipFuncSetAttribute((const void*)k_engine, hipFuncAttributeMaxDynamicSharedMemorySize, E.lds) != hipSuccess) {
+    (void)hipGetLastError();
+    eng_destroy(L);
+    return skip("hipFuncSetAttribute(LDS) refused");
+  }
+  snprintf(E.why, sizeof(E.why), "on: %d CUs, %d images per wave and layer at most, %d B of LDS", ncu, P.maxlen, E.lds);
+  E.enabled = 1;
+  return SMI_OK;
+}
+
+// the one-row step the engine stands for: one live sequence in slot 0, contiguous bf16 cache, one context segment
+bool eng_usable(const smi_llm* L, const RowDesc* rows, int M) {
+  return L->eng.enabled && L->eng_on && M == 1 && rows == L->rows && L->identity_slots && !L->paged && L->attn_seg <= 1 && !L->stamps_on;
+}
+
+int eng_launch(smi_llm* L, hipStream_t st) {
+  const EngState& E = L->eng;
+  const smi_llm_cfg& c = L->cfg;
+  EngP p;
+  memset(&p, 0, sizeof(p));
+  p.H = L->H; p.Q = L->Q; p.KV = L->KV; p.I = L->I; p.n_heads = c.num_heads; p.n_kv = c.num_kv_heads; p.layers = c.num_layers;
+  p.max_pos = c.max_positions; p.eps = c.rms_eps;
+  const EngGeom g = eng_geom(L->H, L->Q, L->KV, L->I, c.num_heads);
+  for (int ph = 0; ph < 4; ++ph) { p.KT[ph] = g.KT[ph]; p.NW[ph] = g.NW[ph]; }
+  p.plan = E.plan; p.stream = E.stream; p.maxlen = E.maxlen; p.ncu = E.ncu;
+  p.arena = L->arena; p.layers_base = L->lay.layers_base; p.layer_stride = L->lay.layer_stride;
+  p.off_ln1 = L->lay.off[SMI_LLM_LN1]; p.off_bqkv = L->lay.off[SMI_LLM_BQKV]; p.off_ln2 = L->lay.off[SMI_LLM_LN2];
+  p.final_norm = (const float*)(L->arena + L->lay.off[SMI_LLM_FINAL_NORM]);
+  p.rope = (const float2*)(L->arena + L->lay.off[SMI_LLM_ROPE]);
+  p.rows = L->rows; p.h = L->h; p.ss_in = L->sspart; p.xs_out = L->xs_h; p.ss_out = L->sspart;
+  p.kcache = (uint16_t*)L->kcache; p.vcache = (uint16_t*)L->vcache; p.kv_layer_elems = L->kv_layer_elems;
+  p.gran = E.gran; p.serial = E.words; p.err = E.words + 4; p.arrive = E.words + 8;
+  p.timeout_ticks = E.timeout_ticks;
+  p.stamps = getenv("SPARKMI_ENGINE_STAMPS") ? E.stamps : nullptr;
+  hipLaunchKernelGGL(k_engine, dim3(E.ncu), dim3(kEngBlock), E.lds, st, p);
+  SMI_LAUNCH_CHECK();
+  return SMI_OK;
+}
+
+// After a stream synchronisation: did an engine launch give up on a hand-off?  (bounded spins, smi_eng_comm.h)
+int eng_check(smi_llm* L) {
+  if (!L->eng.enabled) return SMI_OK;
+  unsigned e[2] = {0, 0};
+  SMI_HIP(hipMemcpy(e, L->eng.words + 4, 8, hipMemcpyDeviceToHost));
+  if (e[0] == 0) return SMI_OK;
+  SMI_HIP(hipMemset(L->eng.words + 4, 0, 8));
+  L->started = 0;
+  smi_set_error("decode engine: a hand-off timed out (layer %u, edge %u) -- are all %d CUs free for this stream?  SPARKMI_ENGINE=0 selects the launch path",
+                (e[1] - 1) / 8, (e[1] - 1) % 8, L->eng.ncu);
+  return SMI_EHIP;
 }
 
 enum { KQKV = 0, KATTN, KO, KGU, KD, KLM, KFIN };
@@ -2739,7 +2872,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
         SMI_LAUNCH_CHECK();
         f.tok = L->tok;
       }
-      f.pval = L->pval; f.pidx = L->pidx; f.M = M; f.KT = L->KTh;
+      f.pval = L->pval; f.pidx = L->pidx; f.M = M; f.KT = L->KTh; f.V = c.vocab_size;
       f.nblk = lm_blocks_for(L, M);
       f.rows = L->rows; f.hist = L->hist; f.count = L->count; f.finished = L->finished; f.step = L->step;
       f.ctl = L->ctl; f.Wlm = (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0); f.h = L->h; f.max_steps = L->max_steps;
@@ -2882,7 +3015,9 @@ int launch_layers(smi_llm* L, const RowDesc* rows, int M, bool kv_only_last, hip
 
 int launch_step(smi_llm* L, int M, hipStream_t st) {
   int rc;
-  if ((rc = launch_layers(L, L->rows, M, false, st))) return rc;
+  if (eng_usable(L, L->rows, M)) {   // one live row: all layers in one persistent launch (smi_eng.h), same bits
+    if ((rc = eng_launch(L, st))) return rc;
+  } else if ((rc = launch_layers(L, L->rows, M, false, st))) return rc;
   if ((rc = launch_one(L, KLM, 0, L->rows, M, nullptr, st))) return rc;
   return launch_one(L, KFIN, 0, L->rows, M, nullptr, st);
 }
@@ -2962,6 +3097,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   { const char* e = getenv("SPARKMI_WD_PLAIN"); L->wd_parts = !(e && e[0] && e[0] != '0'); }
   L->pf_tiles = nullptr; L->pf_tiles_cap = 0; L->pf_ntiles = 0;
   { const char* e = getenv("SPARKMI_ATTN_PF2"); L->attn_pf2 = !(e && e[0] == '0'); }
+  L->graph_stream = nullptr; L->graph_launched = 0;
   L->graph = nullptr; L->graph_B = 0; L->graph_seg = 1; L->graph_ident = 1; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->ctl = nullptr; L->admit_seq = 0; memset(&L->hctl, 0, sizeof(L->hctl));
   L->session = 0; L->identity_slots = 1; L->attn_seg = 1; L->apart = nullptr; L->apart_floats = 0; memset(L->slot_busy, 0, sizeof(L->slot_busy)); memset(L->slot_len, 0, sizeof(L->slot_len));
   const size_t esz = cfg->kv_dtype ? 4 : 2;
@@ -3035,6 +3171,11 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
     smi_llm_destroy(L);
     return SMI_EHIP;
   }
+  L->eng_on = 1;
+  {
+    const int rce = eng_create(L);
+    if (rce) { smi_llm_destroy(L); return rce; }
+  }
   *out = L;
   return SMI_OK;
 }
@@ -3042,6 +3183,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
 int smi_llm_destroy(smi_llm* L) {
   if (!L) return SMI_OK;
   graphs_flush(L);
+  eng_destroy(L);
   void* ptrs[] = {L->h, L->qbuf, L->xs_h, L->xs_attn, L->xs_act, L->sspart, L->part_o, L->h2, L->rows, L->plan, L->pf_tiles, L->pval, L->pidx, L->hist,
                   L->count, L->finished, L->step, L->ctl, L->ptab, L->kcache, L->vcache, L->logits, L->tok, L->cand_v, L->cand_i, L->cand_n, L->stamps, L->bh, L->bq, L->bxs_h, L->bxs_attn, L->bxs_act, L->bss, L->apart};
   for (void* q : ptrs)
@@ -3073,9 +3215,9 @@ int smi_llm_set_sampling(smi_llm* L, int do_sample, float temperature, int top_k
 
 // Runs every prompt token but each sequence's last through the layers (K/V appended at slots[b]) and leaves the n
 // "last prompt token" rows at L->plan + *tail_off (device) and in L->host_rows (host) for the first step.
-static int prefill_prompts(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, int P_max, const int32_t* slots,
-                           size_t* tail_off, hipStream_t st) {
-  size_t total = 0;
+// Argument checks of a prefill / admission, made BEFORE anything of the handle's state (KV pages, sequence numbers, the
+// `started` flag) is touched: a call that fails here changes nothing.
+static int validate_prompts(const smi_llm* L, const int64_t* ids, const int32_t* lens, int B, int P_max) {
   for (int b = 0; b < B; ++b) {
     SMI_REQUIRE(lens[b] >= 1 && lens[b] <= P_max, "smi_llm_prefill: lens[%d]=%d outside 1..%d", b, lens[b], P_max);
     SMI_REQUIRE(lens[b] < L->cfg.max_positions, "smi_llm_prefill: prompt %d longer than max_positions", b);
@@ -3083,8 +3225,15 @@ static int prefill_prompts(smi_llm* L, const int64_t* ids, const int32_t* lens, 
       const int64_t id = ids[(size_t)b * P_max + t];
       SMI_REQUIRE(id >= 0 && id < L->cfg.vocab_size, "smi_llm_prefill: token id %lld out of range", (long long)id);
     }
-    total += lens[b] - 1;
   }
+  return SMI_OK;
+}
+
+static int prefill_prompts(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, int P_max, const int32_t* slots,
+                           size_t* tail_off, hipStream_t st) {
+  size_t total = 0;
+  { const int rcv = validate_prompts(L, ids, lens, B, P_max); if (rcv) return rcv; }
+  for (int b = 0; b < B; ++b) total += lens[b] - 1;
   {
     int longest = 0;
     for (int b = 0; b < B; ++b) longest = lens[b] > longest ? lens[b] : longest;
@@ -3168,11 +3317,20 @@ int smi_llm_prefill(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, 
   hipStream_t st = (hipStream_t)stream;
   int32_t slots[kMaxRows];
   for (int b = 0; b < kMaxRows; ++b) slots[b] = b;
+  { const int rcv = validate_prompts(L, ids, lens, B, P_max); if (rcv) return rcv; }   // nothing touched yet
+  SMI_REQUIRE(n_eos >= 0 && n_eos <= SMI_MAX_EOS && (n_eos == 0 || eos_ids), "eos list: 0..%d ids", SMI_MAX_EOS);
   if (L->paged) {   // a new generation: every page back to the pool, then what the prompts need
+    // the demand is checked against the WHOLE pool first (everything is about to be free), so a prompt set that cannot fit
+    // fails here with the previous generation's pages, table and `started` flag untouched
+    long need = 0;
+    for (int b = 0; b < B; ++b) need += (lens[b] + (1 << L->pshift) - 1) >> L->pshift;
+    if (need > L->cfg.kv_pages) {
+      smi_set_error("KV page pool too small for these prompts: %ld pages of %d tokens needed, the pool has %d", need, 1 << L->pshift, L->cfg.kv_pages);
+      return SMI_ENOMEM;
+    }
     for (int b = 0; b < kMaxRows; ++b) pages_release(L, b);
-    for (int b = 0; b < B; ++b) SMI_REQUIRE(lens[b] >= 1 && lens[b] < L->cfg.max_positions, "smi_llm_prefill: lens[%d]=%d", b, lens[b]);
     int rcp = pages_ensure(L, slots, lens, B, st);
-    if (rcp) return rcp;
+    if (rcp) { L->started = 0; return rcp; }   // (cannot happen after the check above; the old generation is gone by now)
   }
   for (int b = 0; b < B; ++b) L->plen[b] = lens[b];
   for (int b = 0; b < kMaxRows; ++b) L->hctl.seqid[b] = b;
@@ -3190,9 +3348,13 @@ int smi_llm_prefill(smi_llm* L, const int64_t* ids, const int32_t* lens, int B, 
   size_t tail = 0;
   int rc;
   if ((rc = prefill_prompts(L, ids, lens, B, P_max, slots, &tail, st))) { L->started = 0; return rc; }
-  SMI_HIP(hipMemcpyAsync(L->rows, L->plan + tail, kMaxRows * sizeof(RowDesc), hipMemcpyDeviceToDevice, st));
-  if ((rc = launch_embed(L, L->rows, B, st))) return rc;
-  return launch_step(L, B, st);
+  if (hipMemcpyAsync(L->rows, L->plan + tail, kMaxRows * sizeof(RowDesc), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+    L->started = 0;
+    smi_set_error("smi_llm_prefill: copying the first step's rows failed");
+    return SMI_EHIP;
+  }
+  if ((rc = launch_embed(L, L->rows, B, st)) || (rc = launch_step(L, B, st))) { L->started = 0; return rc; }
+  return SMI_OK;
 }
 
 // ---- continuous batching: sequences join (admit) and leave (retire) between decode steps ----
@@ -3253,18 +3415,24 @@ int smi_llm_admit(smi_llm* L, const int64_t* ids, const int32_t* lens, int n, in
   for (int sl = 0; sl < L->cfg.max_slots && k < n; ++sl)
     if (!L->slot_busy[sl]) slots[k++] = sl;
   SMI_REQUIRE(k == n, "smi_llm_admit: no free KV slot");
-  if (L->paged) {
-    for (int b = 0; b < n; ++b) SMI_REQUIRE(lens[b] >= 1 && lens[b] < L->cfg.max_positions, "smi_llm_admit: lens[%d]=%d", b, lens[b]);
-    if ((rc = pages_ensure(L, slots, lens, n, st))) return rc;   // all or nothing: a short pool admits nobody
-  }
-  for (int b = 0; b < n; ++b) L->hctl.seqid[slots[b]] = L->admit_seq++;
-  SMI_HIP(hipMemcpyAsync(L->ctl, &L->hctl, sizeof(Ctl), hipMemcpyHostToDevice, st));
-  size_t tail = 0;
-  if ((rc = prefill_prompts(L, ids, lens, n, P_max, slots, &tail, st))) {
+  if ((rc = validate_prompts(L, ids, lens, n, P_max))) return rc;   // nothing touched yet
+  if (L->paged && (rc = pages_ensure(L, slots, lens, n, st))) return rc;   // all or nothing: a short pool admits nobody
+  const int seq0 = L->admit_seq;
+  int32_t old_seqid[kMaxRows];
+  for (int b = 0; b < n; ++b) { old_seqid[b] = L->hctl.seqid[slots[b]]; L->hctl.seqid[slots[b]] = L->admit_seq++; }
+  auto undo = [&]() {   // nothing was admitted: sequence numbers and pages as before (the device copy is rewritten by the next admission)
+    for (int b = 0; b < n; ++b) L->hctl.seqid[slots[b]] = old_seqid[b];
+    L->admit_seq = seq0;
     if (L->paged)
-      for (int b = 0; b < n; ++b) pages_release(L, slots[b]);   // nothing was admitted: the pages go back
-    return rc;
+      for (int b = 0; b < n; ++b) pages_release(L, slots[b]);
+  };
+  if (hipMemcpyAsync(L->ctl, &L->hctl, sizeof(Ctl), hipMemcpyHostToDevice, st) != hipSuccess) {
+    undo();
+    smi_set_error("smi_llm_admit: uploading the generation controls failed");
+    return SMI_EHIP;
   }
+  size_t tail = 0;
+  if ((rc = prefill_prompts(L, ids, lens, n, P_max, slots, &tail, st))) { undo(); return rc; }
   // first token of the new sequences: one step over the new rows alone
   int32_t zeros[kMaxRows] = {0};
   for (int b = 0; b < n; ++b) {
@@ -3441,6 +3609,7 @@ int smi_llm_decode(smi_llm* L, int n_steps, void* stream) {
   for (int s = 0; s < n_steps; ++s) {
     if (L->cfg.use_graph) {
       SMI_HIP(hipGraphLaunch(L->graph, st));
+      L->graph_stream = st; L->graph_launched = 1;
     } else if ((rc = launch_step(L, L->B, st))) {
       return rc;
     }
@@ -3457,6 +3626,7 @@ int smi_llm_all_done(smi_llm* L, int* all_done, void* stream) {
   int32_t fin[kMaxRows];
   SMI_HIP(hipMemcpyAsync(fin, L->finished, sizeof(fin), hipMemcpyDeviceToHost, (hipStream_t)stream));
   SMI_HIP(hipStreamSynchronize((hipStream_t)stream));
+  { const int rce = eng_check(L); if (rce) return rce; }
   int d = 1;
   for (int b = 0; b < L->B; ++b) d &= fin[b] != 0;
   *all_done = d;
@@ -3470,7 +3640,7 @@ int smi_llm_status(smi_llm* L, int32_t* count_host, int32_t* finished_host, void
   SMI_HIP(hipMemcpyAsync(count_host, L->count, kMaxRows * 4, hipMemcpyDeviceToHost, st));
   SMI_HIP(hipMemcpyAsync(finished_host, L->finished, kMaxRows * 4, hipMemcpyDeviceToHost, st));
   SMI_HIP(hipStreamSynchronize(st));
-  return SMI_OK;
+  return eng_check(L);
 }
 
 int smi_llm_steps(smi_llm* L) {
@@ -3494,6 +3664,7 @@ int smi_llm_get_tokens(smi_llm* L, int64_t* out, int32_t* lens, int cap, void* s
   SMI_HIP(hipMemcpyAsync(cnt, L->count, sizeof(cnt), hipMemcpyDeviceToHost, st));
   SMI_HIP(hipMemcpyAsync(&step, L->step, 4, hipMemcpyDeviceToHost, st));
   SMI_HIP(hipStreamSynchronize(st));
+  { const int rce = eng_check(L); if (rce) return rce; }
   if (step > L->max_steps) step = L->max_steps;
   std::vector<int64_t> hist((size_t)step * kMaxRows);
   if (step) SMI_HIP(hipMemcpy(hist.data(), L->hist, hist.size() * 8, hipMemcpyDeviceToHost));
@@ -3569,12 +3740,22 @@ int smi_llm_debug_stamps(smi_llm* L, int kernel, int layer, double* out) {
 
 int smi_llm_time_kernel(smi_llm* L, int kernel, int layer, int iters, float* ms_avg, void* stream) {
   SMI_REQUIRE(L && ms_avg && iters > 0, "smi_llm_time_kernel: bad argument");
-  SMI_REQUIRE((kernel >= 0 && kernel <= 7) || (kernel >= 16 && kernel <= 16 + KD), "smi_llm_time_kernel: kernel id %d", kernel);
+  SMI_REQUIRE((kernel >= 0 && kernel <= 8) || (kernel >= 16 && kernel <= 16 + KD), "smi_llm_time_kernel: kernel id %d", kernel);
   if (!L->started) { smi_set_error("smi_llm_time_kernel needs a started generation (prefill first)"); return SMI_ESTATE; }
   if (L->paged && kernel != 7) { smi_set_error("smi_llm_time_kernel: the per-kernel probes need a contiguous KV cache (kv_page_tokens = 0)"); return SMI_ESTATE; }
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (kernel == 7) {
+  if (kernel == 8) {
+    // all layers of one step for the live rows: ONE launch of the one-row engine where it applies, else the layer kernels
+    // back to back (each launch takes the previous one's residual row as its input: the values drift, the timing does not)
+    const bool eng = eng_usable(L, L->rows, L->B);
+    if ((rc = eng ? eng_launch(L, st) : launch_layers(L, L->rows, L->B, false, st))) return rc;
+    SMI_HIP(hipEventRecord(L->ev0, st));
+    for (int i = 0; i < iters; ++i)
+      if ((rc = eng ? eng_launch(L, st) : launch_layers(L, L->rows, L->B, false, st))) return rc;
+    SMI_HIP(hipEventRecord(L->ev1, st));
+    L->started = 0;   // the residual row no longer belongs to the generation
+  } else if (kernel == 7) {
     if ((rc = smi_llm_decode(L, 1, stream))) return rc;  // builds the graph if needed
     SMI_HIP(hipEventRecord(L->ev0, st));
     if ((rc = smi_llm_decode(L, iters, stream))) return rc;
@@ -3643,6 +3824,112 @@ int smi_llm_time_kernel(smi_llm* L, int kernel, int layer, int iters, float* ms_
   float ms = 0.f;
   SMI_HIP(hipEventElapsedTime(&ms, L->ev0, L->ev1));
   *ms_avg = ms / iters;
+  return SMI_OK;
+}
+
+// ---- one-row decode engine (smi_eng.h)
+int smi_llm_engine(smi_llm* L, int32_t* enabled, int32_t* info, char* why, int n) {
+  SMI_REQUIRE(L, "smi_llm_engine: null handle");
+  if (enabled) *enabled = L->eng.enabled && L->eng_on;
+  if (info) { info[0] = L->eng.ncu; info[1] = L->eng.maxlen; info[2] = L->eng.lds; info[3] = L->eng.enabled; }
+  if (why && n > 0) { strncpy(why, L->eng.why, (size_t)n - 1); why[n - 1] = 0; }
+  return SMI_OK;
+}
+
+int smi_llm_set_engine(smi_llm* L, int on) {
+  SMI_REQUIRE(L, "smi_llm_set_engine: null handle");
+  const int v = on ? 1 : 0;
+  if (v != L->eng_on) { SMI_HIP(hipDeviceSynchronize()); graphs_flush(L); }   // captured steps hold one path or the other
+  L->eng_on = v;
+  return SMI_OK;
+}
+
+int smi_llm_engine_plan(const smi_llm_cfg* cfg, int ncu, int32_t* stats) {
+  SMI_REQUIRE(cfg_ok(cfg) && stats, "smi_llm_engine_plan: invalid argument");
+  EngPlanHost P;
+  char why[128] = "";
+  const int Q = cfg->num_heads * cfg->head_dim, KV = cfg->num_kv_heads * cfg->head_dim;
+  if (!eng_build_plan(cfg->hidden_size, Q, KV, cfg->intermediate_size, cfg->num_heads, ncu, P, why, sizeof(why))) {
+    smi_set_error("engine plan: %s", why);
+    return SMI_EINVAL;
+  }
+  // every (matrix, part, chain set, round) exactly once, in a stream whose order matches the jobs
+  long total = 0, want = 0;
+  for (int ph = 0; ph < 4; ++ph) want += (long)P.g.nparts[ph] * P.g.part_imgs[ph];
+  std::vector<unsigned char> seen[4];
+  for (int ph = 0; ph < 4; ++ph) seen[ph].assign((size_t)P.g.nparts[ph] * 4 * 64, 0);
+  for (int c = 0; c < ncu; ++c)
+    for (int w = 0; w < kEngWaves; ++w) {
+      const EngWavePlan& wp = P.cu[c].w[w];
+      size_t i = 0;
+      for (int ph = 0; ph < 4; ++ph)
+        for (int j = wp.jstart[ph]; j < wp.jstart[ph + 1]; ++j) {
+          const EngJob& jb = wp.jobs[j];
+          SMI_REQUIRE(P.cu[c].parts[P.cu[c].pstart[ph] + jb.slot] == jb.part, "engine plan: job slot does not name its part");
+          for (int r = 0; r < jb.nimg; ++r, ++i) {
+            const uint32_t d = P.desc[((size_t)c * kEngWaves + w) * P.maxlen + i];
+            SMI_REQUIRE(d == (((uint32_t)ph << 30) | ((uint32_t)jb.set << 26) | ((uint32_t)r << 16) | jb.part), "engine plan: stream order differs from the job order");
+            unsigned char& f = seen[ph][((size_t)jb.part * 4 + jb.set) * 64 + r];
+            SMI_REQUIRE(r < 64 && !f, "engine plan: image listed twice");
+            f = 1;
+            ++total;
+          }
+        }
+      SMI_REQUIRE(i == wp.len, "engine plan: stream length");
+    }
+  SMI_REQUIRE(total == want, "engine plan: %ld images placed, %ld expected", total, want);
+  const EngLds lds = eng_lds(cfg->hidden_size, P.g.KT[EPH_DOWN], P.g.KT[EPH_QKV] > P.g.KT[EPH_O] ? P.g.KT[EPH_QKV] : P.g.KT[EPH_O]);
+  stats[0] = P.maxlen; stats[1] = P.max_wave_phase_imgs; stats[2] = P.max_slots; stats[3] = P.max_jobs;
+  stats[4] = P.min_load; stats[5] = P.max_load; stats[6] = lds.total; stats[7] = (int32_t)(total);
+  return SMI_OK;
+}
+
+// Tests: the residual row of sequence row 0 as the last step left it (input of the next step's first layer).
+int smi_llm_debug_hidden(smi_llm* L, float* out_host, int n) {
+  SMI_REQUIRE(L && out_host && n >= L->H, "smi_llm_debug_hidden: out holds %d floats, %d needed", n, L ? L->H : 0);
+  SMI_HIP(hipDeviceSynchronize());
+  SMI_HIP(hipMemcpy(out_host, L->h, (size_t)L->H * 4, hipMemcpyDeviceToHost));
+  return eng_check(L);
+}
+
+// Tests / debugging: raw copy of one scratch buffer (what: 0 q [Q] f32, 1 attention operand triples, 2 act triples, 3 h operand
+// triples, 4 h [H] f32, 5 engine granules [2][per buffer] u64, 6 partial sums of squares [H / 4], 7 layer-0 K cache of slot 0
+// head 0, 8 h + o_proj [H] (fused path)); returns the bytes copied in *got.
+int smi_llm_debug_read(smi_llm* L, int what, void* out_host, size_t cap, size_t* got) {
+  SMI_REQUIRE(L && out_host && got, "smi_llm_debug_read: null argument");
+  const void* src = nullptr;
+  size_t n = 0;
+  switch (what) {
+    case 0: src = L->qbuf; n = (size_t)L->Q * 4; break;
+    case 1: src = L->xs_attn; n = (size_t)L->Q * 6; break;
+    case 2: src = L->xs_act; n = (size_t)L->I * 6; break;
+    case 3: src = L->xs_h; n = (size_t)L->H * 6; break;
+    case 4: src = L->h; n = (size_t)L->H * 4; break;
+    case 5: src = L->eng.gran; n = L->eng.gran ? (size_t)2 * L->eng.gran_per_buf * 8 : 0; break;
+    case 6: src = L->sspart; n = (size_t)L->H; break;
+    case 7: src = L->kcache; n = (size_t)L->cfg.max_positions * kHeadDim * 2; break;
+    case 8: src = L->h2; n = (size_t)L->H * 4; break;
+    default: smi_set_error("smi_llm_debug_read: what=%d", what); return SMI_EINVAL;
+  }
+  SMI_REQUIRE(src && n <= cap, "smi_llm_debug_read: buffer %d holds %zu bytes, out holds %zu", what, n, cap);
+  SMI_HIP(hipDeviceSynchronize());
+  SMI_HIP(hipMemcpy(out_host, src, n, hipMemcpyDeviceToHost));
+  *got = n;
+  return SMI_OK;
+}
+
+// Diagnostics (SPARKMI_ENGINE_STAMPS=1): out[2][layers][8] microseconds since the first stamp of the last engine launch:
+// CU 0 and the first head CU after the hand-offs A (h), B (q|k|v), C (attention), D (h_mid), E (act).
+int smi_llm_engine_stamps(smi_llm* L, double* out, int cap) {
+  SMI_REQUIRE(L && out && L->eng.enabled, "smi_llm_engine_stamps: engine not built");
+  const int n = 2 * L->cfg.num_layers * 8;
+  SMI_REQUIRE(cap >= n, "smi_llm_engine_stamps: out holds %d values, %d needed", cap, n);
+  std::vector<unsigned long long> h((size_t)n);
+  SMI_HIP(hipDeviceSynchronize());
+  SMI_HIP(hipMemcpy(h.data(), L->eng.stamps, (size_t)n * 8, hipMemcpyDeviceToHost));
+  unsigned long long t0 = ~0ull;
+  for (int i = 0; i < n; ++i) if (h[i] && h[i] < t0) t0 = h[i];
+  for (int i = 0; i < n; ++i) out[i] = h[i] ? (double)(h[i] - t0) * 0.01 : -1.0;
   return SMI_OK;
 }
 

@@ -83,6 +83,12 @@ SYMBOLS = {
     "smi_llm_kv_pages": (_I, [_VP, _P(C.c_int32), _P(C.c_int32)]),
     "smi_llm_time_kernel": (_I, [_VP, _I, _I, _I, _P(C.c_float), _VP]),
     "smi_llm_debug_stamps": (_I, [_VP, _I, _I, _P(C.c_double)]),
+    "smi_llm_engine": (_I, [_VP, _P(C.c_int32), _P(C.c_int32), C.c_char_p, _I]),
+    "smi_llm_set_engine": (_I, [_VP, _I]),
+    "smi_llm_engine_plan": (_I, [_P(LLMCfg), _I, _P(C.c_int32)]),
+    "smi_llm_engine_stamps": (_I, [_VP, _P(C.c_double), _I]),
+    "smi_llm_debug_hidden": (_I, [_VP, _P(C.c_float), _I]),
+    "smi_llm_debug_read": (_I, [_VP, _I, _VP, _SZ, _P(_SZ)]),
     "smi_voc_arena_count": (_I, [_P(VocCfg)]),
     "smi_voc_arena_entry": (_I, [_P(VocCfg), _I, C.c_char_p, _I, _P(_SZ), _P(_SZ), _P(C.c_int32)]),
     "smi_voc_arena_bytes": (_SZ, [_P(VocCfg)]),

@@ -349,7 +349,42 @@ class SparkLLM:
             self._stream()), "smi_llm_forward_logits")
         return out
 
-    KERNELS = ("qkv", "attn", "o_proj", "gate_up", "down", "lm_head", "finalize", "step")
+    # ------------------------------------------------------------------ one-row decode engine (csrc/smi_eng.h)
+    def engine_info(self) -> dict:
+        """Whether one-row decode steps run as one persistent launch, and why / why not."""
+        on = C.c_int32(0)
+        info = (C.c_int32 * 4)()
+        why = C.create_string_buffer(200)
+        _lib.check(self._lib.smi_llm_engine(self._h, C.byref(on), info, why, 200), "smi_llm_engine")
+        return {"enabled": bool(on.value), "built": bool(info[3]), "cus": int(info[0]), "images_per_wave": int(info[1]),
+                "lds_bytes": int(info[2]), "why": why.value.decode(errors="replace")}
+
+    def set_engine(self, on: bool) -> None:
+        """Runtime switch between the engine and the four-launches-per-layer path (same bits; A/B runs and tests)."""
+        _lib.check(self._lib.smi_llm_set_engine(self._h, 1 if on else 0), "smi_llm_set_engine")
+
+    def engine_stamps(self) -> np.ndarray:
+        """(2, layers, 8) microseconds of the last engine launch (needs SPARKMI_ENGINE_STAMPS=1 in the environment)."""
+        n = 2 * self.cfg.num_hidden_layers * 8
+        out = (C.c_double * n)()
+        _lib.check(self._lib.smi_llm_engine_stamps(self._h, out, n), "smi_llm_engine_stamps")
+        return np.array(out, dtype=np.float64).reshape(2, self.cfg.num_hidden_layers, 8)
+
+    def debug_hidden(self) -> np.ndarray:
+        """The residual row of row 0 as the last step left it (tests)."""
+        out = np.zeros(self.cfg.hidden_size, dtype=np.float32)
+        _lib.check(self._lib.smi_llm_debug_hidden(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), out.size), "smi_llm_debug_hidden")
+        return out
+
+    def debug_read(self, what: int) -> np.ndarray:
+        """Raw bytes of one scratch buffer (include/sparkmi.h: smi_llm_debug_read)."""
+        buf = np.zeros(1 << 22, dtype=np.uint8)
+        got = C.c_size_t(0)
+        _lib.check(self._lib.smi_llm_debug_read(self._h, int(what), buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(got)),
+                   "smi_llm_debug_read")
+        return buf[: got.value].copy()
+
+    KERNELS = ("qkv", "attn", "o_proj", "gate_up", "down", "lm_head", "finalize", "step", "layers")
 
     def time_kernel(self, name: str, iters: int = 48, layer: int = 0, in_sequence: bool = False) -> float:
         """Average milliseconds per launch of one decode-step kernel (HIP events on this stream).

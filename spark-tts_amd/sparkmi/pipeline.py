@@ -132,8 +132,9 @@ class SparkTTS:
     def inference_batch(self, requests: Sequence[dict], temperature: float = 0.8, top_k: float = 50,
                         top_p: float = 0.95, *, do_sample: bool = True, max_new_tokens: int = 3000,
                         seed: Optional[int] = None) -> List[np.ndarray]:
-        """Several independent utterances in one ragged batch (<= max_batch).  Each result equals
-        the single-utterance call for that request (greedy)."""
+        """Several independent utterances in one ragged batch (<= max_batch).  Greedy: each result equals the
+        single-utterance call for that request -- exactly with an f32 KV cache; with the default bf16 cache up to near-tie
+        arg-max flips between the prefill kernels the two call shapes select (include/sparkmi.h, smi_llm_session_begin)."""
         if len(requests) > self._max_batch:
             raise ValueError(f"{len(requests)} requests > max_batch={self._max_batch}")
         prompts, globals_ = [], []

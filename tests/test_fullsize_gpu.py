@@ -14,6 +14,7 @@ from conftest import FULL_MAX_POS
 pytestmark = pytest.mark.gpu
 
 
+TIE_GAPS = []   # gaps of the accepted flips of this session (printed by the tests that bound their number)
 TIE = 2e-2   # logit gap (logit std ~1.6) below which two summation orders may pick different tokens once K/V are rounded to bf16
 
 
@@ -36,6 +37,7 @@ def _assert_same_or_tie(probe, prompt, got, want, what):
     assert {int(top.indices[0]), int(top.indices[1])} == {got[i], want[i]}, f"{what}: token {i} differs and is not a top-2 tie: {got[i]} vs {want[i]}, top {top.indices.tolist()}"
     gap = float(top.values[0] - top.values[1])
     assert gap < TIE, f"{what}: token {i} differs at a logit gap of {gap}"
+    TIE_GAPS.append(gap)
     return False
 
 
@@ -61,7 +63,10 @@ def test_config3_prompts_through_the_prefill_gemm(full_llm, golden_dir, kv):
             same += 1
         else:
             same += _assert_same_or_tie(one, prompts[b], batched[b], solo, f"row {b}")
-    assert same >= 16, f"only {same} of 32 rows identical"   # observed 27: ~1 token in 80 sits on a tie closer than the bf16-KV noise
+    # observed 27 of 32 (round 2, three boxes): ~1 token in 80 sits on a tie closer than the bf16-KV noise; the floor leaves
+    # room for three more such rows, not for a kernel that breaks ten
+    print(f"[{kv}] rows identical {same}/32; gaps of the accepted flips: {sorted(round(g, 5) for g in TIE_GAPS)}")
+    assert same >= 24, f"only {same} of 32 rows identical"
     if kv == "f32":
         assert batched[0] == g["greedy"][:n].tolist()
 

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""One-row decode step at the 0.5B shape with the persistent-layer engine (csrc/smi_eng.h) and with the four launches per
+layer it replaces, on one box (GPU): whole step (graph replay), the layers alone, tokens equal.  SPARKMI_ENGINE_STAMPS=1
+adds the per-edge stamps of the last engine launch."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "spark-tts_amd"))
+import numpy as np
+import torch
+from sparkmi import config as C, weights as W
+from sparkmi.arena import llm_cfg_struct, pack_llm_arena
+from sparkmi.llm import SparkLLM
+
+cfg = C.spark_0p5b_llm()
+MAXPOS = 704
+t0 = time.time()
+arena = torch.from_numpy(pack_llm_arena(cfg, W.SyntheticLLM(cfg), llm_cfg_struct(cfg, 1, MAXPOS, "bf16", True))).to("cuda:0")
+print(f"arena packed in {time.time() - t0:.1f}s", flush=True)
+llm = SparkLLM(cfg, None, "cuda:0", max_positions=MAXPOS, arena=arena)
+print("engine:", llm.engine_info(), flush=True)
+prompt = np.random.Generator(np.random.PCG64(1234)).integers(0, cfg.vocab_size, size=128).tolist()
+res = {}
+for on in (True, False, True, False):
+    llm.set_engine(on)
+    toks = llm.generate_ids([prompt], 150)[0]
+    llm.prefill([prompt]); llm.decode(20)
+    step = llm.time_kernel("step", iters=128) * 1e3
+    llm.prefill([prompt]); llm.decode(20)
+    lay = llm.time_kernel("layers", iters=32) * 1e3
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    llm.generate_ids([prompt], 150)
+    wall = (time.perf_counter() - t0) * 1e3
+    print(f"engine {'on ' if on else 'off'}: step {step:7.1f} us   layers {lay:7.1f} us ({lay / cfg.num_hidden_layers:5.2f} per layer)   "
+          f"150-token generate {wall:6.1f} ms   first tokens {toks[:6]}", flush=True)
+    res[on] = toks
+assert res[True] == res[False], "engine and launch path disagree"
+print("tokens identical over 150 steps")
+if os.environ.get("SPARKMI_ENGINE_STAMPS"):
+    llm.set_engine(True)
+    llm.prefill([prompt]); llm.decode(40)
+    s = llm.engine_stamps()
+    names = ["A h", "B qkv", "C attn", "D h_mid", "E act"]
+    d0, dh = s[0], s[1]
+    print("CU 0   (us after the layer's A):", "  ".join(f"{n} {np.mean(d0[2:, i] - d0[2:, 0]):5.2f}" for i, n in enumerate(names) if i != 1))
+    print("head CU (us after the layer's A):", "  ".join(f"{n} {np.mean(dh[2:, i] - dh[2:, 0]):5.2f}" for i, n in enumerate(names) if i in (0, 1, 3)))
+    print("layer period (CU 0):", float(np.mean(np.diff(d0[2:, 0]))), "us")
