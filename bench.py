@@ -12,9 +12,13 @@ weights) -> BiCodec vocoder.  Workloads:
 
   --batch 1  (default; BASELINE configs[1])  128-token prompt -> 150 tokens -> 48 000 samples (3.0 s)
   --batch 32 (configs[2])  ragged: prompt lengths U{96..160}, N_i U{120..180} tokens per utterance, seeds
-             2000+i; the batch decodes max(N_i) steps, row i keeps its first N_i tokens (a static batch
-             whose rows stop at their own length), the vocoder batch is padded to max(N_i) with per-row
-             lengths.  `--uniform` keeps 32 x (128 -> 150) for comparison with round-1 numbers.
+             2000+i.  Default: in-flight retirement with KNOWN budgets -- row i leaves the batch exactly after
+             its N_i tokens (SparkLLM.generate_ragged, no eos, no status polling), the step runs on the live
+             rows only: the best case of in-flight batching; eos-driven serving (SparkLLM.serve) also pays a
+             host round trip every `decode_stride` steps and up to that many surplus steps per finished row.
+             `--static-batch`: all rows decode max(N_i) steps (a padded static batch).  `config.retire` in the
+             JSON says which was timed.  The vocoder batch is padded to max(N_i) with per-row lengths.
+             `--uniform` keeps 32 x (128 -> 150) for comparison with round-1 numbers.
   --clone --batch 8 (configs[4])  each utterance first encodes a 6 s prompt wav on the GPU.
   --gpus N   one rank per GPU: `value` = the same per-rank loop on every rank (weak scaling, N x the work).
              Started without WORLD_SIZE it spawns the N ranks itself (torch.distributed.run, before any
@@ -294,7 +298,8 @@ def main():
     decode_ms, voc_ms, enc_ms = [], [], []
 
     def run_batch(eng, vocoder, pr, wants, glob_dev, timed=False):
-        """prefill -> decode max(N_i) - 1 steps -> row i keeps its first N_i tokens -> ragged vocoder batch -> host."""
+        """prefill -> decode (ragged budgets: row i retired after its own N_i tokens, known in advance -- no eos polling;
+        --static-batch / equal budgets: max(N_i) - 1 steps on all rows) -> ragged vocoder batch -> host."""
         nmax = max(wants)
         if len(pr) > 1 and min(wants) < nmax and not a.static_batch:
             # ragged budgets: rows are retired as they finish (in-flight batching, SURVEY 8f-4) -- the step runs on the live rows
@@ -378,7 +383,9 @@ def main():
         "config": {"workload": f"Spark-TTS-0.5B, batch={B} greedy, {shape} (BASELINE.json configs[{cfg_idx}])",
                    **({"voice_clone": f"each utterance encodes a {a.prompt_seconds:.1f} s prompt wav on the GPU first (BASELINE.json configs[4])"} if a.clone else {}),
                    "batch_per_gpu": B, "prompt_len": [len(p) for p in prompts] if ragged else P, "new_tokens": want if ragged else N,
-                   "kv_cache": a.kv, "hipgraph": not a.no_graph, "parallelism": f"utterance-parallel x{world} (same per-rank loop on every rank)",
+                   "kv_cache": a.kv, "hipgraph": not a.no_graph,
+                   "retire": ("n/a (one row)" if B == 1 else "static batch: every row decodes max(N_i) steps" if (a.static_batch or min(want) == Nmax)
+                              else "in-flight, oracle budgets: row i retired after exactly N_i tokens, no eos polling"), "parallelism": f"utterance-parallel x{world} (same per-rank loop on every rank)",
                    "device": arch, "build": build_hash()},
         "rtf": el / audio_s, "x_realtime": audio_s / el,
         "utterances_per_s": world * a.steps * B / el,
@@ -465,16 +472,35 @@ def main():
                    "o_proj": kb["o_proj"], "gate_up": kb["gate_up"], "down": kb["down"], "lm_head": kb["lm_head"]}
             count = {k: llm_cfg.num_hidden_layers for k in per}
             count["lm_head"] = 1
+            eng = llm.engine_info() if B == 1 else {"enabled": False}
             ks = []
+            if eng["enabled"]:
+                # one live row: all layers of a step are ONE persistent launch (csrc/smi_eng.h); the launch-path layer kernels
+                # below are what batches run -- probed for comparison, not part of this workload's step
+                llm.prefill(prompts, None)
+                llm.decode(Nmax // 2)
+                ms = llm.time_kernel("layers", iters=48)
+                eb = llm_cfg.num_hidden_layers * (kb["qkv"] + kb["o_proj"] + kb["gate_up"] + kb["down"]) + kvb * (ctx_now + B)
+                ks.append({"kernel": "engine", "what": f"all {llm_cfg.num_hidden_layers} layers of the step, one persistent launch",
+                           "launches_per_step": 1, "in_step": True, "avg_us": ms * 1e3, "bytes": eb,
+                           "GBps": eb / (ms * 1e-3) / 1e9, "us_per_step": ms * 1e3,
+                           "us_per_layer": ms * 1e3 / llm_cfg.num_hidden_layers})
+                llm.prefill(prompts, None)
+                llm.decode(Nmax // 2)
             for name in ("qkv", "attn", "o_proj", "gate_up", "down", "lm_head"):
                 # layer kernels are timed where they run: (96 layers captured in a hipGraph) - (the same graph without
                 # the kernel), so each finds the L2 state its producers leave (idle CUs prefetch part of the next
                 # kernels' weights) and no host launch rate enters; lm_head (50 us) is looped on its own
                 ms = llm.time_kernel(name, iters=96, in_sequence=True) if name != "lm_head" else llm.time_kernel(name, iters=24)
-                ks.append({"kernel": name, "launches_per_step": count[name], "avg_us": ms * 1e3,
-                           "bytes": per[name], "GBps": per[name] / (ms * 1e-3) / 1e9,
-                           "us_per_step": ms * 1e3 * count[name]})
-            dom = max(ks, key=lambda k: k["us_per_step"])
+                in_step = name == "lm_head" or not eng["enabled"]
+                fused = name == "o_proj" and B == 1 and ms * 1e3 < 0.5    # one row: done inside the attention kernel (k_attn<.., FUSE>)
+                ent = {"kernel": name, "launches_per_step": count[name], "in_step": in_step, "avg_us": ms * 1e3,
+                       "bytes": per[name], "GBps": per[name] / (ms * 1e-3) / 1e9,
+                       "us_per_step": ms * 1e3 * count[name]}
+                if fused:   # the leave-one-out difference is noise around zero: no rate
+                    ent.update({"fused": True, "avg_us": 0.0, "GBps": None, "us_per_step": 0.0})
+                ks.append(ent)
+            dom = max((k for k in ks if k["in_step"]), key=lambda k: k["us_per_step"])
             prof, src = pmc_traffic(B)
             traffic = None
             if prof is not None and dom["kernel"] in prof.get("kernels", {}):
@@ -482,6 +508,10 @@ def main():
             res["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
                                "traffic_source": src, "bytes_per_launch": dom["bytes"], "avg_us": dom["avg_us"]}
+            if eng["enabled"]:
+                res["roofline"]["note"] = ("dominant kernel of the one-row step = the persistent-layer engine: algorithmic bytes = "
+                                           "24 layers of weights + KV read / write of this context, over its launch duration")
+            res["engine"] = eng
             res["kernels"] = ks
             # the reference's default mode (temperature 0.8 / top-k 50 / top-p 0.95): decode step with the sampler in the graph
             llm.set_sampling(True, 0.8, 50, 0.95, 1234)
@@ -528,7 +558,10 @@ def main():
             tot_ms = sum(m for _, m, _ in vl)
             tot_fl = sum(f for _, _, f in vl)
             res["vocoder_mfma"] = {"launches": len(vl), "sum_ms": tot_ms, "gflop": tot_fl / 1e9,
-                                   "achieved_TFLOPs": tot_fl / (tot_ms * 1e-3) / 1e12, "peak_TFLOPs": 157.3,
+                                   "achieved_TFLOPs": tot_fl / (tot_ms * 1e-3) / 1e12,
+                                   # fp32-equivalent FLOPs on the bf16 pipe with three bf16 products per fp32 product
+                                   # (w_hi x_hi + w_hi x_mid + w_mid x_hi): peak = 2.5 PFLOP/s dense bf16 / 3
+                                   "peak_TFLOPs": 2500.0 / 3, "peak_note": "bf16 MFMA 2.5 PF dense / 3 split products per fp32 product",
                                    "top": [{"name": n, "ms": m, "TFLOPs": f / (m * 1e-3) / 1e12 if m > 0 else 0}
                                            for n, m, f in sorted(vl, key=lambda x: -x[1])[:6]]}
         else:

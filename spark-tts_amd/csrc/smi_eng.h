@@ -32,15 +32,15 @@ namespace {
 constexpr int kEngWaves = 8, kEngThreads = kEngWaves * 64;   // waves / threads of a workgroup (one per CU)
 constexpr int kEngGather = kEngThreads - 64;                  // threads that sweep hand-offs: the last wave moves weights meanwhile
 constexpr int kEngBlock = kEngThreads;
-constexpr int kEngRing = 14;        // 1-KiB slots per wave
+constexpr int kEngRingTotal = 112;   // 1-KiB slots of a CU's weight ring
 constexpr int kEngMaxSlots = 20;    // 4-row parts per CU and phase
 constexpr int kEngMaxJobs = 16;     // (part, chain set) jobs per wave and layer
-constexpr int kEngMaxParts = 58;    // parts per CU and layer, all phases
+constexpr int kEngMaxParts = 52;    // parts per CU and layer, all phases
 enum { EPH_QKV = 0, EPH_O = 1, EPH_GU = 2, EPH_DOWN = 3 };
 
-struct EngJob { uint16_t part; uint8_t set, nimg; uint16_t slot, pad; };                      // 8 bytes
-struct EngWavePlan { uint16_t jstart[5]; uint16_t len; uint16_t pimg[4]; EngJob jobs[kEngMaxJobs]; };
-struct EngCuPlan { uint16_t pstart[5]; int16_t head; uint16_t parts[kEngMaxParts]; EngWavePlan w[kEngWaves]; };
+struct EngJob { uint16_t part; uint8_t set, nimg; uint16_t slot, goff; };                     // 8 bytes; goff: first image, index in the CU's layer stream
+struct EngWavePlan { uint16_t jstart[5]; uint16_t pad; uint16_t pimg[4]; EngJob jobs[kEngMaxJobs]; };
+struct EngCuPlan { uint16_t pstart[5]; int16_t head; uint16_t parts[kEngMaxParts]; uint16_t len_cu, pad; uint16_t pcount[4]; EngWavePlan w[kEngWaves]; };
 static_assert(sizeof(EngJob) == 8 && sizeof(EngCuPlan) % 4 == 0, "plan layout");
 
 struct EngP {
@@ -48,7 +48,7 @@ struct EngP {
   float eps;
   int KT[4], NW[4];
   const EngCuPlan* plan;
-  const unsigned char* stream;   // [layer][cu][wave][maxlen] 1-KiB images
+  const unsigned char* stream;   // [layer][cu][maxlen] 1-KiB images, a CU's layer share in issue order
   int maxlen, ncu;
   const unsigned char* arena; size_t layers_base, layer_stride, off_ln1, off_bqkv, off_ln2;
   const float* final_norm; const float2* rope;
@@ -62,7 +62,7 @@ struct EngP {
   unsigned* serial; unsigned* err; unsigned* arrive;
   unsigned timeout_ticks;
   unsigned long long* stamps;   // diagnostics: [2][layers][8] or null
-  int lds_xs_act, lds_xs_x;     // bytes of the two operand images
+  int ld_burst, ld_sleep;       // loader pacing: fills per look at the arrival counter, pause (x 64 cycles) between bursts
 };
 
 // ---- LDS carve (bytes), all multiples of 16
@@ -70,7 +70,7 @@ struct EngLds { int ring, xs_act, xs_x, hbuf, ssp, red, plan, total; };
 __host__ __device__ inline EngLds eng_lds(int H, int KTact, int KTx) {
   EngLds l;
   int o = 0;
-  l.ring = o; o += kEngWaves * kEngRing * 1024;
+  l.ring = o; o += kEngRingTotal * 1024;
   int act = KTact * 192;
   const int attn = 16384 + 256 + 2048 + 64 + kEngWaves * 512;   // attention scratch aliases the act image (head CUs have no down parts)
   if (act < attn) act = attn;
@@ -86,8 +86,8 @@ __host__ __device__ inline EngLds eng_lds(int H, int KTact, int KTx) {
 
 // ---- repack: image (cu, wave, i) of layer l = A operand of one MFMA: lane (k8, 4 s + r) holds W[4 part + r][tile(s)][8 k8 .. +8]
 struct EngPackP {
-  const uint32_t* desc;     // [ncu * nwv][maxlen]  phase:2 | set:4 | round:10 | part:16
-  const uint16_t* lens;     // [ncu * nwv]
+  const uint32_t* desc;     // [ncu][maxlen]  phase:2 | set:4 | round:10 | part:16
+  const uint16_t* lens;     // [ncu]
   int maxlen, ncw;
   const unsigned char* arena; size_t layers_base, layer_stride;
   size_t woff[4]; int KT[4], NW[4], wperm[4];
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_eng_pack(EngPackP p) {
   const size_t img = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int layer = blockIdx.y;
   if (img >= (size_t)p.ncw * p.maxlen) return;
-  const int cw = (int)(img / p.maxlen), i = (int)(img % p.maxlen);
+  const int cw = (int)(img / p.maxlen), i = (int)(img % p.maxlen);   // cw: the CU
   if (i >= p.lens[cw]) return;
   const uint32_t d = p.desc[img];
   const int ph = d >> 30, set = (d >> 26) & 15, round = (d >> 16) & 1023, part = d & 0xffff;
@@ -155,8 +155,7 @@ __global__ __launch_bounds__(kEngBlock, 1) void k_engine(EngP p) {
   float4* red = (float4*)(smem + L.red);          // [slot][chain]
   EngCuPlan* pl = (EngCuPlan*)(smem + L.plan);
   unsigned* arrive = (unsigned*)(smem + L.plan + ((int)sizeof(EngCuPlan) + 15) / 16 * 16);   // consumer waves arrived at barriers so far
-  const uint32_t ring_base = (uint32_t)(L.ring + wave * kEngRing * 1024);   // this wave's ring, relative to smem
-  // LDS-DMA takes the ABSOLUTE LDS address in M0: the dynamic segment starts behind the kernel's static LDS (__syncthreads_and's)
+  // LDS-DMA takes the ABSOLUTE LDS address in M0: the dynamic segment starts behind the kernel's static LDS (none today; kept exact)
   typedef __attribute__((address_space(3))) void* lptr_t;
   const uint32_t lbase = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)smem);
 
@@ -166,7 +165,7 @@ __global__ __launch_bounds__(kEngBlock, 1) void k_engine(EngP p) {
   {   // this CU's plan -> LDS
     const uint32_t* src = (const uint32_t*)(p.plan + cu);
     for (int i = tid; i < (int)(sizeof(EngCuPlan) / 4); i += kEngBlock) ((uint32_t*)pl)[i] = src[i];
-    if (tid == 0) *arrive = 0u;
+    if (tid == 0) { arrive[0] = 0u; arrive[1] = 0u; }
   }
   const unsigned serial = *(volatile const unsigned*)p.serial;
   const unsigned tbase = serial * (unsigned)(p.layers * 8 + 16) + 1u;
@@ -188,76 +187,61 @@ __global__ __launch_bounds__(kEngBlock, 1) void k_engine(EngP p) {
   // ---- every barrier of the workgroup goes through bar(): the consumers count their arrivals in LDS first, which is what
   //      the loader watches while it trickles (it joins when the last consumer wave has arrived)
   unsigned bars = 0;   // barriers passed so far (same sequence in all nine waves)
-  auto bar = [&](bool okv) -> bool {
+  // bar_chk (behind a hand-off wait, the only thing that can give up): one barrier, then everybody reads the workgroup's
+  // fail word; bar (behind compute): one barrier.
+  volatile unsigned* failw = arrive + 1;
+  auto bar_chk = [&](bool okv) -> bool {
+    if (!loader && lane == 0) atomicAdd(arrive, 1u);
+    if (!okv) *failw = 1u;
+    ++bars;
+    __syncthreads();
+    return *failw == 0u;
+  };
+  auto bar = [&]() {
     if (!loader && lane == 0) atomicAdd(arrive, 1u);
     ++bars;
-    return __syncthreads_and(okv) != 0;
+    __syncthreads();
   };
-  int consumed = 0;    // consumer: images of this wave's ring consumed so far
 
-  // ---- the loader: images in GLOBAL order (layer, phase, wave, index) -- every wave's own stream order -- as far ahead as the
-  //      rings allow.  Lane w < 8 keeps wave w's counters.
-  const size_t layer_imgs_bytes = (size_t)p.ncu * kEngWaves * (size_t)p.maxlen * 1024;
-  const size_t cu_stream = (size_t)cu * kEngWaves * (size_t)p.maxlen * 1024;
-  int v_iss = 0, v_cons = 0, v_idx = 0;             // lane w: images issued / consumed / index inside the layer's stream
-  int v_pimg[4] = {0, 0, 0, 0};
-  int P_ph[4] = {0, 0, 0, 0}, sumP = 0;             // images per phase and per layer of this CU
-  int cur_layer = 0, cur_phase = 0, cur_wave = 0, cur_i = 0, issued_total = 0;
-  if (loader) {
+  // ---- the weight ring: ONE ring of kEngRingTotal 1-KiB slots per CU, filled in the CU's stream order (layer, phase, wave,
+  //      job, image); image number n (counted over the whole launch) lives in slot n mod kEngRingTotal.  The loader wave
+  //      issues as far ahead as the ring allows; a phase's slots are free again behind the barrier that closes its compute.
+  const int len_cu = __builtin_amdgcn_readfirstlane((int)pl->len_cu);
+  int P_ph[4], pre_ph[4];          // images per phase of this CU, and the running total through each phase
 #pragma unroll
-    for (int ph = 0; ph < 4; ++ph) {
-      v_pimg[ph] = lane < kEngWaves ? (int)pl->w[lane].pimg[ph] : 0;
-      int t = 0;
-      for (int w = 0; w < kEngWaves; ++w) t += (int)pl->w[w].pimg[ph];
-      P_ph[ph] = __builtin_amdgcn_readfirstlane(t);
-      sumP += P_ph[ph];
-    }
+  for (int ph = 0; ph < 4; ++ph) {
+    P_ph[ph] = __builtin_amdgcn_readfirstlane((int)pl->pcount[ph]);
+    pre_ph[ph] = P_ph[ph] + (ph ? pre_ph[ph - 1] : 0);
   }
-  auto ld_pimg = [&](int ph, int w) -> int {
-    const int v = ph == 0 ? v_pimg[0] : ph == 1 ? v_pimg[1] : ph == 2 ? v_pimg[2] : v_pimg[3];
-    return __builtin_amdgcn_readlane(v, w);
-  };
-  auto ld_normalize = [&]() {   // the cursor names the next image to issue (or cur_layer == layers: stream finished)
-    while (cur_layer < p.layers && cur_i >= ld_pimg(cur_phase, cur_wave)) {
-      cur_i = 0;
-      if (++cur_wave == kEngWaves) {
-        cur_wave = 0;
-        if (++cur_phase == 4) { cur_phase = 0; ++cur_layer; v_idx = 0; }
-      }
-    }
-  };
-  auto ld_can = [&]() -> bool {
-    return cur_layer < p.layers && __builtin_amdgcn_readlane(v_iss, cur_wave) - __builtin_amdgcn_readlane(v_cons, cur_wave) < kEngRing;
-  };
+  const unsigned char* cu_stream = p.stream + (size_t)cu * (size_t)p.maxlen * 1024 + lane * 16;
+  const size_t layer_imgs_bytes = (size_t)p.ncu * (size_t)p.maxlen * 1024;
+  int issued_total = 0, consumed_total = 0, is_layer = 0, is_idx = 0;   // loader state (wave-uniform)
+  auto ld_can = [&]() -> bool { return is_layer < p.layers && issued_total - consumed_total < kEngRingTotal; };
   auto ld_issue = [&]() {       // precondition: ld_can()
-    const int w = cur_wave;
-    const int iss = __builtin_amdgcn_readlane(v_iss, w), idx = __builtin_amdgcn_readlane(v_idx, w);
-    const unsigned char* src = p.stream + (size_t)cur_layer * layer_imgs_bytes + cu_stream + ((size_t)w * p.maxlen + idx) * 1024 + lane * 16;
-    smi_glds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lbase + (uint32_t)(L.ring + w * kEngRing * 1024) + (uint32_t)(iss % kEngRing) * 1024)));
-    v_iss += lane == w ? 1 : 0;
-    v_idx += lane == w ? 1 : 0;
-    ++issued_total; ++cur_i;
-    ld_normalize();
+    const unsigned char* src = cu_stream + (size_t)is_layer * layer_imgs_bytes + (size_t)is_idx * 1024;
+    smi_glds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lbase + (uint32_t)L.ring + (uint32_t)(issued_total % kEngRingTotal) * 1024)));
+    ++issued_total;
+    if (++is_idx == len_cu) { is_idx = 0; ++is_layer; }
   };
-  // Until the last consumer wave has arrived at barrier number `bars + 1`: a thin trickle of fills.
+  // Until the last sweeping wave has arrived at barrier number `bars + 1`: keep the ring full (p.ld_burst fills per look
+  // at the arrival counter; a pause of p.ld_sleep x 64 cycles between bursts thins the stream beside the sweeps).
   auto ld_trickle = [&]() {
     const unsigned target = (bars + 1) * (kEngWaves - 1);
     for (unsigned it = 0;; ++it) {
-      const unsigned a = *(volatile unsigned*)arrive;
-      if (a >= target) break;
-      if (ld_can()) { ld_issue(); if (ld_can()) ld_issue(); }
-      __builtin_amdgcn_s_sleep(1);
-      if ((it & 1023u) == 1023u && __builtin_amdgcn_s_memrealtime() > sy.t_end + 100000000ull) break;   // (the consumers' spins are bounded; this bounds the loader's too)
+      if (*(volatile unsigned*)arrive >= target) break;
+      if (len_cu > 0) for (int b = 0; b < p.ld_burst && ld_can(); ++b) ld_issue();
+      if (p.ld_sleep > 0 || !ld_can()) __builtin_amdgcn_s_sleep(1);
+      for (int z = 1; z < p.ld_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+      if ((it & 4095u) == 4095u && __builtin_amdgcn_s_memrealtime() > sy.t_end + 100000000ull) break;   // (the consumers' spins are bounded; this bounds the loader's too)
     }
   };
   // Everything up to the end of (layer, phase) issued and landed (called before the barrier that opens that phase's compute).
   auto ld_ensure = [&](int layer, int ph) {
-    int target = layer * sumP;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) target += q <= ph ? P_ph[q] : 0;
-    while (issued_total < target && cur_layer < p.layers) ld_issue();   // fits: a wave's images of one phase never exceed its ring
+    const int target = layer * len_cu + pre_ph[ph];
+    while (issued_total < target && ld_can()) ld_issue();   // fits: a CU's images of one phase never exceed the ring
     const int k = issued_total - target;   // fills issued behind the last one needed may stay in flight (they land in order)
-    if (k >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    if (k >= 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    else if (k >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
     else if (k >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (k >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (k >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -265,9 +249,7 @@ __global__ __launch_bounds__(kEngBlock, 1) void k_engine(EngP p) {
     else if (k >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
-  auto ld_consumed = [&](int ph) {   // after the barrier that closes a phase's compute: its ring slots are free again
-    v_cons += ph == 0 ? v_pimg[0] : ph == 1 ? v_pimg[1] : ph == 2 ? v_pimg[2] : v_pimg[3];
-  };
+  auto ld_consumed = [&](int ph) { consumed_total += P_ph[ph]; };   // behind the barrier that closes a phase's compute
 
   // ---- per-lane constants of the MFMA B operand: column col = 3 s + c of segment s, split term c
   const int col = lane & 15, k8 = lane >> 4;
@@ -275,24 +257,28 @@ __global__ __launch_bounds__(kEngBlock, 1) void k_engine(EngP p) {
   const int boff = (bc * 4 + k8) * 16;
 
   // one phase's jobs of this wave: operand image xs (tiles of 192 bytes), results to red[slot][chain]
-  auto run_jobs = [&](int ph, const unsigned char* xs) {
+  auto run_jobs = [&](int layer, int ph, const unsigned char* xs) {
     const int KT = p.KT[ph], NW = p.NW[ph];
     const int j0 = __builtin_amdgcn_readfirstlane((int)wp.jstart[ph]), j1 = __builtin_amdgcn_readfirstlane((int)wp.jstart[ph + 1]);
     for (int j = j0; j < j1; ++j) {
       const EngJob jb = wp.jobs[j];
       const int set = __builtin_amdgcn_readfirstlane((int)jb.set), nimg = __builtin_amdgcn_readfirstlane((int)jb.nimg);
       const int slot = __builtin_amdgcn_readfirstlane((int)jb.slot);
+      const int img0 = layer * len_cu + __builtin_amdgcn_readfirstlane((int)jb.goff);   // launch-wide number of the job's first image
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       int T = 4 * set + bs;
-      for (int i = 0; i < nimg; ++i) {
-        const uint32_t so = ring_base + (uint32_t)((consumed + i) % kEngRing) * 1024 + lane * 16;
-        const bf16x8 a = *(const bf16x8*)(smem + so);
-        const int Tc = T < KT ? T : KT - 1;
-        const bf16x8 b = *(const bf16x8*)(xs + Tc * 192 + boff);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
-        T += NW;
+      auto lda = [&](int i) -> bf16x8 { return *(const bf16x8*)(smem + (uint32_t)L.ring + (uint32_t)((img0 + i) % kEngRingTotal) * 1024 + lane * 16); };
+      auto ldb = [&](int Tt) -> bf16x8 { return *(const bf16x8*)(xs + (Tt < KT ? Tt : KT - 1) * 192 + boff); };
+      if (nimg > 0) {   // the next image's operands are requested before the current MFMA (one LDS round trip per job, not per image)
+        bf16x8 a = lda(0), b = ldb(T);
+        for (int i = 0; i < nimg; ++i) {
+          T += NW;
+          const int in = i + 1 < nimg ? i + 1 : i;
+          const bf16x8 an = lda(in), bn = ldb(i + 1 < nimg ? T : T - NW);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+          a = an; b = bn;
+        }
       }
-      consumed += nimg;
       // chain 4 set + s: hi / mid / lo accumulators are columns 3 s, 3 s + 1, 3 s + 2 of rows 4 s .. 4 s + 3 (lanes 19 s + c)
       f32x4 t;
 #pragma unroll
@@ -304,12 +290,55 @@ __global__ __launch_bounds__(kEngBlock, 1) void k_engine(EngP p) {
       if (lane == 19 * s && s < 4 && 4 * set + s < NW) red[slot * 16 + 4 * set + s] = make_float4(t[0], t[1], t[2], t[3]);
     }
   };
-  auto finish = [&](int ph, int slot) -> float4 {   // chains summed in order
+  auto finish = [&](int ph, int slot) -> float4 {   // chains summed in order (all 16 loads leave together: one LDS round trip)
     const int NW = p.NW[ph];
-    float4 s = red[slot * 16];
-    for (int w = 1; w < NW; ++w) { const float4 t = red[slot * 16 + w]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+    float4 t[16];
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t[w] = red[slot * 16 + (w < NW ? w : 0)];
+    float4 s = t[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w)
+      if (w < NW) { s.x += t[w].x; s.y += t[w].y; s.z += t[w].z; s.w += t[w].w; }
     return s;
   };
+  // A hidden-size vector arrives (hand-off granules, or the step's input row at layer 0): thread j takes elements 4j .. 4j+3,
+  // leaves them in hbuf, their exact triples (times the norm weight) in xs_x -- one 8-byte LDS store per split term -- and
+  // their partial sum of squares in ssp[j] (the RESID epilogue's arithmetic).  `goff` < 0: read p.h / p.ss_in instead.
+  auto stage_h = [&](const smi_u64* gbuf, int goff, unsigned tag, const float* gamma, unsigned where) -> bool {
+    bool okv = true;
+    for (int j0 = 0; j0 < H / 4; j0 += kEngGather) {
+      const int j = j0 + tid;
+      const bool act = j < H / 4;
+      const int jc = act ? j : 0;
+      const float4 gam = *(const float4*)(gamma + 4 * jc);
+      float4 hv;
+      float ssv = 0.f;
+      if (goff < 0) {
+        hv = *(const float4*)(p.h + 4 * jc);
+        ssv = p.ss_in[jc];
+      } else {
+        unsigned v[4];
+        const int idx[4] = {act ? goff + 4 * j : -1, act ? goff + 4 * j + 1 : -1, act ? goff + 4 * j + 2 : -1, act ? goff + 4 * j + 3 : -1};
+        okv = eng_sweep_idx<4>(gbuf, idx, tag, v, sy, where) && okv;
+        hv = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        ssv = (hv.x * hv.x + hv.y * hv.y) + (hv.z * hv.z + hv.w * hv.w);
+      }
+      if (act) {
+        *(float4*)(hbuf + 4 * j) = hv;
+        ssp[j] = ssv;
+        const float t[4] = {gam.x * hv.x, gam.y * hv.y, gam.z * hv.z, gam.w * hv.w};
+        uint32_t hi[4], mi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split3(t[e], hi[e], mi[e], lo[e]);
+        unsigned char* o = xs_x + eng_xs_elem((4 * j) >> 5, (4 * j) & 31);
+        *(uint2*)(o) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+        *(uint2*)(o + 64) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
+        *(uint2*)(o + 128) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+      }
+    }
+    return okv;
+  };
+  float* rfac = (float*)(arrive + 2);   // the norm factor of the phase under way: computed beside the jobs, read by the epilogue
   // rope factors of this CU's QKV parts do not depend on the layer
   float2 rope0 = make_float2(1.f, 0.f), rope1 = rope0;
   int qn = 0;
@@ -325,7 +354,6 @@ __global__ __launch_bounds__(kEngBlock, 1) void k_engine(EngP p) {
   const bool need_h = np[EPH_QKV] > 0 || np[EPH_O] > 0;        // (the o_proj epilogue adds its rows of h)
   const bool need_hmid = np[EPH_GU] > 0 || np[EPH_DOWN] > 0;   // (the down_proj epilogue adds its rows of h_mid)
   bool ok = true;
-  if (loader) ld_normalize();
   for (int layer = 0; layer < p.layers; ++layer) {
     const unsigned char* lay = p.arena + p.layers_base + (size_t)layer * p.layer_stride;
     smi_u64* gb = p.gran + (size_t)(layer & 1) * gran_per_buf;
@@ -345,55 +373,17 @@ __global__ __launch_bounds__(kEngBlock, 1) void k_engine(EngP p) {
     if (!loader) {
       // (requests that do not depend on the hand-off leave first: norm weights, bias)
       if (tid < np[EPH_QKV]) bq = *(const float4*)((const float*)(lay + p.off_bqkv) + qn);
-      if (need_h) {
-        const float* g1 = (const float*)(lay + p.off_ln1);
-        for (int e0 = 0; e0 < H; e0 += 2 * kEngGather) {
-          const int e[2] = {e0 + tid, e0 + tid + kEngGather};
-          float gam[2], hv[2];
-#pragma unroll
-          for (int k = 0; k < 2; ++k) gam[k] = e[k] < H ? g1[e[k]] : 0.f;
-          if (layer == 0) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) hv[k] = e[k] < H ? p.h[e[k]] : 0.f;
-          } else {
-            unsigned v[2];
-            const int idx[2] = {e[0] < H ? gA + e[0] : -1, e[1] < H ? gA + e[1] : -1};
-            ok = eng_sweep_idx<2>(gb, idx, tl + 0, v, sy, (unsigned)(layer * 8 + 1)) && ok;
-            hv[0] = __uint_as_float(v[0]); hv[1] = __uint_as_float(v[1]);
-          }
-#pragma unroll
-          for (int k = 0; k < 2; ++k)
-            if (e[k] < H) {
-              hbuf[e[k]] = hv[k];
-              eng_put3(xs_x, eng_xs_elem(e[k] >> 5, e[k] & 31), gam[k] * hv[k]);
-            }
-        }
-        if (layer == 0)
-          for (int i = tid; i < H / 4; i += kEngGather) ssp[i] = p.ss_in[i];
-      }
+      if (need_h)
+        ok = stage_h(gb, layer == 0 ? -1 : gA, tl + 0, (const float*)(lay + p.off_ln1), (unsigned)(layer * 8 + 1)) && ok;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       ld_trickle();
       ld_ensure(layer, EPH_QKV);
     }
-    ok = bar(ok);
+    ok = bar_chk(ok);
     if (stamp) sp[0] = __builtin_amdgcn_s_memrealtime();
     if (!ok) break;
-    {
-      if (np[EPH_QKV] > 0) {
-        if (layer > 0)   // partial sums of squares of h, one per 4 columns (the RESID epilogue's)
-          for (int i = tid; i < H / 4; i += kEngThreads) {
-            const float4 h4 = *(const float4*)(hbuf + 4 * i);
-            ssp[i] = (h4.x * h4.x + h4.y * h4.y) + (h4.z * h4.z + h4.w * h4.w);
-          }
-        run_jobs(EPH_QKV, xs_x);
-      }
-    }
-    ok = bar(ok);
-    if (!ok) break;
-    if (loader) ld_consumed(EPH_QKV);
-    // the head CUs' first K/V chunk: requested here (behind the QKV jobs: their registers are free again), used after the
-    // q / k / v hand-off, whose wait covers the round trip
+    // the head CUs' first K/V chunk: requested here, used after the q / k / v hand-off (the QKV phase covers the round trip)
     if (head >= 0) {
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
@@ -404,8 +394,18 @@ __global__ __launch_bounds__(kEngBlock, 1) void k_engine(EngP p) {
         vr[u] = *(const uint4*)(vc + off);
       }
     }
+    if (np[EPH_QKV] > 0) {
+      if (loader) {   // RMSNorm factor of h, beside the jobs (the wave that did not sweep)
+        const float r = eng_rms_from_ssp(ssp, H / 4, lane, p.KT[EPH_QKV] * 32, p.eps);
+        if (lane == 0) rfac[0] = r;
+      }
+      run_jobs(layer, EPH_QKV, xs_x);
+    }
+    bar();
+    if (stamp) sp[5] = __builtin_amdgcn_s_memrealtime();
+    if (loader) ld_consumed(EPH_QKV);
     if (wave == 0 && np[EPH_QKV] > 0) {
-      const float r1 = eng_rms_from_ssp(ssp, H / 4, lane, p.KT[EPH_QKV] * 32, p.eps);
+      const float r1 = rfac[0];
       if (tid < np[EPH_QKV]) {
         float4 s = finish(EPH_QKV, tid);
         s.x *= r1; s.y *= r1; s.z *= r1; s.w *= r1;
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(kEngBlock, 1) void k_engine(EngP p) {
           if (lane == 0) { plw[wave] = Ls; wmax[wave] = m_run; }
         }
       }
-      ok = bar(ok);
+      ok = bar_chk(ok);
       if (!ok) break;
       if (tid < kHeadDim) {
         float bm = wmax[0];
@@ -540,9 +540,9 @@ __global__ __launch_bounds__(kEngBlock, 1) void k_engine(EngP p) {
           O += pw[w][tid] * scw; Ls += plw[w] * scw;
         }
         eng_gstore(gb + gC + head * 64 + tid, tl + 2, __float_as_uint(O / Ls));
+        if (stamp) sp[2] = __builtin_amdgcn_s_memrealtime();   // (head CUs have no o_proj parts: slot 2 = attention published)
       }
-      ok = bar(ok);   // the scratch is reused by the next layer's attention
-      if (!ok) break;
+      bar();   // the scratch is reused by the next layer's attention
     }
 
     // ================= edge C: attention output -> o_proj CUs =================
@@ -565,12 +565,11 @@ __global__ __launch_bounds__(kEngBlock, 1) void k_engine(EngP p) {
         ld_trickle();
         ld_ensure(layer, EPH_O);
       }
-      ok = bar(ok);
+      ok = bar_chk(ok);
       if (stamp) sp[2] = __builtin_amdgcn_s_memrealtime();
       if (!ok) break;
-      run_jobs(EPH_O, xs_x);
-      ok = bar(ok);
-      if (!ok) break;
+      run_jobs(layer, EPH_O, xs_x);
+      bar();
       if (loader) ld_consumed(EPH_O);
       if (tid < np[EPH_O]) {
         const int n = 4 * (int)pl->parts[p0[EPH_O] + tid];
@@ -586,45 +585,28 @@ __global__ __launch_bounds__(kEngBlock, 1) void k_engine(EngP p) {
 
     // ================= edge D: h_mid -> gate_up =================
     if (!loader) {
-      if (need_hmid) {
-        const float* g2 = (const float*)(lay + p.off_ln2);
-        for (int e0 = 0; e0 < H; e0 += 2 * kEngGather) {
-          const int e[2] = {e0 + tid, e0 + tid + kEngGather};
-          float gam[2];
-#pragma unroll
-          for (int k = 0; k < 2; ++k) gam[k] = e[k] < H ? g2[e[k]] : 0.f;
-          unsigned v[2];
-          const int idx[2] = {e[0] < H ? gD + e[0] : -1, e[1] < H ? gD + e[1] : -1};
-          ok = eng_sweep_idx<2>(gb, idx, tl + 3, v, sy, (unsigned)(layer * 8 + 4)) && ok;
-#pragma unroll
-          for (int k = 0; k < 2; ++k)
-            if (e[k] < H) {
-              const float hv = __uint_as_float(v[k]);
-              hbuf[e[k]] = hv;
-              eng_put3(xs_x, eng_xs_elem(e[k] >> 5, e[k] & 31), gam[k] * hv);
-            }
-        }
-      }
+      if (need_hmid)
+        ok = stage_h(gb, gD, tl + 3, (const float*)(lay + p.off_ln2), (unsigned)(layer * 8 + 4)) && ok;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       ld_trickle();
       ld_ensure(layer, EPH_GU);
     }
-    ok = bar(ok);
+    ok = bar_chk(ok);
     if (stamp) sp[3] = __builtin_amdgcn_s_memrealtime();
     if (!ok) break;
     if (np[EPH_GU] > 0) {
-      for (int i = tid; i < H / 4; i += kEngThreads) {
-        const float4 h4 = *(const float4*)(hbuf + 4 * i);
-        ssp[i] = (h4.x * h4.x + h4.y * h4.y) + (h4.z * h4.z + h4.w * h4.w);
+      if (loader) {   // RMSNorm factor of h_mid, beside the jobs
+        const float r = eng_rms_from_ssp(ssp, H / 4, lane, p.KT[EPH_GU] * 32, p.eps);
+        if (lane == 0) rfac[0] = r;
       }
-      run_jobs(EPH_GU, xs_x);
+      run_jobs(layer, EPH_GU, xs_x);
     }
-    ok = bar(ok);
-    if (!ok) break;
+    bar();
+    if (stamp) sp[6] = __builtin_amdgcn_s_memrealtime();
     if (loader) ld_consumed(EPH_GU);
     if (wave == 0 && np[EPH_GU] > 0) {
-      const float r2 = eng_rms_from_ssp(ssp, H / 4, lane, p.KT[EPH_GU] * 32, p.eps);
+      const float r2 = rfac[0];
       if (tid < np[EPH_GU]) {
         const int n = 4 * (int)pl->parts[p0[EPH_GU] + tid];
         float4 s = finish(EPH_GU, tid);
@@ -664,12 +646,12 @@ __global__ __launch_bounds__(kEngBlock, 1) void k_engine(EngP p) {
         ld_trickle();
         ld_ensure(layer, EPH_DOWN);
       }
-      ok = bar(ok);
+      ok = bar_chk(ok);
       if (stamp) sp[4] = __builtin_amdgcn_s_memrealtime();
       if (!ok) break;
-      run_jobs(EPH_DOWN, xs_act);
-      ok = bar(ok);
-      if (!ok) break;
+      run_jobs(layer, EPH_DOWN, xs_act);
+      bar();
+      if (stamp) sp[7] = __builtin_amdgcn_s_memrealtime();
       if (loader) ld_consumed(EPH_DOWN);
       if (tid < np[EPH_DOWN]) {
         const float4 s = finish(EPH_DOWN, tid);

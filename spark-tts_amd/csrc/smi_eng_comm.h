@@ -53,14 +53,43 @@ __device__ __forceinline__ bool eng_sweep(const smi_u64* g, int first, int strid
   }
 }
 
-// The same sweep over arbitrary granule indices (idx[k] < 0: none).
+// The same sweep over arbitrary granule indices (idx[k] < 0: none), in two stages.  While the producers are still computing,
+// hundreds of waves re-reading whole vectors with L1-bypassing loads is traffic on the very lines the producers are about to
+// write and beside the weight stream (price-list row polling-cost), so a wave first watches ONE granule of its set -- one lane,
+// one 8-byte load, a short sleep between looks -- and sweeps its whole set only once that one shows the epoch; the producers of
+// an edge finish within a microsecond of each other, so the full sweep then rarely needs a second pass.
 template <int NPT>
 __device__ __forceinline__ bool eng_sweep_idx(const smi_u64* g, const int (&idx)[NPT], unsigned tag, unsigned (&v)[NPT],
                                               const EngSync& sy, unsigned where) {
   unsigned pend = 0;
 #pragma unroll
   for (int k = 0; k < NPT; ++k) { pend |= idx[k] >= 0 ? (1u << k) : 0u; v[k] = 0u; }
-  for (unsigned it = 0;; ++it) {
+  auto give_up = [&]() -> bool {   // the deadline and the other workgroups' give-up word
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+    if (eng_err_load(sy.err) != 0) return true;
+    if (now > sy.t_end) {
+      if ((threadIdx.x & 63) == 0) { atomicCAS(sy.err, 0u, 1u); atomicCAS(sy.err + 1, 0u, where); }
+      return true;
+    }
+    return false;
+  };
+  {   // stage 1: the wave's first valid granule, watched by the lane that owns it
+    const unsigned long long have = __ballot(pend != 0);
+    if (have == 0) return true;
+    const int first = __ffsll((long long)have) - 1;
+    const bool me = (int)(threadIdx.x & 63) == first;
+    int k0 = 0;
+#pragma unroll
+    for (int k = NPT - 1; k >= 0; --k) k0 = (pend & (1u << k)) ? k : k0;
+    for (unsigned it = 0;; ++it) {
+      bool seen = false;
+      if (me) seen = (unsigned)(eng_gload(g + idx[k0]) >> 32) == tag;
+      if (__any(seen)) break;
+      __builtin_amdgcn_s_sleep(2);
+      if ((it & 63u) == 63u && give_up()) return false;
+    }
+  }
+  for (unsigned it = 0;; ++it) {   // stage 2: the whole set; only granules still missing are re-read
     smi_u64 x[NPT];
 #pragma unroll
     for (int k = 0; k < NPT; ++k)
@@ -69,14 +98,7 @@ __device__ __forceinline__ bool eng_sweep_idx(const smi_u64* g, const int (&idx)
     for (int k = 0; k < NPT; ++k)
       if ((pend & (1u << k)) && (unsigned)(x[k] >> 32) == tag) { v[k] = (unsigned)x[k]; pend &= ~(1u << k); }
     if (!__any(pend != 0)) return true;
-    if ((it & 31u) == 31u) {
-      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-      const unsigned e = eng_err_load(sy.err);
-      if (e != 0) return false;
-      if (now > sy.t_end) {
-        if ((threadIdx.x & 63) == 0) { atomicCAS(sy.err, 0u, 1u); atomicCAS(sy.err + 1, 0u, where); }
-        return false;
-      }
-    }
+    __builtin_amdgcn_s_sleep(1);
+    if ((it & 31u) == 31u && give_up()) return false;
   }
 }

@@ -30,8 +30,8 @@ struct EngPlanHost {
   int ncu = 0, maxlen = 0;
   EngGeom g;
   std::vector<EngCuPlan> cu;
-  std::vector<uint32_t> desc;   // [ncu * waves][maxlen]
-  std::vector<uint16_t> lens;   // [ncu * waves]
+  std::vector<uint32_t> desc;   // [ncu][maxlen]: the CU's images of one layer in stream order
+  std::vector<uint16_t> lens;   // [ncu]
   int max_wave_phase_imgs = 0, max_slots = 0, max_jobs = 0, min_load = 0, max_load = 0;
 };
 
@@ -71,8 +71,8 @@ inline bool eng_build_plan(int H, int Q, int KV, int I, int n_heads, int ncu, En
   place(EPH_GU, true);
   place(EPH_QKV, true);
   P.cu.assign(ncu, EngCuPlan{});
-  P.lens.assign((size_t)ncu * kEngWaves, 0);
-  std::vector<std::vector<uint32_t>> streams((size_t)ncu * kEngWaves);
+  P.lens.assign((size_t)ncu, 0);
+  std::vector<std::vector<uint32_t>> streams((size_t)ncu);
   P.min_load = 1 << 30; P.max_load = 0;
   for (int c = 0; c < ncu; ++c) {
     EngCuPlan& cp = P.cu[c];
@@ -105,43 +105,51 @@ inline bool eng_build_plan(int H, int Q, int KV, int I, int n_heads, int ncu, En
           for (int w = 1; w < kEngWaves; ++w)
             if (pload[w] < pload[best] || (pload[w] == pload[best] && wload[w] < wload[best])) best = w;
           EngJob jb;
-          jb.part = (uint16_t)parts[ph][c][sl]; jb.set = (uint8_t)a; jb.nimg = (uint8_t)g.nimg[ph][a]; jb.slot = (uint16_t)sl; jb.pad = 0;
+          jb.part = (uint16_t)parts[ph][c][sl]; jb.set = (uint8_t)a; jb.nimg = (uint8_t)g.nimg[ph][a]; jb.slot = (uint16_t)sl; jb.goff = 0;
           wj[best][ph].push_back(jb);
           pload[best] += g.nimg[ph][a];
           wload[best] += g.nimg[ph][a];
         }
     }
-    long cl = 0;
-    for (int w = 0; w < kEngWaves; ++w) {
-      EngWavePlan& wp = cp.w[w];
-      int nj = 0, nimg_all = 0;
-      std::vector<uint32_t>& st = streams[(size_t)c * kEngWaves + w];
-      for (int ph = 0; ph < 4; ++ph) {
-        wp.jstart[ph] = (uint16_t)nj;
+    // the CU's stream of one layer: phase by phase, wave by wave, job by job -- the order the loader issues and the ring holds
+    std::vector<uint32_t>& st = streams[(size_t)c];
+    int nj[kEngWaves] = {0};
+    for (int w = 0; w < kEngWaves; ++w) for (int ph = 0; ph < 5; ++ph) cp.w[w].jstart[ph] = 0;
+    // job lists per wave are stored phase-major (jstart), so fill phase by phase
+    for (int ph = 0; ph < 4; ++ph) {
+      int pimg_cu = 0;
+      for (int w = 0; w < kEngWaves; ++w) {
+        EngWavePlan& wp = cp.w[w];
+        wp.jstart[ph] = (uint16_t)nj[w];
         int pimg = 0;
-        for (const EngJob& jb : wj[w][ph]) {
-          if (nj >= kEngMaxJobs) return fail("too many jobs on a wave");
-          wp.jobs[nj++] = jb;
+        for (EngJob jb : wj[w][ph]) {
+          if (nj[w] >= kEngMaxJobs) return fail("too many jobs on a wave");
+          if (st.size() + jb.nimg > 65535) return fail("stream too long");
+          jb.goff = (uint16_t)st.size();
+          wp.jobs[nj[w]++] = jb;
           for (int r = 0; r < jb.nimg; ++r) st.push_back(((uint32_t)ph << 30) | ((uint32_t)jb.set << 26) | ((uint32_t)r << 16) | jb.part);
           pimg += jb.nimg;
         }
         wp.pimg[ph] = (uint16_t)pimg;
-        if (pimg > kEngRing) return fail("a wave's images of one phase exceed its ring");
         if (pimg > P.max_wave_phase_imgs) P.max_wave_phase_imgs = pimg;
-        nimg_all += pimg;
+        pimg_cu += pimg;
       }
-      wp.jstart[4] = (uint16_t)nj;
-      wp.len = (uint16_t)nimg_all;
-      if (nj > P.max_jobs) P.max_jobs = nj;
-      P.lens[(size_t)c * kEngWaves + w] = (uint16_t)nimg_all;
-      if (nimg_all > P.maxlen) P.maxlen = nimg_all;
-      cl += nimg_all;
+      cp.pcount[ph] = (uint16_t)pimg_cu;
+      if (pimg_cu > kEngRingTotal) return fail("a CU's images of one phase exceed its ring");
     }
+    for (int w = 0; w < kEngWaves; ++w) {
+      cp.w[w].jstart[4] = (uint16_t)nj[w];
+      if (nj[w] > P.max_jobs) P.max_jobs = nj[w];
+    }
+    cp.len_cu = (uint16_t)st.size();
+    P.lens[(size_t)c] = (uint16_t)st.size();
+    if ((int)st.size() > P.maxlen) P.maxlen = (int)st.size();
+    const long cl = (long)st.size();
     if (cl < P.min_load) P.min_load = (int)cl;
     if (cl > P.max_load) P.max_load = (int)cl;
   }
   if (P.maxlen == 0) return fail("empty plan");
-  P.desc.assign((size_t)ncu * kEngWaves * P.maxlen, 0);
+  P.desc.assign((size_t)ncu * P.maxlen, 0);
   for (size_t cw = 0; cw < streams.size(); ++cw)
     for (size_t i = 0; i < streams[cw].size(); ++i) P.desc[cw * P.maxlen + i] = streams[cw][i];
   return true;
@@ -155,6 +163,7 @@ struct EngState {
   unsigned* words = nullptr;          // [0] serial, [4..7] err, [8] arrive
   unsigned long long* stamps = nullptr;
   unsigned timeout_ticks = 0;
+  int ld_burst = 4, ld_sleep = 0;
   char why[160] = "";
 };
 

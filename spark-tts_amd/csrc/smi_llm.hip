@@ -2586,8 +2586,10 @@ int eng_create(smi_llm* L) {
   if (lds.total > 160 * 1024 - 512) return skip("LDS image too large");
   E.ncu = ncu; E.maxlen = P.maxlen; E.lds = lds.total;
   E.gran_per_buf = 2 * L->H + (L->Q + 2 * L->KV) + L->Q + L->I;
+  { const char* e = getenv("SPARKMI_ENGINE_BURST"); E.ld_burst = e && atoi(e) > 0 ? atoi(e) : 4; }
+  { const char* e = getenv("SPARKMI_ENGINE_SLEEP"); E.ld_sleep = e && atoi(e) >= 0 ? atoi(e) : 0; }
   { const char* e = getenv("SPARKMI_ENGINE_TIMEOUT_MS"); const double ms = e ? atof(e) : 500.0; E.timeout_ticks = (unsigned)((ms > 1.0 ? ms : 1.0) * 1e5); }
-  const size_t ncw = (size_t)ncu * kEngWaves;
+  const size_t ncw = (size_t)ncu;   // one stream per CU
   const size_t stream_bytes = (size_t)c.num_layers * ncw * P.maxlen * 1024;
   uint32_t* desc_dev = nullptr;
   uint16_t* lens_dev = nullptr;
@@ -2658,6 +2660,7 @@ int eng_launch(smi_llm* L, hipStream_t st) {
   p.kcache = (uint16_t*)L->kcache; p.vcache = (uint16_t*)L->vcache; p.kv_layer_elems = L->kv_layer_elems;
   p.gran = E.gran; p.serial = E.words; p.err = E.words + 4; p.arrive = E.words + 8;
   p.timeout_ticks = E.timeout_ticks;
+  p.ld_burst = E.ld_burst; p.ld_sleep = E.ld_sleep;
   p.stamps = getenv("SPARKMI_ENGINE_STAMPS") ? E.stamps : nullptr;
   hipLaunchKernelGGL(k_engine, dim3(E.ncu), dim3(kEngBlock), E.lds, st, p);
   SMI_LAUNCH_CHECK();
@@ -3861,13 +3864,13 @@ int smi_llm_engine_plan(const smi_llm_cfg* cfg, int ncu, int32_t* stats) {
   for (int c = 0; c < ncu; ++c)
     for (int w = 0; w < kEngWaves; ++w) {
       const EngWavePlan& wp = P.cu[c].w[w];
-      size_t i = 0;
       for (int ph = 0; ph < 4; ++ph)
         for (int j = wp.jstart[ph]; j < wp.jstart[ph + 1]; ++j) {
           const EngJob& jb = wp.jobs[j];
           SMI_REQUIRE(P.cu[c].parts[P.cu[c].pstart[ph] + jb.slot] == jb.part, "engine plan: job slot does not name its part");
-          for (int r = 0; r < jb.nimg; ++r, ++i) {
-            const uint32_t d = P.desc[((size_t)c * kEngWaves + w) * P.maxlen + i];
+          SMI_REQUIRE((int)jb.goff + jb.nimg <= (int)P.cu[c].len_cu, "engine plan: job beyond the CU's stream");
+          for (int r = 0; r < jb.nimg; ++r) {
+            const uint32_t d = P.desc[(size_t)c * P.maxlen + jb.goff + r];
             SMI_REQUIRE(d == (((uint32_t)ph << 30) | ((uint32_t)jb.set << 26) | ((uint32_t)r << 16) | jb.part), "engine plan: stream order differs from the job order");
             unsigned char& f = seen[ph][((size_t)jb.part * 4 + jb.set) * 64 + r];
             SMI_REQUIRE(r < 64 && !f, "engine plan: image listed twice");
@@ -3875,7 +3878,6 @@ int smi_llm_engine_plan(const smi_llm_cfg* cfg, int ncu, int32_t* stats) {
             ++total;
           }
         }
-      SMI_REQUIRE(i == wp.len, "engine plan: stream length");
     }
   SMI_REQUIRE(total == want, "engine plan: %ld images placed, %ld expected", total, want);
   const EngLds lds = eng_lds(cfg->hidden_size, P.g.KT[EPH_DOWN], P.g.KT[EPH_QKV] > P.g.KT[EPH_O] ? P.g.KT[EPH_QKV] : P.g.KT[EPH_O]);

@@ -87,6 +87,36 @@ def test_config3_ragged_batch_with_rows_retired_equals_the_padded_batch(full_llm
     assert llm.generate_ragged(prompts, budgets) == ragged          # second call: every step graph comes from the cache
 
 
+def test_paged_kv_cache_at_full_size_equals_contiguous_cache_and_oracle(full_llm, full_llm_oracle):
+    """SURVEY 8f-4 at the 0.5B shape (the functional analogue of TensorRT-LLM's paged KV, runtime/triton_trtllm/run.sh:50-65):
+    32 ragged prompts on a paged engine (64-token pages: the page size must divide max_positions = 704) give the tokens of
+    the contiguous-cache engine bit for bit -- both prefill the same rows through the same kernels, only the K/V addresses
+    differ -- and two rows equal the CPU oracle (f32 KV: exactly; that run is the pin, bf16 adds only the documented ties).
+    The paged step's time goes to profiles/ through tools/serve_time.py."""
+    cfg, syn, arena = full_llm
+    rng = np.random.Generator(np.random.PCG64(4096))
+    prompts = [rng.integers(0, cfg.vocab_size, size=int(rng.integers(97, 155))).tolist() for _ in range(32)]
+    n = 10
+    for kv in ("f32", "bf16"):
+        paged = _llm(cfg, arena, max_slots=32, kv_dtype=kv, kv_page_tokens=64, kv_pages=104)
+        flat = _llm(cfg, arena, max_slots=32, kv_dtype=kv)
+        got = paged.generate_ids(prompts, n)
+        assert got == flat.generate_ids(prompts, n), f"paged vs contiguous ({kv})"
+        tot, free = paged.kv_pages()
+        assert tot == 104 and 8 <= free <= 40            # every row holds 2-3 pages of 64 tokens, far less than the 11 a reserved slot would
+        ref = full_llm_oracle
+        ref.kv_dtype = kv
+        for b in (3, 17):
+            want = ref.generate_greedy(prompts[b], n)
+            if kv == "f32":
+                assert got[b] == want, f"row {b} vs oracle"
+            else:
+                _assert_same_or_tie(flat, prompts[b], got[b], want, f"row {b} vs oracle")
+        # one sequence alone on the paged engine (the general kernels: no one-row engine, no fused o_proj) = its row of the batch
+        if kv == "f32":
+            assert paged.generate_ids([prompts[5]], n)[0] == got[5]
+
+
 def test_config5_clone_length_prompts_through_the_prefill_gemm(full_llm, full_llm_oracle):
     """configs[4]'s prefill shape: 8 voice-clone prompts of ~460 tokens (text + 32 global + ~300 semantic prompt tokens)
     = 3672+ rows -> k_pgemm with ragged lengths; every row equals its B = 1 run and two rows equal the CPU oracle."""

@@ -276,10 +276,17 @@ def test_continuous_batching_equals_standalone_runs(tiny):
         reqs.append((i, prompt, int(rng.integers(3, 40))))
     single = _llm(cfg, syn, max_slots=1, max_positions=128)
     want = {i: single.generate_ids([p], n)[0] for i, p, n in reqs}
+    oracle = Qwen2Ref(cfg, syn, kv_dtype="bf16")          # the CPU oracle, not another HIP engine: three requests
+    for i in (0, 4, 8):
+        assert oracle.generate_greedy(np.asarray(reqs[i][1]), reqs[i][2]) == want[i], f"request {i} vs oracle"
     longest = max(want, key=lambda i: len(want[i]))
     eos = want[longest][len(want[longest]) // 2]   # a token one of the sequences emits: it must stop there
     want = {i: single.generate_ids([p], n, eos_token_id=eos)[0] for i, p, n in reqs}
     llm = _llm(cfg, syn, max_slots=4, max_positions=128)
+    for i in (1, 5, longest):                              # with the stop id: the oracle's run cut at its first eos
+        ref = oracle.generate_greedy(np.asarray(reqs[i][1]), reqs[i][2])
+        cut = ref[: ref.index(eos) + 1] if eos in ref else ref
+        assert cut == want[i], f"request {i} vs oracle (eos)"
     for stride in (1, 5):
         got = dict(llm.serve(((i, p, n, eos) for i, p, n in reqs), max_live=3, decode_stride=stride))
         assert set(got) == set(want)
@@ -446,6 +453,13 @@ def test_sampled_tokens_do_not_depend_on_batch_composition(tiny):
     llm.set_sampling(True, 0.9, 40, 0.95, seed=78)
     other = dict(llm.serve(iter(reqs), max_live=4, decode_stride=3))
     assert any(other[i] != crowd[i] for i, *_ in reqs)
+    # the same serving path with the sampler off against the CPU oracle (the sampled runs above can only be compared with
+    # each other: another generator's draws are not reproducible bit for bit)
+    llm.set_sampling(False)
+    greedy = dict(llm.serve(iter(reqs), max_live=4, decode_stride=3))
+    oracle = Qwen2Ref(cfg, syn, kv_dtype="bf16")
+    for i in (0, 2, 5):
+        assert greedy[i][: reqs[i][2]] == oracle.generate_greedy(np.asarray(reqs[i][1]), reqs[i][2]), f"request {i} vs oracle"
 
 
 def test_paged_kv_cache_serves_more_sequences_than_it_could_reserve(tiny):
@@ -471,6 +485,9 @@ def test_paged_kv_cache_serves_more_sequences_than_it_could_reserve(tiny):
         got = dict(llm.serve(iter(reqs), max_live=5, decode_stride=4))
         for i, p, n, _ in reqs:
             assert got[i][:n] == want[i], f"request {i} ({kv})"
+        oracle = Qwen2Ref(cfg, syn, kv_dtype=kv)               # the paged engine against the CPU oracle, three requests
+        for i in (1, 6, 9):
+            assert got[i][: reqs[i][2]] == oracle.generate_greedy(np.asarray(reqs[i][1]), reqs[i][2]), f"request {i} ({kv}) vs oracle"
         assert llm.kv_pages() == (40, 40)                     # everything retired: every page is back
     # plain (static-batch) generation on a paged engine, ragged prompts, two m-tiles worth of rows
     llm = _llm(cfg, syn, max_slots=8, max_positions=256, kv_page_tokens=32, kv_pages=24)

@@ -17,11 +17,22 @@ MAXPOS = 704
 t0 = time.time()
 arena = torch.from_numpy(pack_llm_arena(cfg, W.SyntheticLLM(cfg), llm_cfg_struct(cfg, 1, MAXPOS, "bf16", True))).to("cuda:0")
 print(f"arena packed in {time.time() - t0:.1f}s", flush=True)
+prompt = np.random.Generator(np.random.PCG64(1234)).integers(0, cfg.vocab_size, size=128).tolist()
+# loader pacing variants (SPARKMI_ENGINE_BURST fills per look at the arrival counter, SPARKMI_ENGINE_SLEEP x 64-cycle pauses):
+# python tools/engine_time.py 4,0 1,2 16,0
+for knob in sys.argv[1:]:
+    b, z = knob.split(",")
+    os.environ["SPARKMI_ENGINE_BURST"], os.environ["SPARKMI_ENGINE_SLEEP"] = b, z
+    v = SparkLLM(cfg, None, "cuda:0", max_positions=MAXPOS, arena=arena)
+    v.prefill([prompt]); v.decode(20)
+    lay = v.time_kernel("layers", iters=32) * 1e3
+    print(f"burst {b} sleep {z}: layers {lay:7.1f} us ({lay / cfg.num_hidden_layers:5.2f} per layer)", flush=True)
+    v.close()
+os.environ.pop("SPARKMI_ENGINE_BURST", None); os.environ.pop("SPARKMI_ENGINE_SLEEP", None)
 llm = SparkLLM(cfg, None, "cuda:0", max_positions=MAXPOS, arena=arena)
 print("engine:", llm.engine_info(), flush=True)
-prompt = np.random.Generator(np.random.PCG64(1234)).integers(0, cfg.vocab_size, size=128).tolist()
 res = {}
-for on in (True, False, True, False):
+for on in (True, False):
     llm.set_engine(on)
     toks = llm.generate_ids([prompt], 150)[0]
     llm.prefill([prompt]); llm.decode(20)
@@ -41,8 +52,9 @@ if os.environ.get("SPARKMI_ENGINE_STAMPS"):
     llm.set_engine(True)
     llm.prefill([prompt]); llm.decode(40)
     s = llm.engine_stamps()
-    names = ["A h", "B qkv", "C attn", "D h_mid", "E act"]
+    names = ["A h", "B qkv", "C attn", "D h_mid", "E act", "QKV done", "gate_up done", "down done"]
     d0, dh = s[0], s[1]
-    print("CU 0   (us after the layer's A):", "  ".join(f"{n} {np.mean(d0[2:, i] - d0[2:, 0]):5.2f}" for i, n in enumerate(names) if i != 1))
-    print("head CU (us after the layer's A):", "  ".join(f"{n} {np.mean(dh[2:, i] - dh[2:, 0]):5.2f}" for i, n in enumerate(names) if i in (0, 1, 3)))
+    order = [0, 5, 2, 3, 6, 4, 7]
+    print("CU 0   (us after the layer's A, in time order):", "  ".join(f"{names[i]} {np.mean(d0[2:, i] - d0[2:, 0]):5.2f}" for i in order))
+    print("head CU (us after the layer's A):", "  ".join(f"{names[i]} {np.mean(dh[2:, i] - dh[2:, 0]):5.2f}" for i in (0, 5, 1, 3, 6)), f" attention published {np.mean(dh[2:, 2] - dh[2:, 0]):5.2f}")
     print("layer period (CU 0):", float(np.mean(np.diff(d0[2:, 0]))), "us")

@@ -48,10 +48,12 @@ if a.json:
     roles = {}
     resid = []
     for name, grid, n, rd, wr in rows:
-        if n < 24 * steps and not name.startswith("k_lm"):
+        if n < 24 * steps and not name.startswith("k_lm") and not name.startswith("k_engine"):
             continue
         ent = {"kernel": name, "grid": grid, "launches": n, "read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
-        if name.startswith("k_lm") and n >= steps:
+        if name.startswith("k_engine") and n >= steps:
+            roles.setdefault("engine", ent)       # all layers of a one-row step in one launch (csrc/smi_eng.h)
+        elif name.startswith("k_lm") and n >= steps:
             roles.setdefault("lm_head", ent)
         elif name.startswith("k_attn<"):
             roles.setdefault("attn", ent)
