@@ -178,8 +178,8 @@ int smi_llm_debug_stamps(smi_llm* h, int kernel, int layer, double* out);
  *   smi_llm_engine_plan: host-only check of the static work plan for `ncu` CUs (no GPU call): every weight image placed
  *                   exactly once, stream order = job order; stats[8] = {images per wave max, per wave and phase max, parts per
  *                   CU and phase max, jobs per wave max, images per CU min, max, LDS bytes, images per layer}.
- *   smi_llm_engine_stamps: diagnostics, SPARKMI_ENGINE_STAMPS=1: out[2][layers][8] microseconds of the last engine launch
- *                   (CU 0 and the first head CU, after the hand-offs h, q|k|v, attention, h_mid, act).
+ *   smi_llm_engine_stamps: diagnostics, SPARKMI_ENGINE_STAMPS=1: out[3][layers][16] microseconds of the last engine launch
+ *                   (wave 0 of CU 0, wave 0 of the first head CU, wave 7 of CU 0; after the hand-offs h, q|k|v, attention, h_mid, act).
  * A hand-off that does not complete within SPARKMI_ENGINE_TIMEOUT_MS (default 500) ends the launch; the next call that
  * synchronises (smi_llm_get_tokens / _status / _all_done) returns SMI_EHIP. */
 int smi_llm_engine(smi_llm* h, int32_t* enabled, int32_t* info, char* why, int n);

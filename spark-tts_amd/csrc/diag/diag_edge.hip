@@ -57,6 +57,7 @@ __global__ __launch_bounds__(kThreads) void ub_edge(EdgeArg a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cu = blockIdx.x;
   EngSync sy;
   sy.err = a.err;
+  sy.quiet = 0; sy.predelay = 0; sy.go = nullptr; sy.watcher = false;
   sy.t_end = __builtin_amdgcn_s_memrealtime() + a.timeout_ticks;
   const unsigned serial = *(volatile unsigned*)a.serial;
   const unsigned tbase = serial * (unsigned)(a.layers * 8 + 16) + 1u;

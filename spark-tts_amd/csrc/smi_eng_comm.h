@@ -12,9 +12,23 @@
 
 typedef unsigned long long smi_u64;
 
+// Words in LDS that several waves of a workgroup poll or set: always through an LDS-typed pointer and a relaxed workgroup-scope
+// atomic.  (A `volatile` access through a generic pointer compiles to flat_load / flat_store ... sc0 sc1 followed by
+// s_waitcnt vmcnt(0): in a wave with LDS-DMA fills or sweep loads in flight every look at such a word would wait for ALL of
+// them -- this cost the engine 10 us per layer before it was found in the ISA.)
+typedef __attribute__((address_space(3))) unsigned eng_lds_u32;
+__device__ __forceinline__ eng_lds_u32* eng_lds_ptr(const unsigned* p) { return (eng_lds_u32*)(__attribute__((address_space(3))) void*)(void*)p; }
+__device__ __forceinline__ unsigned eng_lds_load(const unsigned* p) { return __hip_atomic_load(eng_lds_ptr(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void eng_lds_store(unsigned* p, unsigned v) { __hip_atomic_store(eng_lds_ptr(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 struct EngSync {
   unsigned* err;            // [4] device words: 0 = timeout code (0: none), 1 = where, 2 = spare, 3 = spare
   unsigned long long t_end; // s_memrealtime deadline of this launch (set per wave at kernel entry)
+  int quiet;                // 1: watch one granule first (two-stage sweep); 0: sweep the whole set from the start;
+                            // 2: sleep `predelay` x 64 cycles (the phase's expected length), then sweep with pauses
+  int predelay;
+  unsigned* go;             // LDS word of the workgroup (eng_lds_load / eng_lds_store): the epoch whose first granule the watching wave has seen
+  bool watcher;             // this wave watches global memory for the workgroup (the others wait on `go`)
 };
 
 __device__ __forceinline__ smi_u64 eng_gload(const smi_u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -73,20 +87,33 @@ __device__ __forceinline__ bool eng_sweep_idx(const smi_u64* g, const int (&idx)
     }
     return false;
   };
-  {   // stage 1: the wave's first valid granule, watched by the lane that owns it
+  if (sy.quiet == 2) {
+    for (int z = 0; z < sy.predelay; ++z) __builtin_amdgcn_s_sleep(1);
+  } else if (sy.quiet) {   // stage 1: ONE wave of the workgroup watches the first granule of its set (the lane that owns it); the others wait in LDS
     const unsigned long long have = __ballot(pend != 0);
     if (have == 0) return true;
-    const int first = __ffsll((long long)have) - 1;
-    const bool me = (int)(threadIdx.x & 63) == first;
-    int k0 = 0;
+    if (sy.watcher) {
+      const int first = __ffsll((long long)have) - 1;
+      const bool me = (int)(threadIdx.x & 63) == first;
+      int k0 = 0;
 #pragma unroll
-    for (int k = NPT - 1; k >= 0; --k) k0 = (pend & (1u << k)) ? k : k0;
-    for (unsigned it = 0;; ++it) {
-      bool seen = false;
-      if (me) seen = (unsigned)(eng_gload(g + idx[k0]) >> 32) == tag;
-      if (__any(seen)) break;
-      __builtin_amdgcn_s_sleep(2);
-      if ((it & 63u) == 63u && give_up()) return false;
+      for (int k = NPT - 1; k >= 0; --k) k0 = (pend & (1u << k)) ? k : k0;
+      for (unsigned it = 0;; ++it) {
+        bool seen = false;
+        if (me) seen = (unsigned)(eng_gload(g + idx[k0]) >> 32) == tag;
+        if (__any(seen)) break;
+        __builtin_amdgcn_s_sleep(2);
+        if ((it & 63u) == 63u && give_up()) { if ((threadIdx.x & 63) == 0) eng_lds_store(sy.go, 0xffffffffu); return false; }
+      }
+      if ((threadIdx.x & 63) == 0) eng_lds_store(sy.go, tag);
+    } else {
+      for (unsigned it = 0;; ++it) {
+        const unsigned gv = eng_lds_load(sy.go);
+        if (gv == tag) break;
+        if (gv == 0xffffffffu) return false;
+        __builtin_amdgcn_s_sleep(1);
+        if ((it & 1023u) == 1023u && give_up()) return false;
+      }
     }
   }
   for (unsigned it = 0;; ++it) {   // stage 2: the whole set; only granules still missing are re-read
@@ -98,7 +125,8 @@ __device__ __forceinline__ bool eng_sweep_idx(const smi_u64* g, const int (&idx)
     for (int k = 0; k < NPT; ++k)
       if ((pend & (1u << k)) && (unsigned)(x[k] >> 32) == tag) { v[k] = (unsigned)x[k]; pend &= ~(1u << k); }
     if (!__any(pend != 0)) return true;
-    __builtin_amdgcn_s_sleep(1);
+    if (sy.quiet == 2) __builtin_amdgcn_s_sleep(3);
+    else if (sy.quiet) __builtin_amdgcn_s_sleep(1);
     if ((it & 31u) == 31u && give_up()) return false;
   }
 }

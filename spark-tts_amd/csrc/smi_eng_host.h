@@ -101,8 +101,8 @@ inline bool eng_build_plan(int H, int Q, int KV, int I, int n_heads, int ncu, En
       int pload[kEngWaves] = {0};
       for (int a = 0; a < g.G[ph]; ++a)   // chain sets in order of size (set 0 has the most images): larger jobs first
         for (size_t sl = 0; sl < parts[ph][c].size(); ++sl) {
-          int best = 0;
-          for (int w = 1; w < kEngWaves; ++w)
+          int best = 0;   // (the last wave streams the weights and computes the norm factors: no jobs)
+          for (int w = 1; w < kEngWaves - 1; ++w)
             if (pload[w] < pload[best] || (pload[w] == pload[best] && wload[w] < wload[best])) best = w;
           EngJob jb;
           jb.part = (uint16_t)parts[ph][c][sl]; jb.set = (uint8_t)a; jb.nimg = (uint8_t)g.nimg[ph][a]; jb.slot = (uint16_t)sl; jb.goff = 0;
@@ -163,7 +163,8 @@ struct EngState {
   unsigned* words = nullptr;          // [0] serial, [4..7] err, [8] arrive
   unsigned long long* stamps = nullptr;
   unsigned timeout_ticks = 0;
-  int ld_burst = 4, ld_sleep = 0;
+  int ld_burst = 16, ld_sleep = 0, poll_quiet = 1;
+  int edge_delay[5] = {16, 16, 16, 16, 16};
   char why[160] = "";
 };
 

@@ -2586,7 +2586,9 @@ int eng_create(smi_llm* L) {
   if (lds.total > 160 * 1024 - 512) return skip("LDS image too large");
   E.ncu = ncu; E.maxlen = P.maxlen; E.lds = lds.total;
   E.gran_per_buf = 2 * L->H + (L->Q + 2 * L->KV) + L->Q + L->I;
-  { const char* e = getenv("SPARKMI_ENGINE_BURST"); E.ld_burst = e && atoi(e) > 0 ? atoi(e) : 4; }
+  { const char* e = getenv("SPARKMI_ENGINE_BURST"); E.ld_burst = e && atoi(e) > 0 ? atoi(e) : 16; }
+  { const char* e = getenv("SPARKMI_ENGINE_POLL"); E.poll_quiet = e ? atoi(e) : 1; }
+  { const char* e = getenv("SPARKMI_ENGINE_DELAYS"); for (int i = 0; i < 5; ++i) E.edge_delay[i] = 16; if (e) sscanf(e, "%d,%d,%d,%d,%d", &E.edge_delay[0], &E.edge_delay[1], &E.edge_delay[2], &E.edge_delay[3], &E.edge_delay[4]); }
   { const char* e = getenv("SPARKMI_ENGINE_SLEEP"); E.ld_sleep = e && atoi(e) >= 0 ? atoi(e) : 0; }
   { const char* e = getenv("SPARKMI_ENGINE_TIMEOUT_MS"); const double ms = e ? atof(e) : 500.0; E.timeout_ticks = (unsigned)((ms > 1.0 ? ms : 1.0) * 1e5); }
   const size_t ncw = (size_t)ncu;   // one stream per CU
@@ -2604,7 +2606,7 @@ int eng_create(smi_llm* L) {
   if (hipMalloc((void**)&E.stream, stream_bytes) != hipSuccess) return oom("weight stream", stream_bytes);
   if (hipMalloc((void**)&E.gran, (size_t)2 * E.gran_per_buf * 8) != hipSuccess) return oom("granules", (size_t)2 * E.gran_per_buf * 8);
   if (hipMalloc((void**)&E.words, 256) != hipSuccess) return oom("words", 256);
-  if (hipMalloc((void**)&E.stamps, (size_t)2 * c.num_layers * 8 * 8) != hipSuccess) return oom("stamps", (size_t)2 * c.num_layers * 64);
+  if (hipMalloc((void**)&E.stamps, (size_t)3 * c.num_layers * 16 * 8) != hipSuccess) return oom("stamps", (size_t)3 * c.num_layers * 128);
   if (hipMalloc((void**)&desc_dev, P.desc.size() * 4) != hipSuccess) return oom("descriptors", P.desc.size() * 4);
   if (hipMalloc((void**)&lens_dev, P.lens.size() * 2) != hipSuccess) return oom("lengths", P.lens.size() * 2);
   SMI_HIP(hipMemcpy(E.plan, P.cu.data(), P.cu.size() * sizeof(EngCuPlan), hipMemcpyHostToDevice));
@@ -2612,7 +2614,7 @@ int eng_create(smi_llm* L) {
   SMI_HIP(hipMemcpy(lens_dev, P.lens.data(), P.lens.size() * 2, hipMemcpyHostToDevice));
   SMI_HIP(hipMemset(E.gran, 0, (size_t)2 * E.gran_per_buf * 8));
   SMI_HIP(hipMemset(E.words, 0, 256));
-  SMI_HIP(hipMemset(E.stamps, 0, (size_t)2 * c.num_layers * 64));
+  SMI_HIP(hipMemset(E.stamps, 0, (size_t)3 * c.num_layers * 128));
   EngPackP pk;
   memset(&pk, 0, sizeof(pk));
   pk.desc = desc_dev; pk.lens = lens_dev; pk.maxlen = P.maxlen; pk.ncw = (int)ncw;
@@ -2660,7 +2662,8 @@ int eng_launch(smi_llm* L, hipStream_t st) {
   p.kcache = (uint16_t*)L->kcache; p.vcache = (uint16_t*)L->vcache; p.kv_layer_elems = L->kv_layer_elems;
   p.gran = E.gran; p.serial = E.words; p.err = E.words + 4; p.arrive = E.words + 8;
   p.timeout_ticks = E.timeout_ticks;
-  p.ld_burst = E.ld_burst; p.ld_sleep = E.ld_sleep;
+  p.ld_burst = E.ld_burst; p.ld_sleep = E.ld_sleep; p.poll_quiet = E.poll_quiet;
+  for (int i = 0; i < 5; ++i) p.edge_delay[i] = E.edge_delay[i];
   p.stamps = getenv("SPARKMI_ENGINE_STAMPS") ? E.stamps : nullptr;
   hipLaunchKernelGGL(k_engine, dim3(E.ncu), dim3(kEngBlock), E.lds, st, p);
   SMI_LAUNCH_CHECK();
@@ -3920,11 +3923,11 @@ int smi_llm_debug_read(smi_llm* L, int what, void* out_host, size_t cap, size_t*
   return SMI_OK;
 }
 
-// Diagnostics (SPARKMI_ENGINE_STAMPS=1): out[2][layers][8] microseconds since the first stamp of the last engine launch:
+// Diagnostics (SPARKMI_ENGINE_STAMPS=1): out[3][layers][16] microseconds since the first stamp of the last engine launch:
 // CU 0 and the first head CU after the hand-offs A (h), B (q|k|v), C (attention), D (h_mid), E (act).
 int smi_llm_engine_stamps(smi_llm* L, double* out, int cap) {
   SMI_REQUIRE(L && out && L->eng.enabled, "smi_llm_engine_stamps: engine not built");
-  const int n = 2 * L->cfg.num_layers * 8;
+  const int n = 3 * L->cfg.num_layers * 16;
   SMI_REQUIRE(cap >= n, "smi_llm_engine_stamps: out holds %d values, %d needed", cap, n);
   std::vector<unsigned long long> h((size_t)n);
   SMI_HIP(hipDeviceSynchronize());

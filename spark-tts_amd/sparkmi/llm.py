@@ -364,11 +364,11 @@ class SparkLLM:
         _lib.check(self._lib.smi_llm_set_engine(self._h, 1 if on else 0), "smi_llm_set_engine")
 
     def engine_stamps(self) -> np.ndarray:
-        """(2, layers, 8) microseconds of the last engine launch (needs SPARKMI_ENGINE_STAMPS=1 in the environment)."""
-        n = 2 * self.cfg.num_hidden_layers * 8
+        """(3, layers, 16) microseconds of the last engine launch (needs SPARKMI_ENGINE_STAMPS=1 in the environment)."""
+        n = 3 * self.cfg.num_hidden_layers * 16
         out = (C.c_double * n)()
         _lib.check(self._lib.smi_llm_engine_stamps(self._h, out, n), "smi_llm_engine_stamps")
-        return np.array(out, dtype=np.float64).reshape(2, self.cfg.num_hidden_layers, 8)
+        return np.array(out, dtype=np.float64).reshape(3, self.cfg.num_hidden_layers, 16)
 
     def debug_hidden(self) -> np.ndarray:
         """The residual row of row 0 as the last step left it (tests)."""

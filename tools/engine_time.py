@@ -21,14 +21,15 @@ prompt = np.random.Generator(np.random.PCG64(1234)).integers(0, cfg.vocab_size, 
 # loader pacing variants (SPARKMI_ENGINE_BURST fills per look at the arrival counter, SPARKMI_ENGINE_SLEEP x 64-cycle pauses):
 # python tools/engine_time.py 4,0 1,2 16,0
 for knob in sys.argv[1:]:
-    b, z = knob.split(",")
-    os.environ["SPARKMI_ENGINE_BURST"], os.environ["SPARKMI_ENGINE_SLEEP"] = b, z
+    b, z, q = (knob.split(",") + ["1"])[:3]
+    os.environ["SPARKMI_ENGINE_BURST"], os.environ["SPARKMI_ENGINE_SLEEP"], os.environ["SPARKMI_ENGINE_POLL"] = b, z, q
     v = SparkLLM(cfg, None, "cuda:0", max_positions=MAXPOS, arena=arena)
     v.prefill([prompt]); v.decode(20)
     lay = v.time_kernel("layers", iters=32) * 1e3
-    print(f"burst {b} sleep {z}: layers {lay:7.1f} us ({lay / cfg.num_hidden_layers:5.2f} per layer)", flush=True)
+    print(f"burst {b} sleep {z} quiet-poll {q}: layers {lay:7.1f} us ({lay / cfg.num_hidden_layers:5.2f} per layer)", flush=True)
     v.close()
-os.environ.pop("SPARKMI_ENGINE_BURST", None); os.environ.pop("SPARKMI_ENGINE_SLEEP", None)
+for k in ("SPARKMI_ENGINE_BURST", "SPARKMI_ENGINE_SLEEP", "SPARKMI_ENGINE_POLL"):
+    os.environ.pop(k, None)
 llm = SparkLLM(cfg, None, "cuda:0", max_positions=MAXPOS, arena=arena)
 print("engine:", llm.engine_info(), flush=True)
 res = {}
@@ -57,4 +58,16 @@ if os.environ.get("SPARKMI_ENGINE_STAMPS"):
     order = [0, 5, 2, 3, 6, 4, 7]
     print("CU 0   (us after the layer's A, in time order):", "  ".join(f"{names[i]} {np.mean(d0[2:, i] - d0[2:, 0]):5.2f}" for i in order))
     print("head CU (us after the layer's A):", "  ".join(f"{names[i]} {np.mean(dh[2:, i] - dh[2:, 0]):5.2f}" for i in (0, 5, 1, 3, 6)), f" attention published {np.mean(dh[2:, 2] - dh[2:, 0]):5.2f}")
+    m = lambda i, j: float(np.mean(d0[2:, i] - d0[2:, j]))
+    print(f"CU 0 wave 0, QKV window: barrier -> jobs start {m(8, 0):.2f}, jobs {m(9, 8):.2f}, epilogue {m(10, 9):.2f}, -> barrier out {m(5, 10):.2f}")
+    print(f"CU 0 wave 0, gate_up window: barrier -> jobs start {m(11, 3):.2f}, jobs {m(12, 11):.2f}, epilogue {m(13, 12):.2f}, -> barrier out {m(6, 13):.2f}")
+    print(f"CU 0 wave 0, act hand-off: gate_up barrier out -> sweep done {m(14, 6):.2f}, staging {m(15, 14):.2f}, -> barrier out {m(4, 15):.2f}")
+    d7 = s[2]
+    m7 = lambda i, j: float(np.mean(d7[2:, i] - d7[2:, j]))
+    print(f"CU 0 wave 7 (loader), QKV window: barrier -> jobs start {m7(8, 0):.2f}, jobs {m7(9, 8):.2f}, epilogue {m7(10, 9):.2f}, -> barrier out {m7(5, 10):.2f}")
+    print(f"CU 0 wave 7 (loader), gate_up window: barrier -> jobs start {m7(11, 3):.2f}, jobs {m7(12, 11):.2f}, epilogue {m7(13, 12):.2f}, -> barrier out {m7(6, 13):.2f}")
+    raw = llm.engine_stamps()   # (microseconds since the first stamp; slot 14 of row 2 holds shader CYCLES scaled the same way)
+    cyc = (raw[2][-1, 14] - raw[2][2, 14]) * 100.0     # undo the 0.01 scaling: cycles
+    us = raw[2][-1, 0] - raw[2][2, 0]
+    print(f"shader clock during the launch: {cyc / us:.0f} MHz")
     print("layer period (CU 0):", float(np.mean(np.diff(d0[2:, 0]))), "us")
