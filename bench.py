@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--new-tokens", type=int, default=150)
     ap.add_argument("--kv", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--engine", action="store_true", help="one-row steps through the persistent-layer engine (csrc/smi_eng.h; opt-in A/B: slower than the launch path on MI355X, DESIGN.md 3.7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probes", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=150, help="tokens of the CPU-oracle utterance (SURVEY 8d: the whole configs[1] utterance)")
@@ -227,6 +228,12 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if a.gpus > 1 and not one_gpu and torch.cuda.device_count() < a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but this process sees {torch.cuda.device_count()} GPU(s): refusing to time fewer devices than asked for")
+    os.environ.setdefault("NCCL_DEBUG", "WARN")            # RCCL warnings reach stderr (and the driver's log)
+    pre = SD.preflight(torch.device("cpu") if one_gpu else dev, rank, world, a.gpus)   # raises on every rank if anything is off
+    if rank == 0 and world > 1:
+        log(f"preflight: {pre}")
     arch = _lib.require_gfx950()
     torch.set_num_threads(host_cores())
     if rank == 0:
@@ -272,6 +279,8 @@ def main():
     llm_arena, voc_arena, bcast_ms = SD.broadcast_arenas(
         llm_arena, voc_arena, SD.arena_sizes(cs_llm, cs_voc), dev, rank, world)
 
+    if a.engine:
+        os.environ["SPARKMI_ENGINE"] = "1"
     llm = SparkLLM(llm_cfg, None, dev, max_slots=B, max_positions=max_pos, kv_dtype=a.kv,
                    use_graph=not a.no_graph, arena=llm_arena)
     voc = BiCodecVocoder(voc_cfg, None, dev, max_batch=B, max_frames=max_frames, arena=voc_arena)
@@ -389,6 +398,7 @@ def main():
                    "device": arch, "build": build_hash()},
         "rtf": el / audio_s, "x_realtime": audio_s / el,
         "utterances_per_s": world * a.steps * B / el,
+        "multi_gpu_preflight": pre,
         "weights": {"build_s_rank0": t_build, "rccl_broadcast_ms": bcast_ms,
                     "llm_arena_bytes": int(llm_arena.numel()), "voc_arena_bytes": int(voc_arena.numel()) * 4},
         "stage_ms": {f"decode_{Nmax - 1}_steps": float(np.median(decode_ms)), "vocoder": float(np.median(voc_ms)),

@@ -171,10 +171,13 @@ int smi_llm_debug_stamps(smi_llm* h, int kernel, int layer, double* out);
  * 1024 tokens) the layers of a decode step run as one persistent launch -- one workgroup per CU, weights streamed through
  * LDS rings by LDS-DMA, the five all-to-all edges of a layer handed over inside the launch -- instead of four dependent
  * launches per layer; the arithmetic (every product, accumulator chain and addition order) is the launch path's, so the
- * tokens are the same bits.  Built at create when config and device fit (SPARKMI_ENGINE=0: never).
+ * tokens are the same bits.  OPT-IN (SPARKMI_ENGINE=1 at create, or smi_llm_set_engine(h, 1), which builds it on first use:
+ * 0.8 GB of re-packed weights): on MI355X at the 0.5B shape the five in-launch hand-offs of a layer cost more than the four
+ * kernel boundaries they replace (26.3 vs 23.4 us per layer), so the launch path stays the default.
  *   smi_llm_engine: *enabled = 1 when one-row steps take the engine; info[4] = {CUs, images per wave and layer, LDS bytes,
  *                   built}; why = a one-line reason / description.
- *   smi_llm_set_engine: runtime switch between the engine and the launch path (A/B, tests); synchronises the device.
+ *   smi_llm_set_engine: runtime switch between the engine and the launch path (A/B, tests); synchronises the device; on = 1
+ *                   where the engine does not apply (f32 / paged KV, odd shapes, small device) leaves it off (see `why`).
  *   smi_llm_engine_plan: host-only check of the static work plan for `ncu` CUs (no GPU call): every weight image placed
  *                   exactly once, stream order = job order; stats[8] = {images per wave max, per wave and phase max, parts per
  *                   CU and phase max, jobs per wave max, images per CU min, max, LDS bytes, images per layer}.

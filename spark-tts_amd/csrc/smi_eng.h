@@ -732,19 +732,33 @@ __global__ __launch_bounds__(kEngBlock, 1) void k_engine(EngP p) {
     if (np[EPH_DOWN] > 0) {
       if (!loader) {
         if (tid < kEngMaxSlots) cnt[tid] = 0u;
-        constexpr int EPT = 12;   // granules per thread in flight in one sweep (12 x 448 covers intermediate sizes up to 5376 in one pass)
-        for (int e0 = 0; e0 < I; e0 += EPT * kEngGather) {
-          int idx[EPT];
-          unsigned v[EPT];
+        // thread t takes the quads t, t + 448, t + 896 of four consecutive act values (12 granules in flight in one sweep:
+        // intermediate sizes up to 5376 in one pass); a quad's exact triples are one 8-byte LDS store per split term
+        constexpr int QPT = 3;
+        for (int q0 = 0; q0 < I / 4; q0 += QPT * kEngGather) {
+          int idx[4 * QPT];
+          unsigned v[4 * QPT];
 #pragma unroll
-          for (int k = 0; k < EPT; ++k) { const int e = e0 + tid + k * kEngGather; idx[k] = e < I ? gE + e : -1; }
+          for (int k = 0; k < QPT; ++k) {
+            const int q = q0 + tid + k * kEngGather;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) idx[4 * k + e] = q < I / 4 ? gE + 4 * q + e : -1;
+          }
           sy.predelay = p.edge_delay[4];
-          ok = eng_sweep_idx<EPT>(gb, idx, tl + 4, v, sy, (unsigned)(layer * 8 + 5)) && ok;
+          ok = eng_sweep_idx<4 * QPT>(gb, idx, tl + 4, v, sy, (unsigned)(layer * 8 + 5)) && ok;
           if (stamp) sp[14] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
-          for (int k = 0; k < EPT; ++k) {
-            const int e = e0 + tid + k * kEngGather;
-            if (e < I) eng_put3(xs_act, eng_xs_elem(e >> 5, e & 31), __uint_as_float(v[k]));
+          for (int k = 0; k < QPT; ++k) {
+            const int q = q0 + tid + k * kEngGather;
+            if (q < I / 4) {
+              uint32_t hi[4], mi[4], lo[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) split3(__uint_as_float(v[4 * k + e]), hi[e], mi[e], lo[e]);
+              unsigned char* o = xs_act + eng_xs_elem((4 * q) >> 5, (4 * q) & 31);
+              *(uint2*)(o) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+              *(uint2*)(o + 64) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
+              *(uint2*)(o + 128) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+            }
           }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -443,6 +443,17 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (j0 + u * NW < KT) {
+        if constexpr (LEAN == 2) {
+          // ONE row: the three split terms of the operand are three COLUMNS of one MFMA (lane (k8, col): col 0 hi, 1 mid, 2 lo;
+          // the other columns repeat hi and are never read), not three MFMAs with the same operand in every column.  A
+          // column's sum does not depend on its neighbours, so column c is bit for bit the old accumulator of split c -- one
+          // third of the matrix-pipe work and of the operand reads behind the last weight byte (the kernel's tail).
+          const bf16x8 b1 = *(const bf16x8*)(bw + ((size_t)((j0 - wave) / NW + u) * 12 + ((lane & 15) < 3 ? (lane & 15) : 0) * 4 + k8) * 16);
+#pragma unroll
+          for (int nb = 0; nb < NTB; ++nb)
+            acc[0][nb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wt[u][nb]), b1, acc[0][nb][0], 0, 0, 0);
+          continue;
+        }
         if (vlds) {
           const unsigned char* bp = bw + ((size_t)((j0 - wave) / NW + u) * 12 * M + k8 * M + mrow[0]) * 16;
 #pragma unroll
@@ -480,7 +491,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
   for (int nb = 0; nb < NTB; ++nb)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const f32x4 t = (acc[2][nb][mt] + acc[1][nb][mt]) + acc[0][nb][mt];   // (lo + mid) + hi
+      f32x4 t;
+      if constexpr (LEAN == 2) {   // columns 1 / 2 (lanes + 1 / + 2 of the row of 16) hold mid / lo; only column 0 -- the row -- is read later
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = (smi_dpp<0x102>(acc[0][nb][mt][r]) + smi_dpp<0x101>(acc[0][nb][mt][r])) + acc[0][nb][mt][r];
+      } else {
+        t = (acc[2][nb][mt] + acc[1][nb][mt]) + acc[0][nb][mt];   // (lo + mid) + hi
+      }
       red[((wave * NTB + nb) * MT + mt) * 64 + lane] = make_float4(t[0], t[1], t[2], t[3]);
     }
   if (EPI == EPI_LM) {
@@ -1408,25 +1425,21 @@ __global__ __launch_bounds__((FUSE ? 2 : 1) * kAttnWaves * 64) void k_attn(AttnP
       }
       __syncthreads();   // the attention waves' merge barrier
       __syncthreads();   // the head's output is in xsl
-      // MFMA column 0 is the row (the other columns see the same operand)
-      bf16x8 bo[2][3];
+      // MFMA columns 0 / 1 / 2 are the row's hi / mid / lo split terms (one MFMA per k tile instead of three; k_gemm LEAN == 2)
+      bf16x8 bo[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int s2 = 0; s2 < 3; ++s2) bo[j][s2] = *(const bf16x8*)(xsl + (size_t)((j * 3 + s2) * 4 + (lane >> 4)) * 16);
+      for (int j = 0; j < 2; ++j) bo[j] = *(const bf16x8*)(xsl + (size_t)((j * 3 + ((lane & 15) < 3 ? (lane & 15) : 0)) * 4 + (lane >> 4)) * 16);
 #pragma unroll
       for (int i = 0; i < kFuseOT; ++i) {
         const int nl = ow + kAttnWaves * i, nt = fq * fper + nl;
         if (nl < fper) {   // wave-uniform
-          f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+          f32x4 a0 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {   // the order of k_gemm's chains: tile by tile, lo / mid / hi in their own accumulators
-            const bf16x8 a = __builtin_bit_cast(bf16x8, wo[i][j]);
-            a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bo[j][2], a2, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bo[j][1], a1, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bo[j][0], a0, 0, 0, 0);
-          }
-          const f32x4 t = (a2 + a1) + a0;   // (lo + mid) + hi
+          for (int j = 0; j < 2; ++j)   // the order of k_gemm's chains: tile by tile, lo / mid / hi in their own accumulators (here: columns)
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wo[i][j]), bo[j], a0, 0, 0, 0);
+          f32x4 t;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[r] = (smi_dpp<0x102>(a0[r]) + smi_dpp<0x101>(a0[r])) + a0[r];   // (lo + mid) + hi
           if ((lane & 15) == 0)
             *(float4*)(p.part_o + (size_t)fh * (p.NTo * 16) + nt * 16 + 4 * (lane >> 4)) = make_float4(t[0], t[1], t[2], t[3]);
         }
@@ -3177,10 +3190,18 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
     smi_llm_destroy(L);
     return SMI_EHIP;
   }
-  L->eng_on = 1;
-  {
-    const int rce = eng_create(L);
-    if (rce) { smi_llm_destroy(L); return rce; }
+  // The one-row decode engine is opt-in (SPARKMI_ENGINE=1, or smi_llm_set_engine later: it is built on first request --
+  // 0.8 GB of re-packed weights): measured on MI355X at the 0.5B shape a layer takes 26.3 us in the engine against 23.4 us
+  // as four launches -- five in-launch hand-offs of 2.5-4.5 us cost more than the four kernel boundaries they replace
+  // (profiles/r03_engine_ab.txt).
+  L->eng_on = 0;
+  snprintf(L->eng.why, sizeof(L->eng.why), "off (opt-in: SPARKMI_ENGINE=1 or smi_llm_set_engine)");
+  { const char* e = getenv("SPARKMI_ENGINE");
+    if (e && e[0] == '1') {
+      const int rce = eng_create(L);
+      if (rce) { smi_llm_destroy(L); return rce; }
+      L->eng_on = L->eng.enabled;
+    }
   }
   *out = L;
   return SMI_OK;
@@ -3844,7 +3865,13 @@ int smi_llm_engine(smi_llm* L, int32_t* enabled, int32_t* info, char* why, int n
 
 int smi_llm_set_engine(smi_llm* L, int on) {
   SMI_REQUIRE(L, "smi_llm_set_engine: null handle");
-  const int v = on ? 1 : 0;
+  int v = on ? 1 : 0;
+  if (v && !L->eng.enabled) {   // first request: build it (plan, 0.8 GB weight stream); stays off, with the reason, where it does not apply
+    SMI_HIP(hipDeviceSynchronize());
+    const int rce = eng_create(L);
+    if (rce) return rce;
+    v = L->eng.enabled;
+  }
   if (v != L->eng_on) { SMI_HIP(hipDeviceSynchronize()); graphs_flush(L); }   // captured steps hold one path or the other
   L->eng_on = v;
   return SMI_OK;

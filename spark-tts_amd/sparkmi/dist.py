@@ -23,6 +23,53 @@ def arena_sizes(cs_llm, cs_voc) -> Tuple[int, int]:
     return int(l.smi_llm_arena_bytes(C.byref(cs_llm))), int(l.smi_voc_arena_bytes(C.byref(cs_voc))) // 4
 
 
+def preflight(device: torch.device, rank: int, world: int, expect_world: int) -> dict:
+    """Fail loudly and early on a multi-GPU launch that is not what was asked for -- nobody can rehearse the 8-GPU run on a
+    one-GPU lease, so everything that can be checked before the 1.4 GB broadcast is: the rank count, one distinct device per
+    rank, a 1 MB broadcast that must arrive intact (timed), and the collective library's version for the record.
+    Every rank calls it; raises RuntimeError on every rank when any check fails."""
+    info = {"world": world, "backend": dist.get_backend() if world > 1 else None, "rccl_version": None,
+            "small_broadcast_ms": None, "devices": None}
+    if world != expect_world:
+        raise RuntimeError(f"preflight: {world} ranks are running, {expect_world} were asked for")
+    if world == 1:
+        return info
+    if dist.get_world_size() != expect_world:
+        raise RuntimeError(f"preflight: process group has {dist.get_world_size()} ranks, {expect_world} were asked for")
+    if device.type == "cuda":
+        if torch.cuda.device_count() < 1:
+            raise RuntimeError("preflight: no GPU visible to this rank")
+        try:
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:   # noqa: BLE001 -- the version is for the record only
+            info["rccl_version"] = "unknown"
+    # one distinct device per rank (a launcher that maps two ranks to one card would halve the node silently)
+    mine = (device.type, device.index if device.index is not None else -1, torch.cuda.current_device() if device.type == "cuda" else -1)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    info["devices"] = [f"{t}:{i}" for t, i, _ in everyone]
+    if device.type == "cuda" and dist.get_backend() == "nccl" and len(set(everyone)) != world:
+        raise RuntimeError(f"preflight: ranks share devices: {everyone}")
+    # a small broadcast before the big one: pattern checked on every rank, time recorded
+    n = 1 << 20
+    stage = device if (device.type != "cuda" or dist.get_backend() == "nccl") else torch.device("cpu")
+    buf = (torch.arange(n, dtype=torch.int64, device=stage) % 251).to(torch.uint8) if rank == 0 else torch.zeros(n, dtype=torch.uint8, device=stage)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    dist.barrier()
+    t0 = time.perf_counter()
+    dist.broadcast(buf, src=0)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    info["small_broadcast_ms"] = (time.perf_counter() - t0) * 1e3
+    want = (torch.arange(n, dtype=torch.int64, device=stage) % 251).to(torch.uint8)
+    ok = torch.tensor([1 if torch.equal(buf, want) else 0], dtype=torch.int32, device=stage)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) != 1:
+        raise RuntimeError("preflight: the 1 MB test broadcast did not arrive intact on every rank")
+    return info
+
+
 def broadcast_arenas(llm_arena: Optional[torch.Tensor], voc_arena: Optional[torch.Tensor], sizes: Tuple[int, int],
                      device: torch.device, rank: int, world: int):
     """Rank 0 passes its arenas, the others pass None; returns (llm_arena, voc_arena, milliseconds)."""

@@ -45,8 +45,14 @@ class _TokenMap:
             if m:
                 self.glob[idx] = int(m.group(1))
         self.special = set(int(i) for i in getattr(tokenizer, "all_special_ids", []) or [])
+        # The reference decodes with skip_special_tokens=True (cli/SparkTTS.py:213): a bicodec token that a tokenizer lists
+        # as SPECIAL would be dropped there before the regex sees it.  The id tables cannot reproduce that, so such a
+        # tokenizer always takes the reference's decode + regex route.
+        self.usable = not (self.special & (set(self.sem) | set(self.glob)))
 
     def fast_parse(self, ids: Sequence[int]) -> Optional[Tuple[List[int], List[int]]]:
+        if not self.usable:
+            return None
         sem, glob = [], []
         for i in ids:
             if i in self.sem:

@@ -26,6 +26,13 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         dev = torch.device("cpu")
+        pre = SD.preflight(dev, rank, world, world)          # rank count, 1 MB test broadcast checked on every rank
+        assert pre["world"] == world and pre["small_broadcast_ms"] >= 0 and len(pre["devices"]) == world
+        try:
+            SD.preflight(dev, rank, world, world + 1)        # asked for another rank count: every rank refuses
+            raise AssertionError("preflight accepted a wrong rank count")
+        except RuntimeError:
+            pass
         sizes = (4096 + 17, 999)
         if rank == 0:
             a = torch.arange(sizes[0], dtype=torch.int64).to(torch.uint8)

@@ -41,8 +41,10 @@ def _run(llm, prompt, steps, engine):
 def test_engine_equals_launch_path_bit_for_bit_tiny(tiny, graph):
     cfg, syn = tiny
     llm = _llm(cfg, syn, max_positions=320, use_graph=graph)
+    assert not llm.engine_info()["enabled"]          # opt-in: the launch path is the default
+    llm.set_engine(True)
     info = llm.engine_info()
-    assert info["built"], f"engine not built: {info['why']}"
+    assert info["built"] and info["enabled"], f"engine not built: {info['why']}"
     prompt = np.random.Generator(np.random.PCG64(11)).integers(0, cfg.vocab_size, size=37).tolist()
     h_eng, t_eng = _run(llm, prompt, 270, True)      # crosses the 256-key chunk boundary of the attention
     h_ref, t_ref = _run(llm, prompt, 270, False)
@@ -53,6 +55,7 @@ def test_engine_equals_launch_path_bit_for_bit_tiny(tiny, graph):
 def test_engine_tokens_match_oracle_tiny(tiny):
     cfg, syn = tiny
     llm = _llm(cfg, syn, max_positions=128)
+    llm.set_engine(True)
     assert llm.engine_info()["enabled"]
     prompt = np.random.Generator(np.random.PCG64(12)).integers(0, cfg.vocab_size, size=21)
     got = llm.generate_ids([prompt.tolist()], 40)[0]
@@ -63,6 +66,7 @@ def test_engine_tokens_match_oracle_tiny(tiny):
 def test_engine_is_deterministic_and_survives_handle_reuse(tiny):
     cfg, syn = tiny
     llm = _llm(cfg, syn, max_positions=128)
+    llm.set_engine(True)
     rng = np.random.Generator(np.random.PCG64(13))
     p1 = rng.integers(0, cfg.vocab_size, size=30).tolist()
     p2 = rng.integers(0, cfg.vocab_size, size=9).tolist()
@@ -75,8 +79,11 @@ def test_engine_is_deterministic_and_survives_handle_reuse(tiny):
 def test_engine_off_for_batches_and_f32_kv(tiny):
     cfg, syn = tiny
     llm = _llm(cfg, syn, max_positions=128, kv_dtype="f32")
-    assert not llm.engine_info()["built"]
+    llm.set_engine(True)                           # does not apply to an f32 cache: stays off, says why
+    info = llm.engine_info()
+    assert not info["built"] and not info["enabled"] and "f32" in info["why"]
     llm2 = _llm(cfg, syn, max_positions=128, max_slots=4)
+    llm2.set_engine(True)
     rng = np.random.Generator(np.random.PCG64(14))
     prompts = [rng.integers(0, cfg.vocab_size, size=12 + i).tolist() for i in range(3)]
     got = llm2.generate_ids(prompts, 20)           # three rows: the launch path
@@ -93,6 +100,7 @@ def test_engine_full_size_equals_launch_path(golden_dir, full_llm):
     g = np.load(os.path.join(golden_dir, "llm_full.npz"))
     from conftest import FULL_MAX_POS
     llm = _llm(cfg, None, max_positions=FULL_MAX_POS, arena=arena)
+    llm.set_engine(True)
     info = llm.engine_info()
     assert info["enabled"], info["why"]
     prompt = g["prompt"].tolist()

@@ -246,3 +246,16 @@ def test_batch_of_voice_clone_requests_with_prompt_files(model_dir, tmp_path):
         one = tts.inference(r["text"], prompt_speech_path=r["prompt_speech_path"], prompt_text=r["prompt_text"], do_sample=False,
                             max_new_tokens=30)
         assert np.array_equal(one, w)
+
+
+def test_check_model_dir_tool_passes_on_a_synthetic_directory(model_dir):
+    """tools/check_model_dir.py -- HIP vs oracle on any directory in the published layout (what SURVEY 8c promises for the
+    day a real checkpoint is on the box): logits, greedy tokens (f32 and bf16 KV), one detokenize; exit code 0 = all pass."""
+    import importlib.util
+    import os
+    d, _ = model_dir
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_model_dir", os.path.join(root, "tools", "check_model_dir.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main([str(d), "--tokens", "24", "--max-positions", "512"]) == 0

@@ -14,6 +14,7 @@ layers = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 cfg = C.tiny_llm(layers=layers)
 syn = W.SyntheticLLM(cfg)
 llm = SparkLLM(cfg, syn, "cuda:0", max_positions=320, use_graph=False)
+llm.set_engine(True)
 print(llm.engine_info())
 H, Q, KV, I = cfg.hidden_size, cfg.q_dim, cfg.kv_dim, cfg.intermediate_size
 prompt = np.random.Generator(np.random.PCG64(11)).integers(0, cfg.vocab_size, size=37).tolist()

@@ -24,6 +24,7 @@ for knob in sys.argv[1:]:
     b, z, q = (knob.split(",") + ["1"])[:3]
     os.environ["SPARKMI_ENGINE_BURST"], os.environ["SPARKMI_ENGINE_SLEEP"], os.environ["SPARKMI_ENGINE_POLL"] = b, z, q
     v = SparkLLM(cfg, None, "cuda:0", max_positions=MAXPOS, arena=arena)
+    v.set_engine(True)
     v.prefill([prompt]); v.decode(20)
     lay = v.time_kernel("layers", iters=32) * 1e3
     print(f"burst {b} sleep {z} quiet-poll {q}: layers {lay:7.1f} us ({lay / cfg.num_hidden_layers:5.2f} per layer)", flush=True)
@@ -31,6 +32,7 @@ for knob in sys.argv[1:]:
 for k in ("SPARKMI_ENGINE_BURST", "SPARKMI_ENGINE_SLEEP", "SPARKMI_ENGINE_POLL"):
     os.environ.pop(k, None)
 llm = SparkLLM(cfg, None, "cuda:0", max_positions=MAXPOS, arena=arena)
+llm.set_engine(True)
 print("engine:", llm.engine_info(), flush=True)
 res = {}
 for on in (True, False):
