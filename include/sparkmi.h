@@ -37,7 +37,7 @@ extern "C" {
 #define SMI_ENOMEM (-3)   /* device allocation failed */
 #define SMI_ESTATE (-4)   /* call sequence violated (e.g. decode before prefill) */
 
-#define SMI_ABI_VERSION 2   /* 2: eos id LISTS (generation_config.json holds several), per-sequence sampler streams */
+#define SMI_ABI_VERSION 3   /* 2: eos id LISTS, per-sequence sampler streams; 3: smi_llm_cfg.wd_plain (the W_down tile order is data, not environment), engine / debug entry points */
 #define SMI_MAX_EOS 4      /* eos ids per generation (HF stops on ANY id of generation_config.eos_token_id) */
 #define SMI_MAX_ROWS 64   /* rows (= concurrent sequences, or prompt tokens per prefill chunk) per step */
 
@@ -73,6 +73,11 @@ typedef struct smi_llm_cfg {
    * same either way. */
   int32_t kv_page_tokens;
   int32_t kv_pages;
+  /* Layout of the WD (down_proj) tiles IN THE ARENA the caller packed: 0 (default) = row-part-major [q:4][k8:4][r:4][8],
+   * 1 = the plain tile order of the other matrices (kept for A/B: sparkmi/arena.py packs it under SPARKMI_WD_PLAIN=1 and
+   * sets this field).  The library reads the layout from here, never from the environment: an arena and the handle that
+   * reads it cannot disagree silently. */
+  int32_t wd_plain;
 } smi_llm_cfg;
 
 /* Arena sections.  The arena is one device buffer the caller fills (see sparkmi/arena.py):

@@ -2313,6 +2313,7 @@ bool cfg_ok(const smi_llm_cfg* c) {
   if (c->max_slots < 1 || c->max_slots > kMaxRows || c->max_positions < 2) return false;
   if ((c->num_heads * c->head_dim) % 32) return false;
   if (c->kv_dtype != 0 && c->kv_dtype != 1) return false;
+  if (c->wd_plain != 0 && c->wd_plain != 1) return false;
   if (c->kv_page_tokens != 0) {   // paged KV: a power of two in 16..1024 that divides max_positions, and a pool of at least one page
     const int t = c->kv_page_tokens;
     if (t < 16 || t > 1024 || (t & (t - 1)) || c->max_positions % t || c->kv_pages < 1) return false;
@@ -2400,7 +2401,7 @@ struct smi_llm {
   int tune2;     // SPARKMI_TUNE2 bit mask (diagnostics)
   int pgemm_min_rows;   // prompt rows from which the prefill GEMM replaces row-grouped decode GEMMs (SPARKMI_PGEMM_MIN_ROWS)
   int pg_min[4];        // ... per kernel (QKV, o_proj, gate_up, down; SPARKMI_PGEMM_MIN_QKV / _O / _GU / _D override the common value)
-  int wd_parts;         // W_down tiles are stored row-part-major (include/sparkmi.h; SPARKMI_WD_PLAIN=1, read by the packer too: plain tile order, for A/B)
+  int wd_parts;         // W_down tiles are stored row-part-major (smi_llm_cfg.wd_plain == 0; include/sparkmi.h)
   int gu1_lo;           // rows from which (up to 16) gate_up runs the one-batch, three-tile shape with one m-tile (SPARKMI_GU1_LO; default 4)
   int gu1_rows;         // rows up to which gate_up runs its one-batch, three-tile shape (SPARKMI_GU1_ROWS; default 32)
   hipGraphExec_t graph; int graph_B, graph_seg, graph_ident;   // the step graph in use (owned by graph_cache)
@@ -3113,7 +3114,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   }
   { const char* e = getenv("SPARKMI_GU1_ROWS"); L->gu1_rows = e ? atoi(e) : 32; }
   { const char* e = getenv("SPARKMI_GU1_LO"); L->gu1_lo = e ? atoi(e) : 4; }
-  { const char* e = getenv("SPARKMI_WD_PLAIN"); L->wd_parts = !(e && e[0] && e[0] != '0'); }
+  L->wd_parts = cfg->wd_plain ? 0 : 1;   // the arena's W_down tile order comes with its config (never from the environment)
   L->pf_tiles = nullptr; L->pf_tiles_cap = 0; L->pf_ntiles = 0;
   { const char* e = getenv("SPARKMI_ATTN_PF2"); L->attn_pf2 = !(e && e[0] == '0'); }
   L->graph_stream = nullptr; L->graph_launched = 0;

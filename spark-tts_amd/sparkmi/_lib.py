@@ -14,7 +14,7 @@ LIB_PATH = Path(os.environ["SPARKMI_LIB"]) if os.environ.get("SPARKMI_LIB") else
 
 SMI_MAX_ROWS = 64
 SMI_MAX_EOS = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class SparkMIError(RuntimeError):
@@ -25,7 +25,7 @@ class LLMCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "vocab_size", "hidden_size", "num_layers", "num_heads", "num_kv_heads", "head_dim",
         "intermediate_size", "max_slots", "max_positions", "kv_dtype", "use_graph")] + [("rms_eps", C.c_float),
-                                                                                        ("kv_page_tokens", C.c_int32), ("kv_pages", C.c_int32)]
+                                                                                        ("kv_page_tokens", C.c_int32), ("kv_pages", C.c_int32), ("wd_plain", C.c_int32)]
 
 
 class VocCfg(C.Structure):

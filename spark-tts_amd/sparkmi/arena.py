@@ -43,7 +43,8 @@ class Bf16RoundingReport:
 
 
 def wd_row_parts() -> bool:
-    """W_down tile order (include/sparkmi.h): row-part-major unless SPARKMI_WD_PLAIN=1 (A/B; the library reads the same variable)."""
+    """W_down tile order (include/sparkmi.h): row-part-major unless SPARKMI_WD_PLAIN=1 (a packer-side A/B switch: it only sets
+    ``smi_llm_cfg.wd_plain``, which travels with the arena's config; the library never reads the variable)."""
     e = os.environ.get("SPARKMI_WD_PLAIN", "")
     return not (e and e != "0")
 
@@ -109,7 +110,7 @@ def llm_cfg_struct(cfg: LLMConfig, max_slots: int, max_positions: int, kv_dtype:
         num_heads=cfg.num_attention_heads, num_kv_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
         intermediate_size=cfg.intermediate_size, max_slots=max_slots, max_positions=max_positions,
         kv_dtype={"bf16": 0, "f32": 1}[kv_dtype], use_graph=int(use_graph), rms_eps=cfg.rms_norm_eps,
-        kv_page_tokens=int(kv_page_tokens), kv_pages=int(kv_pages))
+        kv_page_tokens=int(kv_page_tokens), kv_pages=int(kv_pages), wd_plain=0 if wd_row_parts() else 1)
 
 
 def pack_llm_arena(cfg: LLMConfig, weights: Mapping[str, np.ndarray], cs: _lib.LLMCfg,
@@ -150,7 +151,7 @@ def pack_llm_arena(cfg: LLMConfig, weights: Mapping[str, np.ndarray], cs: _lib.L
         gu = np.empty((2 * g.shape[0], g.shape[1]), np.float32)
         gu[0::2], gu[1::2] = g, u
         put(_lib.LLM_WGU, i, pack_tiles(gu, rep, p + "mlp.gate_up"))
-        put(_lib.LLM_WD, i, pack_tiles(f32(weights[p + "mlp.down_proj.weight"]), rep, p + "mlp.down_proj", row_parts=wd_row_parts()))
+        put(_lib.LLM_WD, i, pack_tiles(f32(weights[p + "mlp.down_proj.weight"]), rep, p + "mlp.down_proj", row_parts=not cs.wd_plain))
     put(_lib.LLM_FINAL_NORM, 0, f32(weights["model.norm.weight"]))
     head = "model.embed_tokens.weight" if cfg.tie_word_embeddings else "lm_head.weight"
     if not cfg.tie_word_embeddings:

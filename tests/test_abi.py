@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(l, n), f"{n} declared in sparkmi.h but not exported"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes signature in sparkmi/_lib.py"
-    assert l.smi_version() == _lib.ABI_VERSION == 2
+    assert l.smi_version() == _lib.ABI_VERSION == 3
 
 
 def test_product_library_exports_only_the_declared_abi():

@@ -43,12 +43,12 @@ vc = _lib.VocCfg()
 from sparkmi.bicodec import voc_cfg_struct
 vs = voc_cfg_struct(Cf.tiny_bicodec(), 2, 64)
 nent = l.smi_voc_arena_count(C.byref(vs))
-name = C.create_string_buffer(256); info = (C.c_int32 * 6)()
+name = C.create_string_buffer(8192); info = (C.c_int32 * 6)()
 off, n = C.c_size_t(), C.c_size_t()
 for i in range(nent):
-    assert l.smi_voc_arena_entry(C.byref(vs), i, name, 256, C.byref(off), C.byref(n), info) == 0
-assert l.smi_voc_arena_entry(C.byref(vs), nent + 5, name, 256, C.byref(off), C.byref(n), info) != 0
-assert l.smi_voc_arena_entry(C.byref(vs), 0, name, 2, C.byref(off), C.byref(n), info) in (0, -1)   # tiny name buffer
+    assert l.smi_voc_arena_entry(C.byref(vs), i, name, 8192, C.byref(off), C.byref(n), info) == 0
+assert l.smi_voc_arena_entry(C.byref(vs), nent + 5, name, 8192, C.byref(off), C.byref(n), info) != 0   # past the table
+l.smi_voc_arena_entry(C.byref(vs), 0, name, 2, C.byref(off), C.byref(n), info)                        # tiny name buffer: any verdict, no overrun
 print("asan child ok")
 '''
 
@@ -63,9 +63,9 @@ def test_host_code_is_clean_under_address_sanitizer():
     rt = _runtime()
     if rt is None:
         pytest.skip("clang's ASAN runtime is not in this image")
-    if not os.path.exists(LIB):
-        r = subprocess.run(["make", "-C", CSRC, "asan"], capture_output=True, text=True, timeout=1400)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    # make decides whether the instrumented library is stale (sources or headers newer than it)
+    r = subprocess.run(["make", "-C", CSRC, "asan"], capture_output=True, text=True, timeout=1400)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     env = dict(os.environ, LD_PRELOAD=rt, SPARKMI_LIB=LIB, SMI_ROOT=ROOT,
                ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23:protect_shadow_gap=0")
     r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, env=env, timeout=600)

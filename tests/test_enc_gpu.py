@@ -159,3 +159,31 @@ def test_graph_replay_equals_eager_launches(tiny, monkeypatch):
     ge, se = eager.tokenize_arrays(wavs[0][:9000], refs[0])
     assert torch.equal(short[0], ge) and torch.equal(short[1], se)
     assert torch.equal(again[0], got[1][0]) and torch.equal(again[1], got[1][1])
+
+
+@pytest.mark.timeout(900)
+def test_config5_eight_prompts_at_full_size_streams_and_graph_replay(golden_dir):
+    """BASELINE configs[4]'s prompt-encode leg as the bench runs it (audio_tokenizer.py:85-130, bicodec.py:151-169): eight
+    six-second prompts at wav2vec2-large-xlsr-53 size through `tokenize_many` -- eight HIP streams, per-lane handles -- twice
+    (the second pass replays the hipGraph captured per shape).  The ids of both passes equal eight one-by-one eager calls bit
+    for bit; prompt 0 is the golden prompt and reproduces tests/golden/tok_full.npz (the reference modules' own tokens)."""
+    wcfg, tcfg, vcfg = T.xlsr53(), T.spark_0p5b_tok(), C.spark_0p5b_bicodec()
+    g = np.load(os.path.join(golden_dir, "tok_full.npz"))
+    enc, wsd, tsd = _build(wcfg, tcfg, vcfg, max_seconds=6.0, ref_seconds=6.0)
+    base = g["wav"].astype(np.float32)
+    wavs = [np.roll(base, int(8000 * i)) for i in range(8)]               # SURVEY 8d cfg 5: the prompt shifted by i * 0.5 s
+    refs = [get_ref_clip(w.astype(np.float64), 16000, 6.0, tcfg.hop_length).astype(np.float32) for w in wavs]
+    first = enc.tokenize_many(wavs, refs, lanes=8)                        # eager on every lane (shape seen once per lane)
+    torch.cuda.synchronize()
+    second = enc.tokenize_many(wavs, refs, lanes=8)                       # capture + replay
+    third = enc.tokenize_many(wavs, refs, lanes=8)                        # replay
+    torch.cuda.synchronize()
+    one = [enc.tokenize_arrays(w, r) for w, r in zip(wavs, refs)]
+    for i in range(8):
+        for many in (first, second, third):
+            assert torch.equal(many[i][0], one[i][0]) and torch.equal(many[i][1], one[i][1]), f"prompt {i}"
+    sem0, glob0 = one[0][1].cpu().numpy(), one[0][0].cpu().numpy()
+    assert sem0.shape == g["sem"].shape
+    assert (sem0 == g["sem"]).mean() > 0.97 and (glob0 == g["glob"]).mean() > 0.9
+    # the shifted prompts are different inputs: their ids must not all collapse onto prompt 0's
+    assert any(not torch.equal(one[i][1], one[0][1]) for i in range(1, 8))
