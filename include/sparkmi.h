@@ -251,6 +251,34 @@ int smi_voc_debug_stage(smi_voc* h, int stage, float* out_dev, size_t max_floats
 int smi_voc_num_launches(smi_voc* h);
 int smi_voc_time_launch(smi_voc* h, int index, int iters, float* ms_avg, double* flops, char* name, int name_cap, void* stream);
 
+/* One block of the vocoder on caller tensors -- the op-level test entry points.  The launches are built by the very functions
+ * smi_voc_forward builds them with (same kernels, launch geometry and epilogue fusions), so the reference's own layer classes
+ * can be checked one at a time: ResidualUnit (sparktts/modules/blocks/layers.py:51-67), DecoderBlock
+ * (sparktts/modules/encoder_decoder/wave_generator.py:29-53), ConvNeXtBlock with LayerNorm or AdaLayerNorm
+ * (sparktts/modules/blocks/vocos.py:26-110).  A block's little arena is described exactly like the vocoder's
+ * (smi_voc_block_arena_entry: names are "L." + the layer's own state_dict keys, "cat:a|b" = rows concatenated). */
+enum { SMI_VOC_BLOCK_RESUNIT = 0, SMI_VOC_BLOCK_DECBLOCK = 1, SMI_VOC_BLOCK_CONVNEXT = 2 };
+typedef struct smi_voc_block_cfg {
+  int32_t kind;        /* SMI_VOC_BLOCK_* */
+  int32_t C;           /* RESUNIT: channels; DECBLOCK: input channels; CONVNEXT: model dim */
+  int32_t Cout;        /* DECBLOCK: output channels */
+  int32_t K, S;        /* DECBLOCK: ConvTranspose1d kernel size and stride (padding (K - S) / 2) */
+  int32_t dil;         /* RESUNIT: dilation of the 7-tap conv (1, 3 or 9) */
+  int32_t I;           /* CONVNEXT: intermediate dim */
+  int32_t cond_dim;    /* CONVNEXT: 0 = LayerNorm; > 0 = AdaLayerNorm on a [B][cond_dim] condition */
+  int32_t exact_fp32;  /* as smi_voc_cfg.exact_fp32 */
+} smi_voc_block_cfg;
+int smi_voc_block_arena_count(const smi_voc_block_cfg* cfg);
+size_t smi_voc_block_arena_bytes(const smi_voc_block_cfg* cfg);
+int smi_voc_block_arena_entry(const smi_voc_block_cfg* cfg, int index, char* name, int name_cap,
+                              size_t* offset, size_t* bytes, int32_t* info);
+/* x_dev [B][C][L] f32 (contiguous), y_dev [B][C or Cout][L or L * S].  The vocoder applies a block's LEADING Snake in the
+ * producer's epilogue, so: RESUNIT takes x_dev and xs_dev = snake(x, block.0.alpha); DECBLOCK takes only xs_dev =
+ * snake(x, block.0.alpha); CONVNEXT takes x_dev (and cond_dev [B][cond_dim] for AdaLayerNorm).  lens_host (may be null =
+ * all rows full) masks ragged rows as in smi_voc_forward.  Synchronises the stream before returning. */
+int smi_voc_block_run(const smi_voc_block_cfg* cfg, const void* arena_dev, size_t arena_bytes, const float* x_dev,
+                      const float* xs_dev, const float* cond_dev, const int32_t* lens_host, int B, int L, float* y_dev, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Prompt encoder (voice cloning): BiCodecTokenizer.tokenize (sparktts/models/audio_tokenizer.py:85-130)
  * = zero-mean/unit-variance wav -> wav2vec2 (layers below the last tapped hidden state) -> mean of

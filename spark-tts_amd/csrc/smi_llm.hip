@@ -3740,10 +3740,7 @@ int smi_llm_forward_logits(smi_llm* L, const int64_t* ids, int S, float* logits_
 int smi_llm_debug_stamps(smi_llm* L, int kernel, int layer, double* out) {
   SMI_REQUIRE(L && out && L->started, "smi_llm_debug_stamps: needs a started generation");
   SMI_REQUIRE(kernel == KQKV || kernel == KO || kernel == KGU || kernel == KD || kernel == KLM, "smi_llm_debug_stamps: GEMM kernels only");
-  const int grids[] = {L->NTqkv, 0, L->NTh, (L->NTgu + 1) / 2, L->NTh, 0};
-  const int nblk = kernel == KLM ? ((L->B <= 16 && L->KTh <= 32) ? 0 : L->lm_cap) : grids[kernel];
-  SMI_REQUIRE(nblk > 0, "smi_llm_debug_stamps: the persistent lm_head has no stamps");
-  SMI_REQUIRE(nblk <= 4096, "smi_llm_debug_stamps: grid too large");
+  SMI_REQUIRE(!(kernel == KLM && L->B <= 16 && L->KTh <= 32), "smi_llm_debug_stamps: the persistent lm_head has no stamps");
   SMI_HIP(hipMemset(L->stamps, 0, (size_t)4096 * 64));
   L->stamps_on = 1;
   graphs_flush(L);   // (the stamped kernels are other instantiations)
@@ -3751,8 +3748,12 @@ int smi_llm_debug_stamps(smi_llm* L, int kernel, int layer, double* out) {
   L->stamps_on = 0;
   if (rc) return rc;
   SMI_HIP(hipDeviceSynchronize());
-  std::vector<unsigned long long> h((size_t)nblk * 8);
+  // the launch's grid depends on the row count: the blocks that ran are the ones that left an entry stamp
+  std::vector<unsigned long long> h((size_t)4096 * 8);
   SMI_HIP(hipMemcpy(h.data(), L->stamps, h.size() * 8, hipMemcpyDeviceToHost));
+  int nblk = 0;
+  while (nblk < 4096 && h[(size_t)nblk * 8]) ++nblk;
+  SMI_REQUIRE(nblk > 0, "smi_llm_debug_stamps: the kernel left no stamps");
   unsigned long long t0 = ~0ull;
   for (int b = 0; b < nblk; ++b) t0 = h[(size_t)b * 8] < t0 ? h[(size_t)b * 8] : t0;
   for (int i = 0; i < 7; ++i) {

@@ -156,23 +156,180 @@ struct smi_voc {
 
 namespace {
 
-const float* ent(const smi_voc* h, const std::string& name) {
-  for (const Entry& e : h->lay.e)
-    if (e.name == name) return (const float*)(h->arena + e.offset);
-  return nullptr;
-}
-bool ent_is_bf(const smi_voc* h, const std::string& name) {
-  for (const Entry& e : h->lay.e)
-    if (e.name == name) return e.kind == PACK_CONV_B || e.kind == PACK_CONVT_B;
-  return false;
-}
+// Where a group of launches finds its packed weights: a table of entries (the vocoder's arena, or one block's -- smi_voc_block_*)
+struct WSrc {
+  const std::vector<Entry>* e;
+  const unsigned char* arena;
+  const float* get(const std::string& name) const {
+    for (const Entry& x : *e)
+      if (x.name == name) return (const float*)(arena + x.offset);
+    return nullptr;
+  }
+  bool is_bf(const std::string& name) const {
+    for (const Entry& x : *e)
+      if (x.name == name) return x.kind == PACK_CONV_B || x.kind == PACK_CONVT_B;
+    return false;
+  }
+};
+WSrc wsrc(const smi_voc* h) { return WSrc{&h->lay.e, h->arena}; }
+const float* ent(const smi_voc* h, const std::string& name) { return wsrc(h).get(name); }
 
+Launch make_conv(const WSrc& w, const std::string& name, const std::string& wname, const char* bname,
+                 int Cout, int Cin, int K, int dil, int S, int pad, const float* X, int xstride, long long xb,
+                 float* Y, float* Ys, const float* alpha, const float* R, int ystride, long long yb,
+                 const int* lens, int B, int Lmax, int act) {
+  return make_conv_w(name, w.get(wname), bname ? w.get(bname) : nullptr, Cout, Cin, K, dil, S, pad, X, xstride, xb, Y, Ys,
+                     alpha, R, ystride, yb, lens, B, Lmax, act, 1, nullptr, w.is_bf(wname));
+}
 Launch make_conv(const smi_voc* h, const std::string& name, const std::string& wname, const char* bname,
                  int Cout, int Cin, int K, int dil, int S, int pad, const float* X, int xstride, long long xb,
                  float* Y, float* Ys, const float* alpha, const float* R, int ystride, long long yb,
                  const int* lens, int B, int Lmax, int act) {
-  return make_conv_w(name, ent(h, wname), bname ? ent(h, bname) : nullptr, Cout, Cin, K, dil, S, pad, X, xstride, xb, Y, Ys,
-                     alpha, R, ystride, yb, lens, B, Lmax, act, 1, nullptr, ent_is_bf(h, wname));
+  return make_conv(wsrc(h), name, wname, bname, Cout, Cin, K, dil, S, pad, X, xstride, xb, Y, Ys, alpha, R, ystride, yb, lens, B, Lmax, act);
+}
+
+// ---- launch builders shared by smi_voc_forward and the one-block entry points (smi_voc_block_run): the same kernels,
+//      the same launch geometry, the same fusions
+
+// ResidualUnit (blocks/layers.py:51-67): y = x + conv1(snake(conv7_dil(snake(x)))).  US holds snake(U, <u>.0.alpha) -- the
+// producer's second output; conv7's epilogue applies the unit's second Snake (-> A); the 1x1 adds the residual U and writes
+// the new U to `rawout` (may be null) and snake(new U, next_alpha) to `US_out` (may be null).
+void add_res_unit(std::vector<Launch>& P, const WSrc& w, const std::string& u, int C, int dil, const float* U, const float* US,
+                  float* A, float* rawout, float* US_out, const float* next_alpha, int L, long long bs, const int* lens, int B) {
+  P.push_back(make_conv(w, u + ".conv7", u + ".1.weight", (u + ".1.bias").c_str(), C, C, 7, dil, 1, 3 * dil, US, L, bs,
+                        nullptr, A, w.get(u + ".2.alpha"), nullptr, L, bs, lens, B, L, ACT_NONE));
+  P.push_back(make_conv(w, u + ".conv1+res", u + ".3.weight", (u + ".3.bias").c_str(), C, C, 1, 1, 1, 0, A, L, bs,
+                        rawout, US_out, next_alpha, U, L, bs, lens, B, L, ACT_NONE));
+}
+
+// DecoderBlock (encoder_decoder/wave_generator.py:29-53) on s_in = snake(x, <b>.0.alpha) (left by the producer):
+// ConvTranspose1d (polyphase) -> U raw, US = snake(U, unit 2's first alpha); three ResidualUnits (dilation 1, 3, 9).
+// The last unit writes its raw output to `raw_final` (may be null) and snake(., next_alpha) to US (next_alpha may be null).
+void add_dec_block(std::vector<Launch>& P, const WSrc& w, const std::string& b, int cin, int cout, int k, int s, const float* s_in,
+                   int Lin, long long bs_in, float* U, float* US, float* A, float* raw_final, const float* next_alpha, long long bs,
+                   const int* lens_in, const int* lens_out, int B) {
+  const int Lout = Lin * s;
+  P.push_back(make_conv(w, b + ".convT", b + ".1.weight", (b + ".1.bias").c_str(), cout, cin, k, 1, s, (k - s) / 2, s_in, Lin, bs_in,
+                        U, US, w.get(b + ".2.block.0.alpha"), nullptr, Lout, bs, lens_in, B, Lin, ACT_NONE));
+  for (int r = 0; r < 3; ++r) {
+    const std::string u = b + "." + std::to_string(r + 2) + ".block";
+    const int dil = r == 0 ? 1 : (r == 1 ? 3 : 9);
+    const bool last = r == 2;
+    const float* na = last ? next_alpha : w.get(b + "." + std::to_string(r + 3) + ".block.0.alpha");
+    add_res_unit(P, w, u, cout, dil, U, US, A, last ? raw_final : U, (last && !next_alpha) ? nullptr : US, na, Lout, bs, lens_out, B);
+  }
+}
+
+// LayerNorm / AdaLayerNorm over channels, optionally behind the depthwise conv7 of a ConvNeXt block (k_dwln)
+void add_lnorm(std::vector<Launch>& P, const WSrc& w, const std::string& name, const std::string& pfx, const float* ada, int ada_stride,
+               const float* dww, const float* dwb, const float* X, float* Y, int triple, int D, int T, long long bs, const int* lens, int B) {
+  Launch L; L.kind = 1; L.name = name; L.flops = (dww ? 14.0 : 0.0) * D * T * B + 8.0 * D * T * B;
+  LnP& p = L.lp; memset(&p, 0, sizeof(p));
+  p.X = X; p.Y = Y; p.dww = dww; p.dwb = dwb; p.lens = lens; p.C = D; p.stride = T; p.bs = bs; p.triple = triple;
+  p.eps = 1e-6f;
+  if (ada) { p.ada = ada; p.ada_stride = ada_stride; }
+  else { p.w = w.get(pfx + ".weight"); p.bsh = w.get(pfx + ".bias"); }
+  L.cpt = (D + 31) / 32; L.grid = dim3((T + 7) / 8, B);
+  P.push_back(L);
+}
+
+// ConvNeXtBlock (blocks/vocos.py:26-62): x += gamma * pwconv2(GELU(pwconv1(norm(dwconv7(x))))); n, m: scratch
+void add_convnext(std::vector<Launch>& P, const WSrc& w, const std::string& b, int D, int I, float* x, float* n, float* m,
+                  const float* ada, int ada_stride, int T, long long bs, const int* lens, int B) {
+  add_lnorm(P, w, b + ".dwconv+norm", b + ".norm", ada, ada_stride, w.get(b + ".dwconv.weight"), w.get(b + ".dwconv.bias"), x, n, 0, D, T, bs, lens, B);
+  P.push_back(make_conv(w, b + ".pwconv1", b + ".pwconv1.weight", (b + ".pwconv1.bias").c_str(), I, D, 1, 1, 1, 0, n, T, bs, m,
+                        nullptr, nullptr, nullptr, T, bs, lens, B, T, ACT_GELU));
+  P.push_back(make_conv(w, b + ".pwconv2", b + ".pwconv2.weight", (b + ".pwconv2.bias").c_str(), D, I, 1, 1, 1, 0, m, T, bs, x,
+                        nullptr, nullptr, x, T, bs, lens, B, T, ACT_NONE));
+  P.back().cp.gamma = w.get(b + ".gamma");
+}
+
+// what every conv launch must satisfy before it runs (the kernels' staging limits)
+int check_launches(const std::vector<Launch>& P, const char* who) {
+  for (const Launch& L : P) {
+    if (L.kind == 0) {
+      SMI_REQUIRE(L.cp.W, "%s: arena entry for %s not found", who, L.name.c_str());
+      SMI_REQUIRE(L.lds <= 64 * 1024, "%s: %s needs %zu bytes of LDS", who, L.name.c_str(), L.lds);
+      SMI_REQUIRE(L.cp.xw <= 128 && (L.chg != 4 || L.cp.xw <= 64), "%s: %s stages %d columns", who, L.name.c_str(), L.cp.xw);
+    }
+  }
+  return SMI_OK;
+}
+
+// ---- one reference block as its own little arena (smi_voc_block_*: op-level tests on the reference's layer classes)
+bool block_cfg_ok(const smi_voc_block_cfg* c) {
+  if (!c) return false;
+  switch (c->kind) {
+    case SMI_VOC_BLOCK_RESUNIT: return c->C >= 1 && c->C <= 4096 && (c->dil == 1 || c->dil == 3 || c->dil == 9);
+    case SMI_VOC_BLOCK_DECBLOCK:
+      return c->C >= 1 && c->Cout >= 1 && c->C <= 4096 && c->Cout <= 4096 && c->S >= 1 && c->S <= kMaxPhases && c->K >= c->S &&
+             (c->K - c->S) % 2 == 0 && (c->K + c->S - 1) / c->S <= kMaxTaps;
+    case SMI_VOC_BLOCK_CONVNEXT: return c->C >= 1 && c->C <= 512 && c->I >= 1 && c->I <= 8192 && c->cond_dim >= 0 && c->cond_dim <= 4096;
+  }
+  return false;
+}
+
+VocLayout block_layout(const smi_voc_block_cfg* c) {
+  VocLayout L;
+  size_t o = 0;
+  auto add = [&](const std::string& name, int kind, int Cout, int Cin, int K, int S, int pad, size_t floats) {
+    Entry e{name, kind, Cout, Cin, K, S, pad, o, floats * 4};
+    L.e.push_back(e);
+    o += smi_align_up(floats * 4, 256);
+  };
+  auto raw = [&](const std::string& name, size_t n) { add(name, PACK_RAW, 0, 0, 0, 1, 0, n); };
+  auto use_bf = [&](int Cout, int Cin) { return !c->exact_fp32 && Cin >= 32 && Cout >= 32; };   // the vocoder's own rule (voc_layout)
+  auto conv = [&](const std::string& name, int Cout, int Cin, int K) {
+    const bool bf = use_bf(Cout, Cin);
+    add(name, bf ? PACK_CONV_B : PACK_CONV, Cout, Cin, K, 1, 0, (size_t)conv_geom(Cout, Cin, K, 1, 0, 1, bf).floats);
+  };
+  auto unit = [&](const std::string& u, int C) {
+    raw(u + ".0.alpha", C);
+    conv(u + ".1.weight", C, C, 7);
+    raw(u + ".1.bias", C);
+    raw(u + ".2.alpha", C);
+    conv(u + ".3.weight", C, C, 1);
+    raw(u + ".3.bias", C);
+  };
+  if (c->kind == SMI_VOC_BLOCK_RESUNIT) {
+    unit("L.block", c->C);
+  } else if (c->kind == SMI_VOC_BLOCK_DECBLOCK) {
+    raw("L.block.0.alpha", c->C);
+    const bool bf = use_bf(c->Cout, c->C);
+    add("L.block.1.weight", bf ? PACK_CONVT_B : PACK_CONVT, c->Cout, c->C, c->K, c->S, (c->K - c->S) / 2,
+        (size_t)conv_geom(c->Cout, c->C, c->K, 1, (c->K - c->S) / 2, c->S, bf).floats);
+    raw("L.block.1.bias", c->Cout);
+    for (int r = 0; r < 3; ++r) unit("L.block." + std::to_string(r + 2) + ".block", c->Cout);
+  } else {
+    const int D = c->C;
+    raw("L.dwconv.weight", (size_t)D * 7);
+    raw("L.dwconv.bias", D);
+    if (c->cond_dim > 0) {
+      add("cat:L.norm.scale.weight|L.norm.shift.weight", PACK_CONV, 2 * D, c->cond_dim, 1, 1, 0, (size_t)conv_geom(2 * D, c->cond_dim, 1, 1, 0, 1).floats);
+      raw("cat:L.norm.scale.bias|L.norm.shift.bias", (size_t)2 * D);
+    } else {
+      raw("L.norm.weight", D);
+      raw("L.norm.bias", D);
+    }
+    conv("L.pwconv1.weight", c->I, D, 1);
+    raw("L.pwconv1.bias", c->I);
+    conv("L.pwconv2.weight", D, c->I, 1);
+    raw("L.pwconv2.bias", D);
+    raw("L.gamma", D);
+  }
+  L.total = o;
+  return L;
+}
+
+int layout_entry(const VocLayout& L, int index, char* name, int name_cap, size_t* offset, size_t* bytes, int32_t* info, const char* who) {
+  SMI_REQUIRE(index >= 0 && index < (int)L.e.size(), "%s: index %d out of range", who, index);
+  const Entry& e = L.e[index];
+  SMI_REQUIRE(name && name_cap > (int)e.name.size(), "%s: name buffer too small (%zu needed)", who, e.name.size() + 1);
+  strcpy(name, e.name.c_str());
+  if (offset) *offset = e.offset;
+  if (bytes) *bytes = e.bytes;
+  if (info) { info[0] = e.kind; info[1] = e.Cout; info[2] = e.Cin; info[3] = e.K; info[4] = e.S; info[5] = e.pad; }
+  return SMI_OK;
 }
 
 }  // namespace
@@ -192,15 +349,7 @@ size_t smi_voc_arena_bytes(const smi_voc_cfg* cfg) {
 int smi_voc_arena_entry(const smi_voc_cfg* cfg, int index, char* name, int name_cap, size_t* offset, size_t* bytes,
                         int32_t* info) {
   SMI_REQUIRE(voc_cfg_ok(cfg), "smi_voc_arena_entry: config outside the kernel contract");
-  VocLayout L = voc_layout(cfg);
-  SMI_REQUIRE(index >= 0 && index < (int)L.e.size(), "smi_voc_arena_entry: index %d out of range", index);
-  const Entry& e = L.e[index];
-  SMI_REQUIRE(name && name_cap > (int)e.name.size(), "smi_voc_arena_entry: name buffer too small (%zu needed)", e.name.size() + 1);
-  strcpy(name, e.name.c_str());
-  if (offset) *offset = e.offset;
-  if (bytes) *bytes = e.bytes;
-  if (info) { info[0] = e.kind; info[1] = e.Cout; info[2] = e.Cin; info[3] = e.K; info[4] = e.S; info[5] = e.pad; }
-  return SMI_OK;
+  return layout_entry(voc_layout(cfg), index, name, name_cap, offset, bytes, info, "smi_voc_arena_entry");
 }
 
 int smi_voc_create(const smi_voc_cfg* cfg, const void* arena_dev, size_t arena_bytes, smi_voc** out) {
@@ -350,16 +499,10 @@ int smi_voc_forward(smi_voc* h, const int64_t* sem_dev, const int32_t* lens_host
                         1, 1, 0, zq, T, bs, cur, nullptr, nullptr, nullptr, T, bs, len0, B, T, ACT_NONE));
   P.back().cp.out_scale = c.pre_num_down > 0 ? 3.0f : 1.0f;   // first SamplingBlock(ratio 1): 3x
   int ada_idx = 0;
-  auto lnorm = [&](const std::string& name, const std::string& pfx, bool ada_norm, const float* dww, const float* dwb,
-                   const float* X, float* Y, int triple) {
-    Launch L; L.kind = 1; L.name = name; L.flops = (dww ? 14.0 : 0.0) * D * T * B + 8.0 * D * T * B;
-    LnP& p = L.lp; memset(&p, 0, sizeof(p));
-    p.X = X; p.Y = Y; p.dww = dww; p.dwb = dwb; p.lens = len0; p.C = D; p.stride = T; p.bs = bs; p.triple = triple;
-    p.eps = 1e-6f;
-    if (ada_norm) { p.ada = ada + (size_t)ada_idx * 2 * D; p.ada_stride = ada_stride; ++ada_idx; }
-    else { p.w = ent(h, pfx + ".weight"); p.bsh = ent(h, pfx + ".bias"); }
-    L.cpt = (D + 31) / 32; L.grid = dim3((T + 7) / 8, B);
-    P.push_back(L);
+  const WSrc ws = wsrc(h);
+  auto lnorm = [&](const std::string& name, const std::string& pfx, bool ada_norm, const float* X, float* Y, int triple) {
+    const float* ap = ada_norm ? ada + (size_t)(ada_idx++) * 2 * D : nullptr;
+    add_lnorm(P, ws, name, pfx, ap, ada_stride, nullptr, nullptr, X, Y, triple, D, T, bs, len0, B);
   };
   // embed conv7 -> norm -> nl x ConvNeXt -> final LN (vocos.py:324-335); consumes cur, leaves result in cur
   auto vocos = [&](const std::string& p, int nl, bool ada_norm, int triple_out) {
@@ -367,18 +510,13 @@ int smi_voc_forward(smi_voc* h, const int64_t* sem_dev, const int32_t* lens_host
     P.push_back(make_conv(h, p + ".embed", p + ".embed.weight", (p + ".embed.bias").c_str(), D, D, 7, 1, 1, 3, cur, T, bs, n,
                           nullptr, nullptr, nullptr, T, bs, len0, B, T, ACT_NONE));
     float* x = other({n});            // residual stream (cur is dead once embed has run)
-    lnorm(p + ".norm", p + ".norm", ada_norm, nullptr, nullptr, n, x, 0);
+    lnorm(p + ".norm", p + ".norm", ada_norm, n, x, 0);
     float* m = other({x, n});         // MLP hidden
     for (int j = 0; j < nl; ++j) {
-      const std::string b = p + ".convnext." + std::to_string(j);
-      lnorm(b + ".dwconv+norm", b + ".norm", ada_norm, ent(h, b + ".dwconv.weight"), ent(h, b + ".dwconv.bias"), x, n, 0);
-      P.push_back(make_conv(h, b + ".pwconv1", b + ".pwconv1.weight", (b + ".pwconv1.bias").c_str(), I, D, 1, 1, 1, 0, n, T, bs, m,
-                            nullptr, nullptr, nullptr, T, bs, len0, B, T, ACT_GELU));
-      P.push_back(make_conv(h, b + ".pwconv2", b + ".pwconv2.weight", (b + ".pwconv2.bias").c_str(), D, I, 1, 1, 1, 0, m, T, bs, x,
-                            nullptr, nullptr, x, T, bs, len0, B, T, ACT_NONE));
-      P.back().cp.gamma = ent(h, b + ".gamma");
+      const float* ap = ada_norm ? ada + (size_t)(ada_idx++) * 2 * D : nullptr;
+      add_convnext(P, ws, p + ".convnext." + std::to_string(j), D, I, x, n, m, ap, ada_stride, T, bs, len0, B);
     }
-    lnorm(p + ".final_layer_norm", p + ".final_layer_norm", false, nullptr, nullptr, x, n, triple_out);
+    lnorm(p + ".final_layer_norm", p + ".final_layer_norm", false, x, n, triple_out);
     cur = n;
   };
   for (int i = 0; i < c.pre_num_down; ++i)
@@ -407,25 +545,12 @@ int smi_voc_forward(smi_voc* h, const int64_t* sem_dev, const int32_t* lens_host
     float* U = other({s_in});
     float* US = other({s_in, U});
     float* A = other({s_in, U, US});
-    // Snake (already applied by the producer) -> ConvTranspose1d: writes U (raw) and US = snake(U, unit0.alpha0)
-    P.push_back(make_conv(h, b + ".convT", b + ".1.weight", (b + ".1.bias").c_str(), cout, cin, k, 1, s, (k - s) / 2, s_in, Lcur, bs,
-                          U, US, ent(h, b + ".2.block.0.alpha"), nullptr, Lout, bs, lens_at(i), B, Lcur, ACT_NONE));
-    for (int r = 0; r < 3; ++r) {
-      const std::string u = b + "." + std::to_string(r + 2) + ".block";
-      const int dil = r == 0 ? 1 : (r == 1 ? 3 : 9);
-      // conv7(dilated) on snake(U); epilogue applies the unit's second Snake
-      P.push_back(make_conv(h, u + ".conv7", u + ".1.weight", (u + ".1.bias").c_str(), cout, cout, 7, dil, 1, 3 * dil, US, Lout, bs,
-                            nullptr, A, ent(h, u + ".2.alpha"), nullptr, Lout, bs, lens_at(i + 1), B, Lout, ACT_NONE));
-      // 1x1 + residual; second output = the NEXT consumer's Snake of the new U
-      std::string next_alpha;
-      if (r < 2) next_alpha = b + "." + std::to_string(r + 3) + ".block.0.alpha";
-      else if (i + 1 < c.dec_nblocks) next_alpha = "decoder.model." + std::to_string(i + 2) + ".block.0.alpha";
-      else next_alpha = "decoder.model." + std::to_string(c.dec_nblocks + 1) + ".alpha";
-      const bool last = r == 2;
-      float* rawout = last ? (h->debug ? h->dbg[3 + i] : nullptr) : U;
-      P.push_back(make_conv(h, u + ".conv1+res", u + ".3.weight", (u + ".3.bias").c_str(), cout, cout, 1, 1, 1, 0, A, Lout, bs,
-                            rawout, US, ent(h, next_alpha), U, Lout, bs, lens_at(i + 1), B, Lout, ACT_NONE));
-    }
+    // Snake (already applied by the producer) -> ConvTranspose1d -> three ResidualUnits; the last unit's second output is the
+    // NEXT consumer's Snake of the block's result (the next block's, or the output conv's)
+    const std::string next_alpha = i + 1 < c.dec_nblocks ? "decoder.model." + std::to_string(i + 2) + ".block.0.alpha"
+                                                         : "decoder.model." + std::to_string(c.dec_nblocks + 1) + ".alpha";
+    add_dec_block(P, ws, b, cin, cout, k, s, s_in, Lcur, bs, U, US, A, h->debug ? h->dbg[3 + i] : nullptr, ent(h, next_alpha), bs,
+                  lens_at(i), lens_at(i + 1), B);
     s_in = US;
     Lcur = Lout;
   }
@@ -449,15 +574,10 @@ int smi_voc_forward(smi_voc* h, const int64_t* sem_dev, const int32_t* lens_host
     Z.grid = dim3((Lcur + 255) / 256, B);
     P.push_back(Z);
   }
-  for (const Launch& L : P) {
-    if (L.kind == 0) {
-      SMI_REQUIRE(L.cp.W, "smi_voc_forward: arena entry for %s not found", L.name.c_str());
-      SMI_REQUIRE(L.lds <= 64 * 1024, "smi_voc_forward: %s needs %zu bytes of LDS", L.name.c_str(), L.lds);
-      SMI_REQUIRE(L.cp.xw <= 128 && (L.chg != 4 || L.cp.xw <= 64), "smi_voc_forward: %s stages %d columns", L.name.c_str(), L.cp.xw);
-    }
-    int rc = run_launch(L, st);
-    if (rc) return rc;
-  }
+  int rc = check_launches(P, "smi_voc_forward");
+  if (rc) return rc;
+  for (const Launch& L : P)
+    if ((rc = run_launch(L, st))) return rc;
   h->lastB = B; h->lastT = T;
   return SMI_OK;
 }
@@ -503,6 +623,89 @@ int smi_voc_time_launch(smi_voc* h, int index, int iters, float* ms_avg, double*
   if (flops) *flops = L.flops;
   if (name && name_cap > 0) { strncpy(name, L.name.c_str(), (size_t)name_cap - 1); name[name_cap - 1] = 0; }
   return SMI_OK;
+}
+
+// ---- one block of the vocoder on caller tensors (op-level tests; include/sparkmi.h)
+int smi_voc_block_arena_count(const smi_voc_block_cfg* cfg) { return block_cfg_ok(cfg) ? (int)block_layout(cfg).e.size() : 0; }
+size_t smi_voc_block_arena_bytes(const smi_voc_block_cfg* cfg) { return block_cfg_ok(cfg) ? block_layout(cfg).total : 0; }
+int smi_voc_block_arena_entry(const smi_voc_block_cfg* cfg, int index, char* name, int name_cap, size_t* offset, size_t* bytes, int32_t* info) {
+  SMI_REQUIRE(block_cfg_ok(cfg), "smi_voc_block_arena_entry: config outside the kernel contract");
+  return layout_entry(block_layout(cfg), index, name, name_cap, offset, bytes, info, "smi_voc_block_arena_entry");
+}
+
+int smi_voc_block_run(const smi_voc_block_cfg* cfg, const void* arena_dev, size_t arena_bytes, const float* x_dev, const float* xs_dev,
+                      const float* cond_dev, const int32_t* lens_host, int B, int L, float* y_dev, void* stream) {
+  SMI_REQUIRE(block_cfg_ok(cfg), "smi_voc_block_run: config outside the kernel contract");
+  const smi_voc_block_cfg& c = *cfg;
+  VocLayout lay = block_layout(cfg);
+  SMI_REQUIRE(arena_dev && arena_bytes >= lay.total, "smi_voc_block_run: arena too small (%zu < %zu)", arena_bytes, lay.total);
+  SMI_REQUIRE(((uintptr_t)arena_dev & 255) == 0, "smi_voc_block_run: arena must be 256-byte aligned");
+  SMI_REQUIRE(y_dev && B >= 1 && B <= 64 && L >= 1 && L <= (1 << 20), "smi_voc_block_run: bad B / L / output");
+  SMI_REQUIRE(c.kind == SMI_VOC_BLOCK_DECBLOCK ? xs_dev != nullptr : x_dev != nullptr, "smi_voc_block_run: input tensor is null");
+  SMI_REQUIRE(c.kind != SMI_VOC_BLOCK_RESUNIT || xs_dev, "smi_voc_block_run: a ResidualUnit needs x and snake(x)");
+  SMI_REQUIRE(c.kind != SMI_VOC_BLOCK_CONVNEXT || c.cond_dim == 0 || cond_dev, "smi_voc_block_run: AdaLayerNorm needs the condition vector");
+  hipStream_t st = (hipStream_t)stream;
+  const WSrc w{&lay.e, (const unsigned char*)arena_dev};
+  const int Lout = c.kind == SMI_VOC_BLOCK_DECBLOCK ? L * c.S : L;
+  const int Cin = c.C, Cres = c.kind == SMI_VOC_BLOCK_DECBLOCK ? c.Cout : c.C;
+  const int Cmax = std::max(std::max(Cin, Cres), c.kind == SMI_VOC_BLOCK_CONVNEXT ? c.I : 1);
+  const long long bs = (long long)smi_align_up((size_t)Cmax * Lout, 64);   // one batch stride for every working buffer, as in the vocoder
+  // working buffers: [0] input / x, [1] snake(input) / n, [2] U or m, [3] US, [4] A ; ints: lens_in, lens_out, ones ; ada
+  float* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* ada = nullptr;
+  int* lens = nullptr;
+  auto cleanup = [&]() {
+    for (float* f : buf) if (f) (void)hipFree(f);
+    if (ada) (void)hipFree(ada);
+    if (lens) (void)hipFree(lens);
+  };
+  bool ok = true;
+  for (int i = 0; i < 5 && ok; ++i) ok = hipMalloc((void**)&buf[i], (size_t)bs * B * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&ada, (size_t)B * 2 * c.C * 4 + 256) == hipSuccess;
+  ok = ok && hipMalloc((void**)&lens, (size_t)3 * 64 * 4) == hipSuccess;
+  if (!ok) { cleanup(); smi_set_error("smi_voc_block_run: device allocation failed"); return SMI_ENOMEM; }
+  std::vector<int32_t> hl((size_t)3 * 64, 0);
+  for (int b = 0; b < B; ++b) {
+    const int n = lens_host ? lens_host[b] : L;
+    if (n < 1 || n > L) { cleanup(); smi_set_error("smi_voc_block_run: lens[%d]=%d outside 1..%d", b, n, L); return SMI_EINVAL; }
+    hl[b] = n; hl[64 + b] = n * (Lout / L); hl[128 + b] = 1;
+  }
+  int rc = SMI_OK;
+  auto fail = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == SMI_OK) { smi_set_error("smi_voc_block_run: %s: %s", what, hipGetErrorString(e)); rc = SMI_EHIP; } };
+  fail(hipMemcpyAsync(lens, hl.data(), hl.size() * 4, hipMemcpyHostToDevice, st), "lens upload");
+  for (int i = 0; i < 5; ++i) fail(hipMemsetAsync(buf[i], 0, (size_t)bs * B * 4, st), "memset");
+  auto copy_in = [&](float* dst, const float* src, int C, int len) {   // contiguous [B][C][len] -> working layout
+    fail(hipMemcpy2DAsync(dst, (size_t)bs * 4, src, (size_t)C * len * 4, (size_t)C * len * 4, (size_t)B, hipMemcpyDeviceToDevice, st), "copy in");
+  };
+  std::vector<Launch> P;
+  const int* lens_in = lens; const int* lens_out = lens + 64; const int* len1 = lens + 128;
+  float* result = nullptr;
+  if (c.kind == SMI_VOC_BLOCK_RESUNIT) {
+    copy_in(buf[0], x_dev, c.C, L);
+    copy_in(buf[1], xs_dev, c.C, L);
+    add_res_unit(P, w, "L.block", c.C, c.dil, buf[0], buf[1], buf[4], buf[2], nullptr, nullptr, L, bs, lens_in, B);
+    result = buf[2];
+  } else if (c.kind == SMI_VOC_BLOCK_DECBLOCK) {
+    copy_in(buf[1], xs_dev, c.C, L);
+    add_dec_block(P, w, "L.block", c.C, c.Cout, c.K, c.S, buf[1], L, bs, buf[2], buf[3], buf[4], buf[0], nullptr, bs, lens_in, lens_out, B);
+    result = buf[0];
+  } else {
+    copy_in(buf[0], x_dev, c.C, L);
+    if (c.cond_dim > 0) {   // all scale / shift projections of the condition in one GEMV (vocos.py:105-108), as smi_voc_forward does
+      P.push_back(make_conv(w, "adaln_params", "cat:L.norm.scale.weight|L.norm.shift.weight", "cat:L.norm.scale.bias|L.norm.shift.bias",
+                            2 * c.C, c.cond_dim, 1, 1, 1, 0, cond_dev, 1, c.cond_dim, ada, nullptr, nullptr, nullptr, 1, 2 * c.C, len1, B, 1, ACT_NONE));
+      P.back().gemv = true; P.back().grid = dim3((2 * c.C + 31) / 32, B);
+    }
+    add_convnext(P, w, "L", c.C, c.I, buf[0], buf[1], buf[2], c.cond_dim > 0 ? ada : nullptr, 2 * c.C, L, bs, lens_in, B);
+    result = buf[0];
+  }
+  if (rc == SMI_OK) rc = check_launches(P, "smi_voc_block_run");
+  for (size_t i = 0; i < P.size() && rc == SMI_OK; ++i) rc = run_launch(P[i], st);
+  if (rc == SMI_OK)
+    fail(hipMemcpy2DAsync(y_dev, (size_t)Cres * Lout * 4, result, (size_t)bs * 4, (size_t)Cres * Lout * 4, (size_t)B, hipMemcpyDeviceToDevice, st), "copy out");
+  fail(hipStreamSynchronize(st), "synchronize");
+  cleanup();
+  return rc;
 }
 
 }  // extern "C"

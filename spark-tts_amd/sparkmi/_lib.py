@@ -40,6 +40,11 @@ class VocCfg(C.Structure):
         + [("max_batch", C.c_int32), ("max_frames", C.c_int32), ("exact_fp32", C.c_int32)])
 
 
+class VocBlockCfg(C.Structure):
+    """smi_voc_block_cfg: one reference block (ResidualUnit 0 / DecoderBlock 1 / ConvNeXtBlock 2) for the op-level entry points"""
+    _fields_ = [(n, C.c_int32) for n in ("kind", "C", "Cout", "K", "S", "dil", "I", "cond_dim", "exact_fp32")]
+
+
 class EncCfg(C.Structure):
     _fields_ = ([("w2v_conv_dim", C.c_int32), ("w2v_nconv", C.c_int32), ("w2v_kernel", C.c_int32 * 8), ("w2v_stride", C.c_int32 * 8)]
                 + [(n, C.c_int32) for n in ("w2v_hidden", "w2v_layers", "w2v_heads", "w2v_inter", "w2v_pos_k", "w2v_pos_groups")]
@@ -98,6 +103,10 @@ SYMBOLS = {
     "smi_voc_debug_stage": (_I, [_VP, _I, _VP, _SZ, _P(_SZ), _VP]),
     "smi_voc_num_launches": (_I, [_VP]),
     "smi_voc_time_launch": (_I, [_VP, _I, _I, _P(C.c_float), _P(C.c_double), C.c_char_p, _I, _VP]),
+    "smi_voc_block_arena_count": (_I, [_P(VocBlockCfg)]),
+    "smi_voc_block_arena_bytes": (_SZ, [_P(VocBlockCfg)]),
+    "smi_voc_block_arena_entry": (_I, [_P(VocBlockCfg), _I, C.c_char_p, _I, _P(_SZ), _P(_SZ), _P(C.c_int32)]),
+    "smi_voc_block_run": (_I, [_P(VocBlockCfg), _VP, _SZ, _VP, _VP, _VP, _P(C.c_int32), _I, _I, _VP, _VP]),
     "smi_enc_arena_count": (_I, [_P(EncCfg)]),
     "smi_enc_arena_entry": (_I, [_P(EncCfg), _I, C.c_char_p, _I, _P(_SZ), _P(_SZ), _P(C.c_int32)]),
     "smi_enc_arena_bytes": (_SZ, [_P(EncCfg)]),

@@ -103,19 +103,18 @@ def pack_conv_b(w: np.ndarray, kind: int, S: int, pad: int) -> np.ndarray:
     return np.concatenate(out).view(np.float32)
 
 
-def pack_voc_arena(cfg: BiCodecConfig, folded: Mapping[str, np.ndarray], cs: _lib.VocCfg) -> np.ndarray:
-    lib = _lib.lib()
-    n = lib.smi_voc_arena_count(C.byref(cs))
-    total = lib.smi_voc_arena_bytes(C.byref(cs))
+def _pack_entries(count_fn, bytes_fn, entry_fn, cs, folded: Mapping[str, np.ndarray], what: str) -> np.ndarray:
+    """Pack the tensors a layout enumerates (the vocoder's, or one block's) into a flat f32 arena."""
+    n = count_fn(C.byref(cs))
+    total = bytes_fn(C.byref(cs))
     if n <= 0 or total == 0:
-        raise _lib.SparkMIError("smi_voc_arena_count: config outside the kernel contract")
+        raise _lib.SparkMIError(f"{what}: config outside the kernel contract")
     arena = np.zeros(total // 4, dtype=np.float32)
     name = C.create_string_buffer(8192)
     for i in range(n):
         off, nb = C.c_size_t(), C.c_size_t()
         info = (C.c_int32 * 6)()
-        _lib.check(lib.smi_voc_arena_entry(C.byref(cs), i, name, 8192, C.byref(off), C.byref(nb), info),
-                   "smi_voc_arena_entry")
+        _lib.check(entry_fn(C.byref(cs), i, name, 8192, C.byref(off), C.byref(nb), info), what)
         key = name.value.decode()
         if key.startswith("cat:"):
             t = np.concatenate([np.asarray(folded[k], np.float32) for k in key[4:].split("|")], axis=0)
@@ -128,6 +127,47 @@ def pack_voc_arena(cfg: BiCodecConfig, folded: Mapping[str, np.ndarray], cs: _li
             raise ValueError(f"{key}: packed {data.size * 4} bytes, library expects {nb.value}")
         arena[off.value // 4: off.value // 4 + data.size] = data
     return arena
+
+
+def pack_voc_arena(cfg: BiCodecConfig, folded: Mapping[str, np.ndarray], cs: _lib.VocCfg) -> np.ndarray:
+    lib = _lib.lib()
+    return _pack_entries(lib.smi_voc_arena_count, lib.smi_voc_arena_bytes, lib.smi_voc_arena_entry, cs, folded, "smi_voc_arena_entry")
+
+
+BLOCK_RESUNIT, BLOCK_DECBLOCK, BLOCK_CONVNEXT = 0, 1, 2
+
+
+@torch.no_grad()
+def run_block(kind: int, params: Mapping[str, np.ndarray], x: Optional[torch.Tensor], xs: Optional[torch.Tensor] = None,
+              cond: Optional[torch.Tensor] = None, lens: Optional[Sequence[int]] = None, *, dil: int = 1, K: int = 0, S: int = 1,
+              exact_fp32: bool = False) -> torch.Tensor:
+    """ONE block of the vocoder on the HIP kernels (``smi_voc_block_run``), built by the functions ``smi_voc_forward`` builds its
+    launches with -- the op-level seam for the reference's own layer classes: ResidualUnit (``blocks/layers.py:51-67``),
+    DecoderBlock (``encoder_decoder/wave_generator.py:29-53``), ConvNeXtBlock (``blocks/vocos.py:26-110``).
+    ``params``: the layer's state_dict (after remove_weight_norm) with keys prefixed "L."; ``x`` (B, C, L) on the GPU; ``xs`` =
+    snake(x, block.0.alpha), which the vocoder leaves to the PRODUCER's epilogue (needed by RESUNIT and DECBLOCK)."""
+    lib = _lib.lib()
+    _lib.require_gfx950()
+    t = x if x is not None else xs
+    B, Cin, L = t.shape
+    cs = _lib.VocBlockCfg(kind=kind, C=Cin, exact_fp32=int(exact_fp32), dil=dil, K=K, S=S)
+    if kind == BLOCK_DECBLOCK:
+        cs.Cout = int(np.asarray(params["L.block.1.weight"]).shape[1])
+    if kind == BLOCK_CONVNEXT:
+        cs.I = int(np.asarray(params["L.pwconv1.weight"]).shape[0])
+        cs.cond_dim = 0 if cond is None else int(cond.shape[-1])
+    flat = {k: np.asarray(v, np.float32) for k, v in params.items()}
+    arena = torch.from_numpy(_pack_entries(lib.smi_voc_block_arena_count, lib.smi_voc_block_arena_bytes, lib.smi_voc_block_arena_entry,
+                                           cs, flat, "smi_voc_block_arena_entry")).to(t.device)
+    Cout = cs.Cout if kind == BLOCK_DECBLOCK else Cin
+    y = torch.empty(B, Cout, L * (S if kind == BLOCK_DECBLOCK else 1), dtype=torch.float32, device=t.device)
+    ptr = lambda a: C.c_void_p(a.contiguous().data_ptr()) if a is not None else None
+    keep = [a.contiguous().float() if a is not None else None for a in (x, xs, cond)]
+    hl = (C.c_int32 * B)(*[int(v) for v in lens]) if lens is not None else None
+    _lib.check(lib.smi_voc_block_run(C.byref(cs), C.c_void_p(arena.data_ptr()), arena.numel() * 4, ptr(keep[0]), ptr(keep[1]), ptr(keep[2]),
+                                     hl, B, L, C.c_void_p(y.data_ptr()), C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)),
+               "smi_voc_block_run")
+    return y
 
 
 class BiCodecVocoder:

@@ -49,6 +49,15 @@ for i in range(nent):
     assert l.smi_voc_arena_entry(C.byref(vs), i, name, 8192, C.byref(off), C.byref(n), info) == 0
 assert l.smi_voc_arena_entry(C.byref(vs), nent + 5, name, 8192, C.byref(off), C.byref(n), info) != 0   # past the table
 l.smi_voc_arena_entry(C.byref(vs), 0, name, 2, C.byref(off), C.byref(n), info)                        # tiny name buffer: any verdict, no overrun
+for kind, kw in ((0, dict(C=24, dil=3)), (1, dict(C=32, Cout=16, K=11, S=5)), (2, dict(C=48, I=112, cond_dim=20)), (2, dict(C=48, I=112)),
+                 (1, dict(C=32, Cout=16, K=9, S=4))):                                                  # the last one is outside the contract
+    bc = _lib.VocBlockCfg(kind=kind, **kw)
+    nb_ = l.smi_voc_block_arena_count(C.byref(bc))
+    assert (nb_ > 0) == (kw.get("K") != 9) and (l.smi_voc_block_arena_bytes(C.byref(bc)) > 0) == (nb_ > 0)
+    for i in range(nb_ + 1):
+        rc = l.smi_voc_block_arena_entry(C.byref(bc), i, name, 8192, C.byref(off), C.byref(n), info)
+        assert (rc == 0) == (i < nb_)
+    assert l.smi_voc_block_run(C.byref(bc), C.c_void_p(256), 0, None, None, None, None, 1, 8, None, None) != 0   # validation only
 print("asan child ok")
 '''
 
@@ -64,7 +73,7 @@ def test_host_code_is_clean_under_address_sanitizer():
     if rt is None:
         pytest.skip("clang's ASAN runtime is not in this image")
     # make decides whether the instrumented library is stale (sources or headers newer than it)
-    r = subprocess.run(["make", "-C", CSRC, "asan"], capture_output=True, text=True, timeout=1400)
+    r = subprocess.run(["make", "-j4", "-C", CSRC, "asan"], capture_output=True, text=True, timeout=1400)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     env = dict(os.environ, LD_PRELOAD=rt, SPARKMI_LIB=LIB, SMI_ROOT=ROOT,
                ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23:protect_shadow_gap=0")
