@@ -170,7 +170,9 @@ int smi_llm_kv_pages(smi_llm* h, int32_t* total, int32_t* free_pages);
 int smi_llm_time_kernel(smi_llm* h, int kernel, int layer, int iters, float* ms_avg, void* stream);
 /* Diagnostics: one launch of a decode-step GEMM kernel (ids as above, GEMM kernels only) with in-kernel
  * s_memrealtime phase stamps; out[0..7) = mean over blocks of (stamp i - earliest stamp 0) in microseconds,
- * out[7] = shader clock in MHz (tools/stamps.py).  Needs a started generation. */
+ * out[7] = shader clock in MHz (tools/stamps.py).  kernel + 32: the layer's earlier kernels (and the previous layer's down_proj)
+ * run first, un-stamped, so the stamped kernel finds the cache state it finds inside a decode step (tools/prefetch_stamps.py).
+ * Needs a started generation. */
 int smi_llm_debug_stamps(smi_llm* h, int kernel, int layer, double* out);
 /* One-row decode engine (csrc/smi_eng.h).  With ONE live sequence in slot 0 (bf16 KV, contiguous cache, contexts up to
  * 1024 tokens) the layers of a decode step run as one persistent launch -- one workgroup per CU, weights streamed through

@@ -647,6 +647,90 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// One-row RESID GEMV with four row parts per weight tile (down_proj at batch 1), FULL load instructions.
+// k_gemm<.., H = 4> gives each of 16 waves one chain (k tiles kt mod 16) and, a part being 4 of a tile's 16 rows, loads with
+// 16 of its 64 lanes: 160 quarter-full load instructions per block.  Here a wave owns FOUR chains and advances them with one
+// MFMA: A row 4s + r = weight row r of the part in the k tile of chain 4 * wave + s, B column 3s + c = split c (hi, mid, lo)
+// of that tile's operand; the four 4 x 3 diagonal blocks of D are the four chains' accumulators (the other blocks mix tiles
+// and are never read).  One load instruction then carries 1 KiB (W_down is stored row-part-major: the part's 16 pieces of a
+// k tile are 256 contiguous bytes), 40 per block.  A chain's sum, (lo + mid) + hi, and the in-order sum over the 16 chains are
+// k_gemm's, so the result is the same bit for bit; measured on the stand-alone probe (tools/gemv_ab.py, csrc/diag/
+// diag_gemv.hip): 5.92 -> 3.98 us per launch.  TPC = k tiles per chain the registers hold (KT <= 16 * TPC).
+// ------------------------------------------------------------------------------------------
+template <int TPC>
+__global__ __launch_bounds__(256) void k_down1(GemmP p) {
+  __shared__ float red[16 * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= p.work_blocks) {
+    pf_run(p.pf, (int)blockIdx.x - p.work_blocks, (int)gridDim.x - p.work_blocks, tid, 256);
+    return;
+  }
+  const int KT = p.KT, NT = p.NT;
+  const int nt = (int)blockIdx.x % NT, part = (int)blockIdx.x / NT;   // part r of tile t is block r * NT + t (same XCD for all r)
+  const uint4* wt = p.W + (size_t)nt * KT * 64;
+  const int row = lane & 15, k8 = lane >> 4;
+  const int sa = row >> 2, r = row & 3;                                   // A: chain slot and weight row of this lane's row
+  const int sb = row < 12 ? row / 3 : 0, c = row < 12 ? row % 3 : 0;      // B: chain slot and split term of this lane's column
+  const int piece = p.wperm ? part * 16 + k8 * 4 + r : k8 * 16 + part * 4 + r;
+  // the epilogue's operands (one lane per block owns the part's 4 output columns) are requested first: they are L2 hits
+  // and must not queue behind the cold weight tiles
+  const int n = nt * 16 + part * 4;
+  float4 epre = make_float4(0.f, 0.f, 0.f, 0.f), egam = epre;
+  if (tid == 0) {
+    epre = *(const float4*)((p.Yin ? p.Yin : p.Y) + n);
+    egam = *(const float4*)(p.gamma_next + n);
+  }
+  uint4 w[TPC];
+  bf16x8 b[TPC];
+#pragma unroll
+  for (int u = 0; u < TPC; ++u) {
+    int t = 4 * wave + sa + 16 * u;
+    const bool ok = t < KT;
+    t = ok ? t : KT - 1;
+    w[u] = smi_ldw(wt + (size_t)t * 64 + piece);
+    if (!ok) w[u] = make_uint4(0u, 0u, 0u, 0u);   // a chain's missing last tile adds zeros
+  }
+#pragma unroll
+  for (int u = 0; u < TPC; ++u) {
+    int t = 4 * wave + sb + 16 * u;
+    t = t < KT ? t : KT - 1;
+    b[u] = *(const bf16x8*)(p.XS + xs_off(t, c, k8, 0, 1));
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < TPC; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[u]), b[u], acc, 0, 0, 0);
+  // D: lane (col = lane & 15, g = lane >> 4) holds rows 4g .. 4g + 3 of column col; chain slot s is row group s, columns 3s .. 3s + 2
+  float t4[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) t4[e] = (smi_dpp<0x102>(acc[e]) + smi_dpp<0x101>(acc[e])) + acc[e];   // (lo + mid) + hi
+  if (row == 3 * k8) *(float4*)(red + (4 * wave + k8) * 4) = make_float4(t4[0], t4[1], t4[2], t4[3]);
+  __syncthreads();
+  if (tid == 0) {
+    float4 sres = *(const float4*)red;
+#pragma unroll
+    for (int ch = 1; ch < 16; ++ch) {   // the 16 chains in order, as k_gemm sums its 16 waves
+      const float4 q = *(const float4*)(red + ch * 4);
+      sres.x += q.x; sres.y += q.y; sres.z += q.z; sres.w += q.w;
+    }
+    // RESID epilogue of k_gemm for row 0, columns n .. n + 3
+    float4 h = epre;
+    h.x += sres.x; h.y += sres.y; h.z += sres.z; h.w += sres.w;
+    *(float4*)(p.Y + n) = h;
+    const float ssq = (h.x * h.x + h.y * h.y) + (h.z * h.z + h.w * h.w);
+    const float tv[4] = {egam.x * h.x, egam.y * h.y, egam.z * h.z, egam.w * h.w};
+    uint32_t hi[4], mi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split3(tv[e], hi[e], mi[e], lo[e]);
+    const size_t o = xs_off(n >> 5, 0, (n >> 3) & 3, 0, 1) + ((n >> 2) & 1) * 8;
+    const size_t pl = (size_t)4 * 16;
+    *(uint2*)(p.XSout + o) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+    *(uint2*)(p.XSout + o + pl) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
+    *(uint2*)(p.XSout + o + 2 * pl) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+    p.ssout[(size_t)nt * 4 + part] = ssq;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Prefill GEMM: many rows (a whole batch of prompts) against one weight matrix, no split-K.
 // Block = 4 waves = 8 weight tiles (128 output columns) x 128 rows; each wave owns 2 weight tiles
 // (A operands straight from HBM, used for all 8 m-tiles) and the block shares the rows' operand
@@ -2397,7 +2481,7 @@ struct smi_llm {
   unsigned long long* stamps; int stamps_on;
   int max_steps;
   int tune[4];   // SPARKMI_TUNE block-shape selectors (diagnostics)
-  int prefetch;  // same-XCD L2 prefetch by helper blocks (SPARKMI_NO_PREFETCH=1 turns it off)
+  int prefetch_mask, prefetch_rows;  // same-XCD L2 prefetch by helper blocks: one bit per producer kernel, up to this many live rows (smi_llm_create)
   int tune2;     // SPARKMI_TUNE2 bit mask (diagnostics)
   int pgemm_min_rows;   // prompt rows from which the prefill GEMM replaces row-grouped decode GEMMs (SPARKMI_PGEMM_MIN_ROWS)
   int pg_min[4];        // ... per kernel (QKV, o_proj, gate_up, down; SPARKMI_PGEMM_MIN_QKV / _O / _GU / _D override the common value)
@@ -2464,8 +2548,19 @@ int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
   const int work = (p.NT + NTB - 1) / NTB * H;
   p.work_blocks = work;
   p.stamps = L->stamps_on ? L->stamps : nullptr;
+  if constexpr (MT == 1 && NTB == 1 && NW == 16 && H == 4 && PRO == PRO_PLAIN && EPI == EPI_RESID) {
+    // one row: four chains per wave, full load instructions (k_down1; same bits).  SPARKMI_TUNE2 bit 1048576 keeps k_gemm (A/B)
+    if (p.M == 1 && !p.stamps && p.KT <= 160 && !(L->tune2 & 1048576)) {
+      const int helpers = (L->prefetch_mask & 4) && p.pf.base && work < 232 ? (256 - work) / 8 * 8 : 0;
+      if (p.KT <= 32) hipLaunchKernelGGL(k_down1<2>, dim3(work + helpers), dim3(256), 0, st, p);
+      else if (p.KT <= 96) hipLaunchKernelGGL(k_down1<6>, dim3(work + helpers), dim3(256), 0, st, p);
+      else hipLaunchKernelGGL(k_down1<10>, dim3(work + helpers), dim3(256), 0, st, p);
+      SMI_LAUNCH_CHECK();
+      return SMI_OK;
+    }
+  }
   // idle CUs warm the L2 of their own XCD for a later kernel (decode with few rows only)
-  const int helpers = (L->prefetch && p.pf.base && p.M <= 8 && work < 232) ? (256 - work) / 8 * 8 : 0;
+  const int helpers = ((L->prefetch_mask & (EPI == EPI_QKV ? 1 : 4)) && p.pf.base && p.M <= L->prefetch_rows && work < 232) ? (256 - work) / 8 * 8 : 0;
   size_t lds = (size_t)NW * NTB * MT * 1024 + 32 * 4 + NTB * 32 * 8;
   p.ldsb = 0; p.lt_shift = 0;
   if (MT == 1 && p.M <= 5) {
@@ -2729,7 +2824,7 @@ int launch_attn(smi_llm* L, AttnP a, int helpers_ok, hipStream_t st) {
     if (rc) return rc;
     a.part = L->apart;
   }
-  const int helpers = (helpers_ok && L->prefetch && a.M <= 8 && a.work_blocks < 232) ? (256 - a.work_blocks) / 8 * 8 : 0;
+  const int helpers = (helpers_ok && (L->prefetch_mask & 2) && a.M <= L->prefetch_rows && a.work_blocks < 232) ? (256 - a.work_blocks) / 8 * 8 : 0;
   if (fuse)
     hipLaunchKernelGGL((k_attn<KVF32, 1, 1>), dim3(a.work_blocks + helpers), dim3(2 * kAttnWaves * 64), 0, st, a);
   else if (a.M == 1 && a.nseg == 1 && a.slot_is_row)
@@ -3098,7 +3193,14 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->do_sample = 0; L->top_k = 50; L->temperature = 0.8f; L->top_p = 0.95f; L->seed = 0; L->logits = nullptr; L->tok = nullptr; L->cand_v = nullptr; L->cand_i = nullptr; L->cand_n = nullptr; L->stamps = nullptr; L->stamps_on = 0;
   { L->tune[0] = L->tune[1] = L->tune[2] = L->tune[3] = 0; const char* e = getenv("SPARKMI_TUNE"); if (e) sscanf(e, "%d,%d,%d,%d", &L->tune[0], &L->tune[1], &L->tune[2], &L->tune[3]); }
   L->bh = L->bq = nullptr; L->bxs_h = L->bxs_attn = L->bxs_act = nullptr; L->bss = nullptr; L->big_rows = 0;
-  L->prefetch = getenv("SPARKMI_NO_PREFETCH") ? 0 : 1;
+  // helper-block prefetch per producer: bit 0 QKV (gate_up's first half), bit 1 attention (second half), bit 2 down_proj (the next
+  // layer's QKV / o_proj); SPARKMI_PREFETCH=<mask> picks, SPARKMI_NO_PREFETCH=1 is mask 0
+  // Default since k_down1 (round 3): QKV's helpers at ONE row only.  Measured on one box, alternating processes, graph step at one
+  // row: mask 0 566-571 us, 1 563-564, 2 581, 3 583, 4 597, 5 602, 6 658, 7 665 (down_proj's 256-thread blocks make slow helpers);
+  // at 4 rows mask 0 727 us, 3 748, 7 739-745 (profiles/r03_prefetch.txt).  SPARKMI_PREFETCH=<mask> applies up to 8 rows as before.
+  L->prefetch_mask = 1; L->prefetch_rows = 1;
+  if (const char* e = getenv("SPARKMI_PREFETCH")) { L->prefetch_mask = atoi(e) & 7; L->prefetch_rows = 8; }
+  if (getenv("SPARKMI_NO_PREFETCH")) L->prefetch_mask = 0;
   L->part_o = nullptr; L->h2 = nullptr;
   L->fuse_o = !getenv("SPARKMI_NO_FUSE_O") && (cfg->num_heads == 14 || cfg->num_heads == 4) && cfg->num_heads <= kMaxOHeads &&
               L->NTh % kFuseQB == 0 && L->NTh / kFuseQB <= kAttnWaves * kFuseOT && L->KTh * 8 <= 256;
@@ -3739,12 +3841,22 @@ int smi_llm_forward_logits(smi_llm* L, const int64_t* ids, int S, float* logits_
 // (10 ns ticks); out[0..7) = mean over blocks of (stamp i - earliest stamp 0), out[7] = blocks.
 int smi_llm_debug_stamps(smi_llm* L, int kernel, int layer, double* out) {
   SMI_REQUIRE(L && out && L->started, "smi_llm_debug_stamps: needs a started generation");
+  // kernel + 32: the layer's earlier kernels run first (un-stamped, with their helper blocks), so the stamped kernel finds in
+  // the caches what it finds inside a decode step -- the in-kernel evidence for (or against) the helpers' prefetch
+  const bool with_producers = (kernel & 32) != 0;
+  kernel &= 31;
   SMI_REQUIRE(kernel == KQKV || kernel == KO || kernel == KGU || kernel == KD || kernel == KLM, "smi_llm_debug_stamps: GEMM kernels only");
   SMI_REQUIRE(!(kernel == KLM && L->B <= 16 && L->KTh <= 32), "smi_llm_debug_stamps: the persistent lm_head has no stamps");
   SMI_HIP(hipMemset(L->stamps, 0, (size_t)4096 * 64));
-  L->stamps_on = 1;
   graphs_flush(L);   // (the stamped kernels are other instantiations)
-  int rc = launch_one(L, kernel, layer, L->rows, L->B, nullptr, 0);
+  int rc = SMI_OK;
+  if (with_producers) {
+    if (layer > 0) rc = launch_one(L, KD, layer - 1, L->rows, L->B, nullptr, 0);   // (its helpers warm this layer's QKV / o_proj slices)
+    for (int k = KQKV; k < kernel && rc == SMI_OK; ++k) rc = launch_one(L, k, layer, L->rows, L->B, nullptr, 0);
+    if (rc) return rc;
+  }
+  L->stamps_on = 1;
+  rc = launch_one(L, kernel, layer, L->rows, L->B, nullptr, 0);
   L->stamps_on = 0;
   if (rc) return rc;
   SMI_HIP(hipDeviceSynchronize());
