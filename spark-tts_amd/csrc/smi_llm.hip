@@ -696,6 +696,7 @@ __global__ __launch_bounds__(256) void k_down1(GemmP p) {
     t = t < KT ? t : KT - 1;
     b[u] = *(const bf16x8*)(p.XS + xs_off(t, c, k8, 0, 1));
   }
+  __builtin_amdgcn_sched_barrier(0);   // every load of the wave is requested before the first MFMA's wait
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int u = 0; u < TPC; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[u]), b[u], acc, 0, 0, 0);
@@ -727,6 +728,99 @@ __global__ __launch_bounds__(256) void k_down1(GemmP p) {
     *(uint2*)(p.XSout + o + pl) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
     *(uint2*)(p.XSout + o + 2 * pl) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
     p.ssout[(size_t)nt * 4 + part] = ssq;
+  }
+}
+
+// The same for 2 .. 8 rows (k_downS<TPC, MG>, rows in MG groups of four): a wave's load instruction still carries four chains'
+// parts; B column 4s + j = row 4g + j of the tile of chain slot s, one MFMA per split term and row group (3 * MG per step
+// instead of 12 with quarter-full loads), accumulators and summation order as k_gemm's -- (lo + mid) + hi per chain, chains in
+// order -- so a row's result stays bit-identical whatever the batch.  All operands of a wave are in flight at once (one wave
+// per SIMD: up to 512 registers).
+template <int TPC, int MG>
+__global__ __launch_bounds__(256) void k_downS(GemmP p) {
+  __shared__ __attribute__((aligned(16))) float red[16 * 4 * MG * 4];   // [chain][row][4 columns]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int KT = p.KT, NT = p.NT, M = p.M;
+  const int nt = (int)blockIdx.x % NT, part = (int)blockIdx.x / NT;
+  const uint4* wt = p.W + (size_t)nt * KT * 64;
+  const int row = lane & 15, k8 = lane >> 4;
+  const int sa = row >> 2, r = row & 3;      // A: chain slot and weight row of this lane's row; B: chain slot and row inside its group of four
+  const int piece = p.wperm ? part * 16 + k8 * 4 + r : k8 * 16 + part * 4 + r;
+  const int n = nt * 16 + part * 4;
+  float4 epre = make_float4(0.f, 0.f, 0.f, 0.f), egam = epre;
+  if (tid < M) {
+    epre = *(const float4*)((p.Yin ? p.Yin : p.Y) + (size_t)tid * (NT * 16) + n);
+    egam = *(const float4*)(p.gamma_next + n);
+  }
+  uint4 w[TPC];
+  bf16x8 b[TPC][3][MG];
+#pragma unroll
+  for (int u = 0; u < TPC; ++u) {
+    int t = 4 * wave + sa + 16 * u;
+    const bool ok = t < KT;
+    t = ok ? t : KT - 1;
+    w[u] = smi_ldw(wt + (size_t)t * 64 + piece);
+    if (!ok) w[u] = make_uint4(0u, 0u, 0u, 0u);
+  }
+#pragma unroll
+  for (int u = 0; u < TPC; ++u) {
+    int t = 4 * wave + sa + 16 * u;
+    t = t < KT ? t : KT - 1;
+#pragma unroll
+    for (int g = 0; g < MG; ++g) {
+      int m = 4 * g + r;
+      m = m < M ? m : M - 1;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) b[u][c][g] = *(const bf16x8*)(p.XS + xs_off(t, c, k8, m, M));
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);   // every load of the wave is requested before the first MFMA's wait
+  f32x4 acc[3][MG];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int g = 0; g < MG; ++g) acc[c][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < TPC; ++u) {
+    const bf16x8 a = __builtin_bit_cast(bf16x8, w[u]);
+#pragma unroll
+    for (int g = 0; g < MG; ++g) {
+      acc[2][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[u][2][g], acc[2][g], 0, 0, 0);
+      acc[1][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[u][1][g], acc[1][g], 0, 0, 0);
+      acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[u][0][g], acc[0][g], 0, 0, 0);
+    }
+  }
+  // D: lane (col, rg = lane >> 4) holds weight rows 0..3 of chain slot rg for column col; the slot's own columns are 4 rg .. 4 rg + 3
+  if (sa == k8) {
+#pragma unroll
+    for (int g = 0; g < MG; ++g) {
+      const f32x4 t = (acc[2][g] + acc[1][g]) + acc[0][g];   // (lo + mid) + hi
+      *(float4*)(red + ((4 * wave + k8) * 4 * MG + 4 * g + r) * 4) = make_float4(t[0], t[1], t[2], t[3]);
+    }
+  }
+  __syncthreads();
+  if (tid < M) {
+    const int m = tid;
+    float4 sres = *(const float4*)(red + m * 4);
+#pragma unroll
+    for (int ch = 1; ch < 16; ++ch) {   // the 16 chains in order
+      const float4 q = *(const float4*)(red + (ch * 4 * MG + m) * 4);
+      sres.x += q.x; sres.y += q.y; sres.z += q.z; sres.w += q.w;
+    }
+    float4 h = epre;   // RESID epilogue of k_gemm for row m, columns n .. n + 3
+    h.x += sres.x; h.y += sres.y; h.z += sres.z; h.w += sres.w;
+    *(float4*)(p.Y + (size_t)m * (NT * 16) + n) = h;
+    const float ssq = (h.x * h.x + h.y * h.y) + (h.z * h.z + h.w * h.w);
+    const float tv[4] = {egam.x * h.x, egam.y * h.y, egam.z * h.z, egam.w * h.w};
+    uint32_t hi[4], mi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split3(tv[e], hi[e], mi[e], lo[e]);
+    const size_t o = xs_off(n >> 5, 0, (n >> 3) & 3, m, M) + ((n >> 2) & 1) * 8;
+    const size_t pl = (size_t)4 * M * 16;
+    *(uint2*)(p.XSout + o) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+    *(uint2*)(p.XSout + o + pl) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
+    *(uint2*)(p.XSout + o + 2 * pl) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+    p.ssout[((size_t)m * NT + nt) * 4 + part] = ssq;
   }
 }
 
@@ -2555,6 +2649,20 @@ int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
       if (p.KT <= 32) hipLaunchKernelGGL(k_down1<2>, dim3(work + helpers), dim3(256), 0, st, p);
       else if (p.KT <= 96) hipLaunchKernelGGL(k_down1<6>, dim3(work + helpers), dim3(256), 0, st, p);
       else hipLaunchKernelGGL(k_down1<10>, dim3(work + helpers), dim3(256), 0, st, p);
+      SMI_LAUNCH_CHECK();
+      return SMI_OK;
+    }
+    if (p.M >= 2 && p.M <= 8 && !p.stamps && p.KT <= 160 && !(L->tune2 & 2097152)) {   // SPARKMI_TUNE2 bit 2097152 keeps k_gemm (A/B)
+      const dim3 g(work), b(256);
+      if (p.M <= 4) {
+        if (p.KT <= 32) hipLaunchKernelGGL((k_downS<2, 1>), g, b, 0, st, p);
+        else if (p.KT <= 96) hipLaunchKernelGGL((k_downS<6, 1>), g, b, 0, st, p);
+        else hipLaunchKernelGGL((k_downS<10, 1>), g, b, 0, st, p);
+      } else {
+        if (p.KT <= 32) hipLaunchKernelGGL((k_downS<2, 2>), g, b, 0, st, p);
+        else if (p.KT <= 96) hipLaunchKernelGGL((k_downS<6, 2>), g, b, 0, st, p);
+        else hipLaunchKernelGGL((k_downS<10, 2>), g, b, 0, st, p);
+      }
       SMI_LAUNCH_CHECK();
       return SMI_OK;
     }

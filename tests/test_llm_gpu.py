@@ -202,6 +202,41 @@ def test_full_size_batch_is_bit_identical_to_single_runs(full_llm):
     assert int(chunked.argmax()) == step_tok
 
 
+@pytest.mark.parametrize("size", ["tiny", "full"])
+def test_few_row_down_proj_kernels_keep_the_bits_of_the_general_kernel(tiny, full_llm, monkeypatch, size):
+    """k_down1 / k_downS (1 .. 8 rows: four chains per wave, full load instructions) against k_gemm's row-part form
+    (SPARKMI_TUNE2 bits 1048576 | 2097152 keep it): teacher-forced logits of 1 .. 8 rows are equal BIT FOR BIT, and so are
+    the greedy tokens of ragged batches of 2 .. 8 sequences."""
+    from conftest import FULL_MAX_POS
+    from sparkmi.llm import SparkLLM
+    if size == "tiny":
+        cfg, syn = tiny
+        mk = lambda slots: _llm(cfg, syn, max_slots=slots, max_positions=96, kv_dtype="bf16")
+    else:
+        cfg, syn, arena = full_llm
+        mk = lambda slots: SparkLLM(cfg, None, "cuda:0", max_slots=slots, max_positions=FULL_MAX_POS, arena=arena)
+    rng = np.random.Generator(np.random.PCG64(77))
+    seqs = {S: rng.integers(0, cfg.vocab_size, size=S) for S in range(1, 9)}
+    prompts = [rng.integers(0, cfg.vocab_size, size=int(rng.integers(3, 30))).tolist() for _ in range(8)]
+    out = {}
+    for mode in ("new", "old"):
+        if mode == "old":
+            monkeypatch.setenv("SPARKMI_TUNE2", str(1048576 | 2097152))
+        else:
+            monkeypatch.delenv("SPARKMI_TUNE2", raising=False)
+        one = mk(1)
+        logits = {S: one.forward_logits(ids).clone() for S, ids in seqs.items()}
+        toks = {B: mk(B).generate_ids(prompts[:B], 10) for B in (2, 3, 4, 5, 8)}
+        toks[1] = [one.generate_ids([q], 10)[0] for q in prompts[:3]]
+        out[mode] = (logits, toks)
+    for S in seqs:
+        assert torch.equal(out["new"][0][S], out["old"][0][S]), f"{S} rows: logits differ from the general kernel's"
+    assert out["new"][1] == out["old"][1]
+    for B in (2, 3, 4, 5, 8):      # and a row does not depend on its batch
+        k = min(B, 3)
+        assert out["new"][1][B][:k] == out["new"][1][1][:k], f"batch of {B}"
+
+
 def test_prefill_paths_agree(tiny, monkeypatch):
     """More than 32 prompt rows run as row-grouped decode GEMMs (one launch per layer kernel) or through the prefill GEMM
     (k_pgemm), chosen per kernel by row count (SPARKMI_PGEMM_MIN_ROWS / _QKV / _O / _GU / _D); every mix -- the RESID kernels
