@@ -191,7 +191,7 @@ __device__ __forceinline__ float smi_ss_lane_sum(const float* sp, int npart, int
   return v;
 }
 
-template <int MT, int NTB, int NW, int U, int WB, int PRO, int EPI, int KVF32, int H = 1, int OCC = 1, int LEAN = 0>
+template <int MT, int NTB, int NW, int U, int WB, int PRO, int EPI, int KVF32, int H = 1, int OCC = 1, int LEAN = 0, int NOH = kMaxOHeads>
 __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
   static_assert(H == 1 || ((H == 2 || H == 4) && NTB == 1 && EPI == EPI_RESID), "row-split tiles: RESID, one tile per block");
   static_assert(PRO != PRO_FUSEDO || (LEAN == 2 && MT == 1 && EPI == EPI_SWIGLU), "PRO_FUSEDO: the one-row gate_up kernel");
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
   // one k) are requested BEFORE the weight tiles: loads return in issue order, so behind the (cold) weights they would only
   // arrive after them and the whole operand build would sit between the weights' arrival and the first MFMA
   constexpr int FRND = PRO == PRO_FUSEDO ? 2 : 1;
-  float fpv[FRND][kMaxOHeads], fhv[FRND], fgv[FRND];
+  float fpv[FRND][NOH], fhv[FRND], fgv[FRND];   // NOH: the head count the instantiation is built for (PRO_FUSEDO: 14 or 4 -- no dead loads)
   int fkk[FRND];
   if constexpr (PRO == PRO_FUSEDO) {
     const int tw = (KT - wave + NW - 1) / NW, K = KT * 32;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
       const int tl = 2 * r + (lane >> 5);
       fkk[r] = (wave + (tl < tw ? tl : tw - 1) * NW) * 32 + (lane & 31);
 #pragma unroll
-      for (int hd = 0; hd < kMaxOHeads; ++hd) fpv[r][hd] = p.part_o[(size_t)(hd < p.n_oheads ? hd : p.n_oheads - 1) * K + fkk[r]];
+      for (int hd = 0; hd < NOH; ++hd) fpv[r][hd] = p.part_o[(size_t)(hd < p.n_oheads ? hd : p.n_oheads - 1) * K + fkk[r]];
       fhv[r] = p.hres[fkk[r]]; fgv[r] = p.gam[fkk[r]];
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -336,12 +336,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
     for (int r = 0; r < FRND; ++r) {
       const int tl = 2 * r + (lane >> 5), k = fkk[r];
       const bool ok = tl < tw;
-      float (&pv)[FRND][kMaxOHeads] = fpv;
+      float (&pv)[FRND][NOH] = fpv;
       float (&hv)[FRND] = fhv;
       float (&gv)[FRND] = fgv;
       float y = pv[r][0];
 #pragma unroll
-      for (int hd = 1; hd < kMaxOHeads; ++hd)
+      for (int hd = 1; hd < NOH; ++hd)
         if (hd < p.n_oheads) y += pv[r][hd];   // wave-uniform
       const float hm = hv[r] + y;
       uint32_t hi, mi, lo;
@@ -1569,7 +1569,10 @@ constexpr int kFuseOT = 2;       // W_o n tiles per wave (8 waves x 2 x 4 blocks
 // block's two barriers while waves 0..7 run the attention exactly as in the plain kernel, then multiply and store.  (Issued
 // by the attention waves themselves, the cold weight loads either hold q / K / V back -- loads return in issue order -- or,
 // issued behind them, are caught by the compiler's counted waits for K / V.)
-template <int KVF32, int ONE = 0, int FUSE = 0>
+// PG (with ONE != 0): the KV cache is paged -- a token's row comes through the slot's page-table row (one more dependent,
+// cache-resident load in front of the K/V loads; every table entry is a valid page at all times, so the unconditional first
+// chunk stays safe), everything else as the slot == row kernels.
+template <int KVF32, int ONE = 0, int FUSE = 0, int PG = 0>
 __global__ __launch_bounds__((FUSE ? 2 : 1) * kAttnWaves * 64) void k_attn(AttnP p) {
   static_assert(!FUSE || ONE == 1, "fused o_proj: one-row kernel only");
   constexpr int LPT = KVF32 ? 16 : 8;   // lanes per token row (each lane 16 bytes)
@@ -1669,7 +1672,7 @@ __global__ __launch_bounds__((FUSE ? 2 : 1) * kAttnWaves * 64) void k_attn(AttnP
     for (int u = 0; u < UNR; ++u) {
       const int t = c0 + u * NGRP + grp;
       const int tc = sir ? (t < p.max_pos ? t : p.max_pos - 1) : (t < ctx ? t : ctx - 1);
-      const size_t off = (ONE ? rowbase + tc : kv_row(p.km, slot, kvh, p.n_kv, p.max_pos, tc)) * kHeadDim + dl * DPL;
+      const size_t off = ((ONE && !PG) ? rowbase + tc : kv_row(p.km, slot, kvh, p.n_kv, p.max_pos, tc)) * kHeadDim + dl * DPL;
       if (KVF32) {
         kr[u] = *(const uint4*)((const float*)p.kcache + off);
         vr[u] = *(const uint4*)((const float*)p.vcache + off);
@@ -2703,6 +2706,11 @@ int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
   if (kLean && p.ldsb > 0 && !p.stamps && p.M == 1 && p.lt_shift == 4) {
     if constexpr (PRO == PRO_NORM && EPI == EPI_SWIGLU && H == 1 && MT == 1) {
       if (p.part_o) {   // one row behind the fused o_proj: the operand is built in the kernel from the per-head partials
+#ifndef SMI_NOH16   // (A/B build: make variant NAME=noh16 VARFLAGS=-DSMI_NOH16 keeps the 16-slot form)
+        if (p.n_oheads == 14) hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO_FUSEDO, EPI, 0, H, OCC, 2, 14>), dim3(work + helpers, groups), dim3(NW * 64), lds + 1024, st, p);
+        else if (p.n_oheads == 4) hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO_FUSEDO, EPI, 0, H, OCC, 2, 4>), dim3(work + helpers, groups), dim3(NW * 64), lds + 1024, st, p);
+        else
+#endif
         hipLaunchKernelGGL((k_gemm<MT, NTB, NW, U, WB, PRO_FUSEDO, EPI, 0, H, OCC, 2>), dim3(work + helpers, groups), dim3(NW * 64), lds + 1024, st, p);
         SMI_LAUNCH_CHECK();
         return SMI_OK;
@@ -2933,10 +2941,17 @@ int launch_attn(smi_llm* L, AttnP a, int helpers_ok, hipStream_t st) {
     a.part = L->apart;
   }
   const int helpers = (helpers_ok && (L->prefetch_mask & 2) && a.M <= L->prefetch_rows && a.work_blocks < 232) ? (256 - a.work_blocks) / 8 * 8 : 0;
-  if (fuse)
+  const bool pg = a.km.ptab != nullptr;   // paged cache: the slot == row kernels look the token's page up (PG)
+  if (fuse && pg)
+    hipLaunchKernelGGL((k_attn<KVF32, 1, 1, 1>), dim3(a.work_blocks + helpers), dim3(2 * kAttnWaves * 64), 0, st, a);
+  else if (fuse)
     hipLaunchKernelGGL((k_attn<KVF32, 1, 1>), dim3(a.work_blocks + helpers), dim3(2 * kAttnWaves * 64), 0, st, a);
+  else if (a.M == 1 && a.nseg == 1 && a.slot_is_row && pg)
+    hipLaunchKernelGGL((k_attn<KVF32, 1, 0, 1>), dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
   else if (a.M == 1 && a.nseg == 1 && a.slot_is_row)
     hipLaunchKernelGGL((k_attn<KVF32, 1>), dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
+  else if (a.nseg == 1 && a.slot_is_row && pg)
+    hipLaunchKernelGGL((k_attn<KVF32, 2, 0, 1>), dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
   else if (a.nseg == 1 && a.slot_is_row)
     hipLaunchKernelGGL((k_attn<KVF32, 2>), dim3(a.work_blocks + helpers), dim3(kAttnWaves * 64), 0, st, a);
   else
@@ -2953,7 +2968,7 @@ int launch_attn(smi_llm* L, AttnP a, int helpers_ok, hipStream_t st) {
 // (k_attn<.., FUSE>), gate_up builds its operand from those partials (PRO_FUSEDO) and down_proj adds its residual from h2;
 // the o_proj kernel is not launched.  The predicate is the one launch_attn picks the one-row kernel by.
 bool fuse_o_now(const smi_llm* L, const RowDesc* rows, int M) {
-  return L->fuse_o && !L->paged && M == 1 && rows == L->rows && L->identity_slots && L->attn_seg <= 1;
+  return L->fuse_o && M == 1 && rows == L->rows && L->identity_slots && L->attn_seg <= 1;
 }
 
 // o_proj: NW = number of heads, so that wave w sums head w's two (head-interleaved) k tiles -- the per-head partial the
@@ -2994,7 +3009,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       a.q = L->qbuf; a.kcache = kv_layer(L, L->kcache, layer); a.vcache = kv_layer(L, L->vcache, layer);
       a.rows = rows; a.xs_out = L->xs_attn; a.M = M; a.q_dim = L->Q; a.n_kv = c.num_kv_heads;
       a.group = c.num_heads / c.num_kv_heads; a.max_pos = c.max_positions; a.n_heads = c.num_heads; a.km = kv_map(L);
-      a.slot_is_row = rows == L->rows && L->identity_slots && !L->paged;   // the live decode rows are (slot b, ...) in order, slots contiguous
+      a.slot_is_row = rows == L->rows && L->identity_slots;   // the live decode rows are (slot b, ...) in order (contiguous cache: slots contiguous; paged: through the page table)
       // helpers: second half of this layer's gate_up slices
       a.pf = PfDesc{sec(L, SMI_LLM_WGU, layer), L->KTh * 1024, L->NTgu, (L->NTgu / 8 + 1) / 2, (L->NTgu + 7) / 8};
       if (fused) { a.Wo = (const uint4*)sec(L, SMI_LLM_WO, layer); a.NTo = L->NTh; a.part_o = L->part_o; }

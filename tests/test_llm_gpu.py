@@ -533,6 +533,14 @@ def test_paged_kv_cache_serves_more_sequences_than_it_could_reserve(tiny):
     assert tot == 24 and 0 < free < 24
     ids = np.asarray(prompts[3] + [1, 2, 3])
     assert torch.equal(llm.forward_logits(ids), _llm(cfg, syn, max_positions=256).forward_logits(ids))
+    # ONE sequence on a paged engine takes the one-row kernels (one-row attention through the page table, fused o_proj):
+    # tokens equal the contiguous engine's and the oracle's, across several page boundaries, graph and eager
+    for graph in (True, False):
+        one = _llm(cfg, syn, max_slots=2, max_positions=256, kv_page_tokens=16, kv_pages=20, use_graph=graph)
+        for p in (prompts[0], prompts[4]):
+            got1 = one.generate_ids([p], 70)[0]
+            assert got1 == single.generate_ids([p], 70)[0]
+        assert got1 == Qwen2Ref(cfg, syn, kv_dtype="bf16").generate_greedy(np.asarray(prompts[4]), 70)
     # a pool that cannot hold the request refuses it and changes nothing
     small = _llm(cfg, syn, max_slots=4, max_positions=256, kv_page_tokens=16, kv_pages=6)
     small.session_begin(None)
