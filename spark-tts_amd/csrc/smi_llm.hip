@@ -2578,6 +2578,7 @@ struct smi_llm {
   unsigned long long* stamps; int stamps_on;
   int max_steps;
   int tune[4];   // SPARKMI_TUNE block-shape selectors (diagnostics)
+  int pf_qkv_eighths;   // SPARKMI_PF_QKV: how much of gate_up QKV's helpers prefetch, in eighths (default 2)
   int prefetch_mask, prefetch_rows;  // same-XCD L2 prefetch by helper blocks: one bit per producer kernel, up to this many live rows (smi_llm_create)
   int tune2;     // SPARKMI_TUNE2 bit mask (diagnostics)
   int pgemm_min_rows;   // prompt rows from which the prefill GEMM replaces row-grouped decode GEMMs (SPARKMI_PGEMM_MIN_ROWS)
@@ -2648,7 +2649,7 @@ int launch_gemm_kv(const smi_llm* L, GemmP p, hipStream_t st) {
   if constexpr (MT == 1 && NTB == 1 && NW == 16 && H == 4 && PRO == PRO_PLAIN && EPI == EPI_RESID) {
     // one row: four chains per wave, full load instructions (k_down1; same bits).  SPARKMI_TUNE2 bit 1048576 keeps k_gemm (A/B)
     if (p.M == 1 && !p.stamps && p.KT <= 160 && !(L->tune2 & 1048576)) {
-      const int helpers = (L->prefetch_mask & 4) && p.pf.base && work < 232 ? (256 - work) / 8 * 8 : 0;
+      const int helpers = (L->prefetch_mask & 4) && p.pf.base && work < 232 ? ((L->tune2 & 4194304) ? 224 : (256 - work) / 8 * 8) : 0;   // bit 4194304: as many helper blocks as work blocks (they share the CUs)
       if (p.KT <= 32) hipLaunchKernelGGL(k_down1<2>, dim3(work + helpers), dim3(256), 0, st, p);
       else if (p.KT <= 96) hipLaunchKernelGGL(k_down1<6>, dim3(work + helpers), dim3(256), 0, st, p);
       else hipLaunchKernelGGL(k_down1<10>, dim3(work + helpers), dim3(256), 0, st, p);
@@ -2997,7 +2998,9 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       p.kcache = kv_layer(L, L->kcache, layer); p.vcache = kv_layer(L, L->vcache, layer);
       p.q_dim = L->Q; p.kv_dim = L->KV; p.n_kv = c.num_kv_heads; p.max_pos = c.max_positions; p.km = kv_map(L);
       // helpers: first half of this layer's gate_up slices (consumer block b reads weight tile row b)
-      p.pf = PfDesc{sec(L, SMI_LLM_WGU, layer), L->KTh * 1024, L->NTgu, 0, (L->NTgu / 8 + 1) / 2};
+      // helpers: the first pf_qkv_eighths / 8 of this layer's gate_up slices (consumer block b reads weight tile row b).  Measured
+      // at one row, graph step, one box (profiles/r03_prefetch.txt): 8/8 600 us, 6/8 569, 4/8 564, 2/8 559 (default), none 566-571
+      p.pf = PfDesc{sec(L, SMI_LLM_WGU, layer), L->KTh * 1024, L->NTgu, 0, ((L->NTgu + 7) / 8 * L->pf_qkv_eighths + 7) / 8};
       switch (L->tune[0]) {   // SPARKMI_TUNE=q,o,g,d: block-shape sweeps (diagnostics; NW changes the summation order)
         case 1: return launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_QKV>(L, p, st);
         case 3: return launch_gemm<1, 4, 8, 1, PRO_NORM, EPI_QKV>(L, p, st);
@@ -3324,6 +3327,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->prefetch_mask = 1; L->prefetch_rows = 1;
   if (const char* e = getenv("SPARKMI_PREFETCH")) { L->prefetch_mask = atoi(e) & 7; L->prefetch_rows = 8; }
   if (getenv("SPARKMI_NO_PREFETCH")) L->prefetch_mask = 0;
+  { const char* e = getenv("SPARKMI_PF_QKV"); L->pf_qkv_eighths = e ? atoi(e) : 2; if (L->pf_qkv_eighths < 0 || L->pf_qkv_eighths > 8) L->pf_qkv_eighths = 2; }
   L->part_o = nullptr; L->h2 = nullptr;
   L->fuse_o = !getenv("SPARKMI_NO_FUSE_O") && (cfg->num_heads == 14 || cfg->num_heads == 4) && cfg->num_heads <= kMaxOHeads &&
               L->NTh % kFuseQB == 0 && L->NTh / kFuseQB <= kAttnWaves * kFuseOT && L->KTh * 8 <= 256;
