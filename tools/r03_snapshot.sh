@@ -8,4 +8,8 @@ bash tools/bench_prof.sh ${tag}
 bash tools/pmc_traffic.sh ${tag}_b1 1
 timeout -k 10 300 python bench.py --batch 32 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_bench_b32.json 2> gpurun_out/${tag}_bench_b32.err
 timeout -k 10 300 python bench.py --clone --batch 8 --steps 3 --warmup 1 --no-cpu-baseline --no-probes > gpurun_out/${tag}_bench_clone8.json 2> gpurun_out/${tag}_bench_clone8.err
-tail -c 400 gpurun_out/${tag}_bench_b1.json
+bash tools/pmc_traffic.sh ${tag}_b32 32
+export TMPDIR=/tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_b32 -o r -- python3 bench.py --batch 32 --steps 3 --warmup 1 --no-cpu-baseline --no-probes > gpurun_out/bench_under_rocprof_${tag}_b32.json 2> gpurun_out/prof_${tag}_b32.log
+find gpurun_out/prof_${tag}_b32 -name "*kernel_trace*" -delete
+tail -c 300 gpurun_out/${tag}_bench_b1.json
