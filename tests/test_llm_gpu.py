@@ -229,6 +229,14 @@ def test_few_row_down_proj_kernels_keep_the_bits_of_the_general_kernel(tiny, ful
         toks = {B: mk(B).generate_ids(prompts[:B], 10) for B in (2, 3, 4, 5, 8)}
         toks[1] = [one.generate_ids([q], 10)[0] for q in prompts[:3]]
         out[mode] = (logits, toks)
+    if size == "tiny":   # the plain W_down tile order (smi_llm_cfg.wd_plain: a packer-side A/B) through the same kernels: same bits again
+        monkeypatch.delenv("SPARKMI_TUNE2", raising=False)
+        monkeypatch.setenv("SPARKMI_WD_PLAIN", "1")
+        plain = mk(1)
+        assert plain._cs.wd_plain == 1
+        for S, ids in seqs.items():
+            assert torch.equal(plain.forward_logits(ids), out["new"][0][S]), f"{S} rows, plain W_down layout"
+        monkeypatch.delenv("SPARKMI_WD_PLAIN")
     for S in seqs:
         assert torch.equal(out["new"][0][S], out["old"][0][S]), f"{S} rows: logits differ from the general kernel's"
     assert out["new"][1] == out["old"][1]

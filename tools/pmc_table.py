@@ -57,6 +57,8 @@ if a.json:
             roles.setdefault("lm_head", ent)
         elif name.startswith("k_attn<"):
             roles.setdefault("attn", ent)
+        elif name.startswith("k_down1<") or name.startswith("k_downS<"):
+            roles.setdefault("down", ent)         # down_proj at 1 .. 8 rows (four chains per wave)
         elif name.startswith("k_gemm<"):
             args = [x.strip() for x in name[name.index("<") + 1: name.rindex(">")].split(",")]
             epi = int(args[6])
@@ -67,10 +69,14 @@ if a.json:
             elif epi == 0:
                 resid.append(ent)
     resid.sort(key=lambda e: -e["read_bytes"])
-    if resid:
-        roles["down"] = resid[0]
-    if len(resid) > 1:
-        roles["o_proj"] = resid[1]
+    if "down" in roles:                           # the residual GEMMs left are o_proj's (none at one row: fused into attention)
+        if resid:
+            roles["o_proj"] = resid[0]
+    else:
+        if resid:
+            roles["down"] = resid[0]
+        if len(resid) > 1:
+            roles["o_proj"] = resid[1]
     json.dump({"build": build_hash(), "batch": a.batch, "tokens": a.tokens,
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes with --kernel-trace only, eager launches; "
                          "read bytes = 2 x FETCH_SIZE KiB x 1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B), write bytes = WRITE_SIZE KiB x 1024; "
