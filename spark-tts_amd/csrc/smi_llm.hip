@@ -111,6 +111,7 @@ struct GemmP {
   const float* gam;      // [K] this RMSNorm's weight
   float* h2out;          // [K] block 0 leaves h + o_proj here (the residual down_proj adds to)
   const float* Yin;      // RESID: residual row source when it is not Y itself (null: Y)
+  const unsigned char* pf2_base; int pf2_slice, pf2_nslices;   // PRO_FUSEDO: a later kernel's weights the work blocks touch (null: none)
   int wperm;             // weight tiles stored row-part-major [q:4][k8:4][r:4][8] (W_down): lane (k8, n = 4q + r) owns piece q*16 + k8*4 + r
 };
 // piece index of `lane` inside a 1 KiB weight tile (see GemmP::wperm)
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
     pf_run(p.pf, (int)blockIdx.x - p.work_blocks, (int)gridDim.x - p.work_blocks, tid, NW * 64);
     return;
   }
+  const int bx = (int)blockIdx.x;
   const int KT = p.KT, M = LEAN == 2 ? 1 : p.M, NT = p.NT;   // LEAN == 2: exactly one row (batch-1 decode), folded at compile time
   const int mbase = LEAN == 2 ? 0 : (int)blockIdx.y * (MT * 16);   // row group (grid.y > 1: a prompt's rows, 32 per block row)
   const int nblk = p.work_blocks / H;   // blocks per row part; part r of tile t is block r * nblk + t (same XCD for all r)
@@ -280,6 +282,21 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
 #pragma unroll
   for (int b = 0; b < WB; ++b)
     if (wave + b * NW * U < KT) load_w(w[b], wave + b * NW * U);
+  // PRO_FUSEDO (gate_up at one row, 608 blocks): every block also touches its share -- one wave-instruction, a dword per 64-byte
+  // line -- of the NEXT layer's QKV weights, right behind its own weight loads: the 2 MB are then in the L2 of the XCD whose QKV
+  // blocks read them (consumer slice s is read by block s; 72 slices, 8 XCDs: block j takes slice j mod 72 -- same XCD) when
+  // QKV starts two launches later, instead of a cold HBM round trip in front of a 3-us kernel.  The value is only kept alive
+  // until the MFMA loop is over (the loads return in order behind the weights; nothing waits for them).
+  uint32_t pf2v = 0;
+  if constexpr (PRO == PRO_FUSEDO) {
+    if (p.pf2_base && wave == NW - 1) {
+      const int sl = bx % p.pf2_nslices, part = bx / p.pf2_nslices, nparts = (p.work_blocks + p.pf2_nslices - 1) / p.pf2_nslices;
+      const int lines = p.pf2_slice >> 6, per = (lines + nparts - 1) / nparts;
+      int ln = part * per + (lane < per ? lane : per - 1);
+      ln = ln < lines ? ln : lines - 1;
+      pf2v = *(const uint32_t*)(p.pf2_base + (size_t)sl * p.pf2_slice + (size_t)ln * 64);
+    }
+  }
   if constexpr (LEAN == 2 && EPI == EPI_QKV) {
     // one row: its descriptor sits at a uniform address, so it comes through the SCALAR cache -- not counted by vmcnt,
     // hence the RoPE load that needs the position no longer waits for the weight tiles issued above (the compiler's
@@ -485,6 +502,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
     if (!vlds) load_bf(j0);
     compute(w[0], j0);
   }
+  if constexpr (PRO == PRO_FUSEDO) asm volatile("" ::"v"(pf2v));
   SMI_STAMP(4);
   // ---- split-K reduction across the block's waves (fixed order => deterministic)
 #pragma unroll
@@ -2578,6 +2596,7 @@ struct smi_llm {
   unsigned long long* stamps; int stamps_on;
   int max_steps;
   int tune[4];   // SPARKMI_TUNE block-shape selectors (diagnostics)
+  int pf_inline;        // gate_up's work blocks touch the next layer's QKV weights (SPARKMI_PF_INLINE=0: off)
   int pf_qkv_eighths;   // SPARKMI_PF_QKV: how much of gate_up QKV's helpers prefetch, in eighths (default 2)
   int prefetch_mask, prefetch_rows;  // same-XCD L2 prefetch by helper blocks: one bit per producer kernel, up to this many live rows (smi_llm_create)
   int tune2;     // SPARKMI_TUNE2 bit mask (diagnostics)
@@ -3039,6 +3058,9 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       p.XS = L->xs_h; p.XSout = L->xs_act;
       if (fused) {
         p.part_o = L->part_o; p.n_oheads = c.num_heads; p.hres = L->h; p.h2out = L->h2;
+        if (L->pf_inline && layer + 1 < c.num_layers && L->NTqkv % 8 == 0) {   // SPARKMI_PF_INLINE=0: off (A/B)
+          p.pf2_base = sec(L, SMI_LLM_WQKV, layer + 1); p.pf2_slice = L->KTh * 1024; p.pf2_nslices = L->NTqkv;
+        }
         p.gam = (const float*)sec(L, SMI_LLM_LN2, layer);
       }
       switch (L->tune[2]) {
@@ -3327,6 +3349,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->prefetch_mask = 1; L->prefetch_rows = 1;
   if (const char* e = getenv("SPARKMI_PREFETCH")) { L->prefetch_mask = atoi(e) & 7; L->prefetch_rows = 8; }
   if (getenv("SPARKMI_NO_PREFETCH")) L->prefetch_mask = 0;
+  { const char* e = getenv("SPARKMI_PF_INLINE"); L->pf_inline = !(e && e[0] == '0'); }
   { const char* e = getenv("SPARKMI_PF_QKV"); L->pf_qkv_eighths = e ? atoi(e) : 2; if (L->pf_qkv_eighths < 0 || L->pf_qkv_eighths > 8) L->pf_qkv_eighths = 2; }
   L->part_o = nullptr; L->h2 = nullptr;
   L->fuse_o = !getenv("SPARKMI_NO_FUSE_O") && (cfg->num_heads == 14 || cfg->num_heads == 4) && cfg->num_heads <= kMaxOHeads &&
