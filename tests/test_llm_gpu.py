@@ -245,6 +245,27 @@ def test_few_row_down_proj_kernels_keep_the_bits_of_the_general_kernel(tiny, ful
         assert out["new"][1][B][:k] == out["new"][1][1][:k], f"batch of {B}"
 
 
+def test_prefetch_switches_change_speed_only(tiny, monkeypatch):
+    """The helper-block / inline L2 prefetches touch caches, never values: every setting gives the same
+    tokens and the same logits bits."""
+    cfg, syn = tiny
+    rng = np.random.Generator(np.random.PCG64(5150))
+    prompt = rng.integers(0, cfg.vocab_size, size=37).tolist()
+    ids = rng.integers(0, cfg.vocab_size, size=9)
+    ref = None
+    for env in ({}, {"SPARKMI_NO_PREFETCH": "1", "SPARKMI_PF_INLINE": "0"}, {"SPARKMI_PREFETCH": "7", "SPARKMI_PF_QKV": "8"},
+                {"SPARKMI_PREFETCH": "2"}):
+        for k in ("SPARKMI_NO_PREFETCH", "SPARKMI_PF_INLINE", "SPARKMI_PREFETCH", "SPARKMI_PF_QKV"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        llm = _llm(cfg, syn, max_positions=128)
+        got = (llm.generate_ids([prompt], 40)[0], llm.forward_logits(ids).clone())
+        if ref is None:
+            ref = got
+        assert got[0] == ref[0] and torch.equal(got[1], ref[1]), env
+
+
 def test_prefill_paths_agree(tiny, monkeypatch):
     """More than 32 prompt rows run as row-grouped decode GEMMs (one launch per layer kernel) or through the prefill GEMM
     (k_pgemm), chosen per kernel by row count (SPARKMI_PGEMM_MIN_ROWS / _QKV / _O / _GU / _D); every mix -- the RESID kernels
