@@ -158,6 +158,7 @@ __global__ __launch_bounds__(NW * 64) void ub_gemv(GemvArg a) {
 // tiles and are never read).  A chain's sum and the in-order sum over the 16 chains are the product's, bit for bit; what changes
 // is that one load instruction carries 1 KiB (four tiles' parts) instead of 256 B with 48 idle lanes.  NWV waves per block,
 // 16 / NWV ... (4 waves: four chains each).
+template <int TPC, bool WPERM>
 __global__ __launch_bounds__(256) void ub_gemv4(GemvArg a) {
   __shared__ float red[16 * 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -167,7 +168,6 @@ __global__ __launch_bounds__(256) void ub_gemv4(GemvArg a) {
   const int row = lane & 15, k8 = lane >> 4;
   const int sa = row >> 2, r = row & 3;               // A: chain slot and weight row of this lane's row
   const int col = row, sb = col < 12 ? col / 3 : 0, c = col < 12 ? col % 3 : 0;   // B: chain slot and split of this lane's column
-  constexpr int TPC = 10;                              // k tiles per chain (upper bound: 152 / 16)
   uint4 w[TPC];
   gbf16x8 b[TPC];
 #pragma unroll
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void ub_gemv4(GemvArg a) {
     int t = 4 * wave + sa + 16 * u;
     const bool ok = t < KT;
     t = ok ? t : KT - 1;
-    w[u] = ldw(wt + (size_t)t * 64 + part * 16 + k8 * 4 + r);
+    w[u] = ldw(wt + (size_t)t * 64 + (WPERM ? part * 16 + k8 * 4 + r : k8 * 16 + part * 4 + r));
     if (!ok) w[u] = make_uint4(0u, 0u, 0u, 0u);
   }
 #pragma unroll
@@ -214,7 +214,7 @@ void launch(int shape, const GemvArg& a, hipStream_t st) {
 // last launch's y (so that the caller can check variant 0 against variant 1 on its own inputs).
 extern "C" int smi_diag_gemv(int variant, int shape, const void* W, int copies, const void* XS, const float* X, float* Y, int iters,
                              float* us_per_launch, void* stream) {
-  if (variant < 0 || variant > 3 || (variant == 3 && shape != 0) || shape < 0 || shape > 1 || copies < 1 || iters < 1 || !W || !XS || !X || !Y || !us_per_launch) {
+  if (variant < 0 || variant > 3 || shape < 0 || shape > 1 || copies < 1 || iters < 1 || !W || !XS || !X || !Y || !us_per_launch) {
     smi_set_error("diag_gemv: bad argument");
     return SMI_EINVAL;
   }
@@ -229,7 +229,8 @@ extern "C" int smi_diag_gemv(int variant, int shape, const void* W, int copies, 
   auto go = [&](int i) {
     a.W = (const uint4*)W + (size_t)(i % copies) * per;
     if (variant == 0) launch<0>(shape, a, st); else if (variant == 1) launch<1>(shape, a, st); else if (variant == 2) launch<2>(shape, a, st);
-    else hipLaunchKernelGGL(ub_gemv4, dim3(a.NT * 4), dim3(256), 0, st, a);
+    else if (shape == 0) hipLaunchKernelGGL((ub_gemv4<10, true>), dim3(a.NT * 4), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((ub_gemv4<2, false>), dim3(a.NT * 4), dim3(256), 0, st, a);   // QKV: plain tile order, four 64-byte segments per part
   };
   for (int i = 0; i < copies; ++i) go(i);
   SMI_LAUNCH_CHECK();

@@ -39,7 +39,7 @@ for shape, (name, N, K, parts) in enumerate([("down_proj 896 x 4864", 896, 4864,
     print(f"--- {name}: {N * K * 2 / 1e6:.2f} MB of weights per launch, {COPIES} copies walked")
     for var, vname in enumerate(["MFMA, one per tile, hi/mid/lo columns (product arithmetic)", "VALU fp32 FMA on expanded bf16 weights (exact x)",
                                  "VALU v_dot2_f32_bf16, x rounded to bf16 (inexact bound)",
-                                 "MFMA, four chains per wave: full 1 KiB load instructions"][: 4 if shape == 0 else 3]):
+                                 "MFMA, four chains per wave: full 1 KiB load instructions"]):
         Y = torch.zeros(N, dtype=torch.float32, device="cuda")
         us = C.c_float(0)
         rc = f(var, shape, C.c_void_p(Wd.data_ptr()), COPIES, C.c_void_p(XS.data_ptr()), C.c_void_p(X.data_ptr()), C.c_void_p(Y.data_ptr()),
