@@ -472,6 +472,17 @@ def main():
             "frac": step_bytes / (dec_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
             "bytes_per_step": step_bytes, "ms_per_step": dec_step_ms,
             "note": "whole decode step of this workload (one hipGraph replay), events inside the timed region"}
+        # HBM traffic of a whole step from the PMC profile of THIS build at this batch, when there is one: layers x the layer
+        # kernels' read + write bytes per launch + lm_head's (the profile is taken at full, uniform rows: an upper bound for a
+        # ragged batch whose rows retire)
+        tr_step, tr_src = pmc_traffic(B)
+        if tr_step is not None:
+            tk = tr_step.get("kernels", {})
+            need = [k for k in ("qkv", "attn", "o_proj", "gate_up", "down") if k in tk]
+            if {"qkv", "attn", "gate_up", "down", "lm_head"} <= set(tk):
+                res["roofline_step"]["traffic"] = (llm_cfg.num_hidden_layers * sum(tk[k]["hbm_bytes_per_launch"] for k in need)
+                                                   + tk["lm_head"]["hbm_bytes_per_launch"])
+                res["roofline_step"]["traffic_source"] = tr_src
         if not a.no_probes:
             llm.prefill(prompts, None)
             llm.decode(Nmax // 2)
