@@ -2596,6 +2596,7 @@ struct smi_llm {
   unsigned long long* stamps; int stamps_on;
   int max_steps;
   int tune[4];   // SPARKMI_TUNE block-shape selectors (diagnostics)
+  int graph_steps;      // decode steps captured per graph replay (SPARKMI_GRAPH_STEPS, default 8; 1: one)
   int pf_inline;        // gate_up's work blocks touch the next layer's QKV weights (SPARKMI_PF_INLINE=0: off)
   int pf_qkv_eighths;   // SPARKMI_PF_QKV: how much of gate_up QKV's helpers prefetch, in eighths (default 2)
   int prefetch_mask, prefetch_rows;  // same-XCD L2 prefetch by helper blocks: one bit per producer kernel, up to this many live rows (smi_llm_create)
@@ -3349,6 +3350,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->prefetch_mask = 1; L->prefetch_rows = 1;
   if (const char* e = getenv("SPARKMI_PREFETCH")) { L->prefetch_mask = atoi(e) & 7; L->prefetch_rows = 8; }
   if (getenv("SPARKMI_NO_PREFETCH")) L->prefetch_mask = 0;
+  { const char* e = getenv("SPARKMI_GRAPH_STEPS"); L->graph_steps = e ? atoi(e) : 8; if (L->graph_steps < 1 || L->graph_steps > 32) L->graph_steps = 8; }
   { const char* e = getenv("SPARKMI_PF_INLINE"); L->pf_inline = !(e && e[0] == '0'); }
   { const char* e = getenv("SPARKMI_PF_QKV"); L->pf_qkv_eighths = e ? atoi(e) : 2; if (L->pf_qkv_eighths < 0 || L->pf_qkv_eighths > 8) L->pf_qkv_eighths = 2; }
   L->part_o = nullptr; L->h2 = nullptr;
@@ -3886,7 +3888,42 @@ int smi_llm_decode(smi_llm* L, int n_steps, void* stream) {
     if (!L->graph) { smi_set_error("hipGraph capture of the decode step failed"); return SMI_EHIP; }
     L->graph_cache[key] = L->graph;
   }
-  for (int s = 0; s < n_steps; ++s) {
+  // Several steps per replay (SPARKMI_GRAPH_STEPS = K, default 8; 1: off): a step needs nothing from the host, so K of them are
+  // captured back to back into one graph; the call replays it n_steps / K times and the one-step graph for the rest.  One replay
+  // boundary costs ~5 us that a kernel boundary inside a graph does not: graph step at one row 548.6 -> 544.5 us (K = 4 .. 25
+  // alike; profiles/r03_graph_steps.txt).  The K-step graph of a (rows, segments) key is only built by a call long enough to
+  // replay it twice (a capture of 8 x 98 nodes is not free; short serving strides keep to the one-step graph).
+  int s0 = 0;
+  if (L->cfg.use_graph && L->graph_steps > 1 && n_steps >= L->graph_steps) {
+    const int K = L->graph_steps;
+    const uint32_t keyk = (uint32_t)L->B | ((uint32_t)L->attn_seg << 8) | ((uint32_t)(L->identity_slots ? 1 : 0) << 24) | ((uint32_t)K << 26);
+    hipGraphExec_t gk = nullptr;
+    auto hit = L->graph_cache.find(keyk);
+    if (hit != L->graph_cache.end()) gk = hit->second;
+    else if (n_steps >= 2 * K && L->graph_cache.size() < 192) {
+      hipStream_t cs;
+      SMI_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+      hipGraph_t g = nullptr;
+      hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+      if (e == hipSuccess) {
+        rc = SMI_OK;
+        for (int k = 0; k < K && rc == SMI_OK; ++k) rc = launch_step(L, L->B, cs);
+        hipError_t e2 = hipStreamEndCapture(cs, &g);
+        if (rc == SMI_OK && e2 == hipSuccess && g && hipGraphInstantiate(&gk, g, nullptr, nullptr, 0) != hipSuccess) gk = nullptr;
+        if (g) (void)hipGraphDestroy(g);
+      }
+      (void)hipStreamDestroy(cs);
+      (void)hipGetLastError();
+      if (gk) L->graph_cache[keyk] = gk;
+    }
+    if (gk) {
+      for (; s0 + K <= n_steps; s0 += K) {
+        SMI_HIP(hipGraphLaunch(gk, st));
+        L->graph_stream = st; L->graph_launched = 1;
+      }
+    }
+  }
+  for (int s = s0; s < n_steps; ++s) {
     if (L->cfg.use_graph) {
       SMI_HIP(hipGraphLaunch(L->graph, st));
       L->graph_stream = st; L->graph_launched = 1;
