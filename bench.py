@@ -37,6 +37,7 @@ PyTorch-CPU arithmetic) on this box's host cores: the whole configs[1] utterance
 from __future__ import annotations
 
 import argparse
+import ctypes
 import glob
 import hashlib
 import json
@@ -224,18 +225,19 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")        # BEFORE the communicator exists (device_id= creates it eagerly): RCCL warnings reach stderr
         if one_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if a.gpus > 1 and not one_gpu and torch.cuda.device_count() < a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but this process sees {torch.cuda.device_count()} GPU(s): refusing to time fewer devices than asked for")
-    os.environ.setdefault("NCCL_DEBUG", "WARN")            # RCCL warnings reach stderr (and the driver's log)
     pre = SD.preflight(torch.device("cpu") if one_gpu else dev, rank, world, a.gpus)   # raises on every rank if anything is off
     if rank == 0 and world > 1:
         log(f"preflight: {pre}")
     arch = _lib.require_gfx950()
-    torch.set_num_threads(host_cores())
+    # host threads: the ranks of one node share its cores (rank 0 packs the arenas; the CPU baseline only runs at world == 1)
+    torch.set_num_threads(max(1, host_cores() // max(1, world)))
     if rank == 0:
         log(f"device {arch}, world {world}, host cores {host_cores()}: building synthetic weights")
 
@@ -279,19 +281,27 @@ def main():
     llm_arena, voc_arena, bcast_ms = SD.broadcast_arenas(
         llm_arena, voc_arena, SD.arena_sizes(cs_llm, cs_voc), dev, rank, world)
 
-    if a.engine:
+    if a.engine:   # the experimental one-row engine lives in the diagnostics build (include/sparkmi_debug.h)
         os.environ["SPARKMI_ENGINE"] = "1"
     llm = SparkLLM(llm_cfg, None, dev, max_slots=B, max_positions=max_pos, kv_dtype=a.kv,
-                   use_graph=not a.no_graph, arena=llm_arena)
+                   use_graph=not a.no_graph, arena=llm_arena, diag=bool(a.engine))
     voc = BiCodecVocoder(voc_cfg, None, dev, max_batch=B, max_frames=max_frames, arena=voc_arena)
     enc = None
     if a.clone:
         if rank == 0:
             log("building the prompt encoder (wav2vec2-large-xlsr-53 shape, 16 layers + BiCodec tokenizer side)")
-        # every rank builds its own copy of the 1 GB encoder arena from the same seeds (no second broadcast path)
-        enc = BiCodecEncoder(wcfg, tcfg, W.fold_pos_conv_weight_norm(W.wav2vec2_state(wcfg)),
-                             W.fold_weight_norm(W.bicodec_tok_state(tcfg, voc_cfg.vq_input_dim)), dev,
-                             max_seconds=a.prompt_seconds, ref_seconds=6.0)
+        # rank 0 packs the 1 GB encoder arena, the others receive it like the other two (one more broadcast at start-up)
+        from sparkmi.encoder import enc_cfg_struct, pack_enc_arena
+        max_s, max_r = int(a.prompt_seconds * tcfg.sample_rate), int(6.0 * tcfg.sample_rate) + tcfg.n_fft
+        cs_enc = enc_cfg_struct(wcfg, tcfg, max_s, max_r, None)
+        enc_arena = None
+        if rank == 0:
+            enc_arena = torch.from_numpy(pack_enc_arena(tcfg, W.fold_pos_conv_weight_norm(W.wav2vec2_state(wcfg)),
+                                                        W.fold_weight_norm(W.bicodec_tok_state(tcfg, voc_cfg.vq_input_dim)), cs_enc)).to(dev)
+        n_enc = int(_lib.lib().smi_enc_arena_bytes(ctypes.byref(cs_enc))) // 4
+        (enc_arena,), enc_bcast_ms = SD.broadcast_tensors([enc_arena], [(n_enc, torch.float32)], dev, rank, world)
+        bcast_ms += enc_bcast_ms
+        enc = BiCodecEncoder(wcfg, tcfg, None, None, dev, max_seconds=a.prompt_seconds, ref_seconds=6.0, arena=enc_arena)
         tt = np.arange(int(16000 * a.prompt_seconds)) / 16000.0
         pwavs, prefs = [], []
         for i in range(B):
@@ -484,35 +494,40 @@ def main():
                                                    + tk["lm_head"]["hbm_bytes_per_launch"])
                 res["roofline_step"]["traffic_source"] = tr_src
         if not a.no_probes:
-            llm.prefill(prompts, None)
-            llm.decode(Nmax // 2)
-            kb = llm.weight_bytes()
+            # per-kernel probes, stamps and the sampling-step timing are diagnostics (include/sparkmi_debug.h): they run on a
+            # second engine on libsparkmi_diag.so -- the same sources and kernels, same arena -- never on the product library
+            # that the timed region above ran on
+            pl = llm if llm._lib.is_diag else SparkLLM(llm_cfg, None, dev, max_slots=B, max_positions=max_pos, kv_dtype=a.kv,
+                                                      use_graph=not a.no_graph, arena=llm_arena, diag=True)
+            pl.prefill(prompts, None)
+            pl.decode(Nmax // 2)
+            kb = pl.weight_bytes()
             ctx_now = sum(len(p) + Nmax // 2 for p in prompts)
             per = {"qkv": kb["qkv"] + kvb // llm_cfg.num_hidden_layers * B,
                    "attn": kvb // llm_cfg.num_hidden_layers * ctx_now,
                    "o_proj": kb["o_proj"], "gate_up": kb["gate_up"], "down": kb["down"], "lm_head": kb["lm_head"]}
             count = {k: llm_cfg.num_hidden_layers for k in per}
             count["lm_head"] = 1
-            eng = llm.engine_info() if B == 1 else {"enabled": False}
+            eng = pl.engine_info() if B == 1 else {"enabled": False}
             ks = []
             if eng["enabled"]:
                 # one live row: all layers of a step are ONE persistent launch (csrc/smi_eng.h); the launch-path layer kernels
                 # below are what batches run -- probed for comparison, not part of this workload's step
-                llm.prefill(prompts, None)
-                llm.decode(Nmax // 2)
-                ms = llm.time_kernel("layers", iters=48)
+                pl.prefill(prompts, None)
+                pl.decode(Nmax // 2)
+                ms = pl.time_kernel("layers", iters=48)
                 eb = llm_cfg.num_hidden_layers * (kb["qkv"] + kb["o_proj"] + kb["gate_up"] + kb["down"]) + kvb * (ctx_now + B)
                 ks.append({"kernel": "engine", "what": f"all {llm_cfg.num_hidden_layers} layers of the step, one persistent launch",
                            "launches_per_step": 1, "in_step": True, "avg_us": ms * 1e3, "bytes": eb,
                            "GBps": eb / (ms * 1e-3) / 1e9, "us_per_step": ms * 1e3,
                            "us_per_layer": ms * 1e3 / llm_cfg.num_hidden_layers})
-                llm.prefill(prompts, None)
-                llm.decode(Nmax // 2)
+                pl.prefill(prompts, None)
+                pl.decode(Nmax // 2)
             for name in ("qkv", "attn", "o_proj", "gate_up", "down", "lm_head"):
                 # layer kernels are timed where they run: (96 layers captured in a hipGraph) - (the same graph without
                 # the kernel), so each finds the L2 state its producers leave (idle CUs prefetch part of the next
                 # kernels' weights) and no host launch rate enters; lm_head (50 us) is looped on its own
-                ms = llm.time_kernel(name, iters=96, in_sequence=True) if name != "lm_head" else llm.time_kernel(name, iters=24)
+                ms = pl.time_kernel(name, iters=96, in_sequence=True) if name != "lm_head" else pl.time_kernel(name, iters=24)
                 in_step = name == "lm_head" or not eng["enabled"]
                 fused = name == "o_proj" and B == 1 and ms * 1e3 < 0.5    # one row: done inside the attention kernel (k_attn<.., FUSE>)
                 ent = {"kernel": name, "launches_per_step": count[name], "in_step": in_step, "avg_us": ms * 1e3,
@@ -535,14 +550,16 @@ def main():
             res["engine"] = eng
             res["kernels"] = ks
             # the reference's default mode (temperature 0.8 / top-k 50 / top-p 0.95): decode step with the sampler in the graph
-            llm.set_sampling(True, 0.8, 50, 0.95, 1234)
-            llm.prefill(prompts, None)
-            llm.decode(8)
-            res["sampling_step_us"] = llm.time_kernel("step", iters=64) * 1e3
-            llm.set_sampling(False)
-            llm.prefill(prompts, None)
-            llm.decode(8)
-            res["greedy_step_us"] = llm.time_kernel("step", iters=64) * 1e3
+            pl.set_sampling(True, 0.8, 50, 0.95, 1234)
+            pl.prefill(prompts, None)
+            pl.decode(8)
+            res["sampling_step_us"] = pl.time_kernel("step", iters=64) * 1e3
+            pl.set_sampling(False)
+            pl.prefill(prompts, None)
+            pl.decode(8)
+            res["greedy_step_us"] = pl.time_kernel("step", iters=64) * 1e3
+            if pl is not llm:
+                pl.close()
             if B == 1:
                 # streaming mode: wall time to the first 1.0 s chunk on the host, and to all chunks
                 from sparkmi.streaming import ChunkScheduler

@@ -20,6 +20,9 @@
  *   - A handle is bound to the device current at create and may be used by one host thread at
  *     a time.  All launches go to the caller's stream; nothing synchronises unless stated.
  *   - There is no CPU fallback anywhere behind this ABI.
+ *   - libsparkmi.so reads NO environment variable.  Timing probes, in-kernel stamps, scratch dumps, A/B switches and the
+ *     experimental one-row engine live in libsparkmi_diag.so (the same sources built with -DSMI_DIAG; it exports this
+ *     header's symbols plus include/sparkmi_debug.h's) -- tools, the bench probes and the op-level tests load that one.
  */
 #ifndef SPARKMI_H
 #define SPARKMI_H
@@ -37,7 +40,9 @@ extern "C" {
 #define SMI_ENOMEM (-3)   /* device allocation failed */
 #define SMI_ESTATE (-4)   /* call sequence violated (e.g. decode before prefill) */
 
-#define SMI_ABI_VERSION 3   /* 2: eos id LISTS, per-sequence sampler streams; 3: smi_llm_cfg.wd_plain (the W_down tile order is data, not environment), engine / debug entry points */
+#define SMI_ABI_VERSION 4   /* 2: eos id LISTS, per-sequence sampler streams; 3: smi_llm_cfg.wd_plain (the W_down tile order is data, not environment);
+                              4: diagnostics (timing probes, stamps, scratch dumps, the one-row engine) left this header for sparkmi_debug.h /
+                                 libsparkmi_diag.so; the product library reads no environment variable */
 #define SMI_MAX_EOS 4      /* eos ids per generation (HF stops on ANY id of generation_config.eos_token_id) */
 #define SMI_MAX_ROWS 64   /* rows (= concurrent sequences, or prompt tokens per prefill chunk) per step */
 
@@ -95,9 +100,20 @@ typedef struct smi_llm_cfg {
  *   norms/bias: f32;  ROPE: float2 (cos,sin) [max_positions][head_dim/2].                      */
 enum smi_llm_section {
   SMI_LLM_LN1 = 0, SMI_LLM_WQKV, SMI_LLM_BQKV, SMI_LLM_WO, SMI_LLM_LN2, SMI_LLM_WGU, SMI_LLM_WD, /* per layer */
-  SMI_LLM_FINAL_NORM, SMI_LLM_LM_HEAD, SMI_LLM_ROPE,                                            /* layer = 0 */
+  SMI_LLM_FINAL_NORM, SMI_LLM_LM_HEAD, SMI_LLM_ROPE, SMI_LLM_TAG,                               /* layer = 0 */
   SMI_LLM_NUM_SECTIONS
 };
+/* SMI_LLM_TAG: 256 bytes the packer fills with a smi_llm_arena_tag.  smi_llm_create reads it back from the device and refuses
+ * an arena that was packed for another ABI version, other dimensions or another W_down tile order than the config it is given
+ * says: a packed arena and the handle that streams it cannot disagree silently (an arena re-used under a different
+ * SPARKMI_WD_PLAIN setting used to give wrong logits with no error). */
+typedef struct smi_llm_arena_tag {
+  char magic[8];             /* "SMIARENA" */
+  int32_t abi_version;       /* SMI_ABI_VERSION of the packer */
+  int32_t wd_plain;          /* = smi_llm_cfg.wd_plain the matrices were packed with */
+  int32_t vocab_size, hidden_size, num_layers, num_heads, num_kv_heads, intermediate_size, max_positions;
+  int32_t reserved[53];
+} smi_llm_arena_tag;
 /* Total arena size in bytes for this config (0 on invalid config). */
 size_t smi_llm_arena_bytes(const smi_llm_cfg* cfg);
 /* Byte offset and byte size of one section; returns SMI_EINVAL for a bad section/layer. */
@@ -160,50 +176,6 @@ int smi_llm_forward_logits(smi_llm* h, const int64_t* ids_host, int S, float* lo
 int smi_llm_steps(smi_llm* h);
 /* Paged KV cache: pages in the pool and pages currently free (both 0 when the cache is not paged). */
 int smi_llm_kv_pages(smi_llm* h, int32_t* total, int32_t* free_pages);
-/* Per-kernel timing probe used by bench.py: launches ONLY the named decode-step kernel of `layer`
- * `iters` times on `stream` (inputs are whatever the scratch holds), bracketed by HIP events, and
- * returns the average milliseconds per launch.  kernel: 0 qkv, 1 attn, 2 o_proj, 3 gate_up,
- * 4 down, 5 lm_head, 6 finalize, 7 = the whole decode step (graph or eager as configured), 8 = all layers of one step
- * (one launch of the one-row engine where it applies, else the layer kernels in order; needs a new prefill afterwards).
- * 16 + k (k = 0..4): layer kernel k timed in sequence -- (iters whole layers) minus (the same layers
- * without k) -- so that it finds the L2 state its producers leave, as inside the decode graph. */
-int smi_llm_time_kernel(smi_llm* h, int kernel, int layer, int iters, float* ms_avg, void* stream);
-/* Diagnostics: one launch of a decode-step GEMM kernel (ids as above, GEMM kernels only) with in-kernel
- * s_memrealtime phase stamps; out[0..7) = mean over blocks of (stamp i - earliest stamp 0) in microseconds,
- * out[7] = shader clock in MHz (tools/stamps.py).  kernel + 32: the layer's earlier kernels (and the previous layer's down_proj)
- * run first, un-stamped, so the stamped kernel finds the cache state it finds inside a decode step (tools/prefetch_stamps.py).
- * Needs a started generation. */
-int smi_llm_debug_stamps(smi_llm* h, int kernel, int layer, double* out);
-/* One-row decode engine (csrc/smi_eng.h).  With ONE live sequence in slot 0 (bf16 KV, contiguous cache, contexts up to
- * 1024 tokens) the layers of a decode step run as one persistent launch -- one workgroup per CU, weights streamed through
- * LDS rings by LDS-DMA, the five all-to-all edges of a layer handed over inside the launch -- instead of four dependent
- * launches per layer; the arithmetic (every product, accumulator chain and addition order) is the launch path's, so the
- * tokens are the same bits.  OPT-IN (SPARKMI_ENGINE=1 at create, or smi_llm_set_engine(h, 1), which builds it on first use:
- * 0.8 GB of re-packed weights): on MI355X at the 0.5B shape the five in-launch hand-offs of a layer cost more than the four
- * kernel boundaries they replace (26.3 vs 23.4 us per layer), so the launch path stays the default.
- *   smi_llm_engine: *enabled = 1 when one-row steps take the engine; info[4] = {CUs, images per wave and layer, LDS bytes,
- *                   built}; why = a one-line reason / description.
- *   smi_llm_set_engine: runtime switch between the engine and the launch path (A/B, tests); synchronises the device; on = 1
- *                   where the engine does not apply (f32 / paged KV, odd shapes, small device) leaves it off (see `why`).
- *   smi_llm_engine_plan: host-only check of the static work plan for `ncu` CUs (no GPU call): every weight image placed
- *                   exactly once, stream order = job order; stats[8] = {images per wave max, per wave and phase max, parts per
- *                   CU and phase max, jobs per wave max, images per CU min, max, LDS bytes, images per layer}.
- *   smi_llm_engine_stamps: diagnostics, SPARKMI_ENGINE_STAMPS=1: out[3][layers][16] microseconds of the last engine launch
- *                   (wave 0 of CU 0, wave 0 of the first head CU, wave 7 of CU 0; after the hand-offs h, q|k|v, attention, h_mid, act).
- * A hand-off that does not complete within SPARKMI_ENGINE_TIMEOUT_MS (default 500) ends the launch; the next call that
- * synchronises (smi_llm_get_tokens / _status / _all_done) returns SMI_EHIP. */
-int smi_llm_engine(smi_llm* h, int32_t* enabled, int32_t* info, char* why, int n);
-int smi_llm_set_engine(smi_llm* h, int on);
-int smi_llm_engine_plan(const smi_llm_cfg* cfg, int ncu, int32_t* stats);
-int smi_llm_engine_stamps(smi_llm* h, double* out, int cap);
-/* Tests: synchronises and copies the residual row (hidden_size floats) of row 0 as the last step left it. */
-int smi_llm_debug_hidden(smi_llm* h, float* out_host, int n);
-/* Tests / debugging: synchronises and copies one scratch buffer as raw bytes.  what: 0 q [q_dim] f32, 1 / 2 / 3 the operand
- * triples of o_proj / down_proj / the next norm ([K / 32][3][4][16 B] at one row), 4 the residual row, 5 the engine's
- * granules [2][per buffer] u64 {tag << 32 | f32 bits}, 6 partial sums of squares [hidden / 4], 7 K rows of layer 0, slot 0,
- * kv head 0 (bf16), 8 h + o_proj of the fused one-row path. */
-int smi_llm_debug_read(smi_llm* h, int what, void* out_host, size_t cap, size_t* got);
-
 /* ------------------------------------------------------------------------------------------
  * Vocoder: BiCodec.detokenize (codebook lookup, d-vector, ConvNeXt prenet, WaveGenerator).
  * ---------------------------------------------------------------------------------------- */

@@ -3,7 +3,23 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include "sparkmi.h"
+#ifdef SMI_DIAG
+#include "sparkmi_debug.h"
+#endif
+
+// Environment switches exist only in the diagnostics build (libsparkmi_diag.so, -DSMI_DIAG: A/B variants, ablations, the
+// test-only stage dumps).  The product library reads nothing from the environment: every behaviour a maintainer binding
+// include/sparkmi.h sees comes from the config structs and the call arguments.
+static inline const char* smi_env(const char* name) {
+#ifdef SMI_DIAG
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 void smi_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 

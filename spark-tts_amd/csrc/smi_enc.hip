@@ -615,7 +615,7 @@ int smi_enc_create(const smi_enc_cfg* cfg, const void* arena_dev, size_t arena_b
   want("out_sem", (size_t)2 * T);           // int64 ids
   want("out_glob", (size_t)c.spk_tokens + 64);
   {
-    const char* e = getenv("SPARKMI_ENC_GRAPH");
+    const char* e = smi_env("SPARKMI_ENC_GRAPH");
     h->use_graph = !(e && e[0] == '0');
   }
   // more than the default dynamic LDS window for the attention / positional-conv kernels (per device, before any capture)

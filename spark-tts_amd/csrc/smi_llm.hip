@@ -677,7 +677,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
 // ------------------------------------------------------------------------------------------
 template <int TPC>
 __global__ __launch_bounds__(256) void k_down1(GemmP p) {
-  __shared__ float red[16 * 4];
+  __shared__ __attribute__((aligned(16))) float red[16 * 4];   // read and written as float4
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if ((int)blockIdx.x >= p.work_blocks) {
     pf_run(p.pf, (int)blockIdx.x - p.work_blocks, (int)gridDim.x - p.work_blocks, tid, 256);
@@ -2290,12 +2290,13 @@ __global__ __launch_bounds__(256) void k_sample_scan(SampleP p) {
 __global__ __launch_bounds__(1024) void k_sample(SampleP p) {
   __shared__ unsigned int hist[256];
   __shared__ unsigned int s_prefix, s_need, s_cnt;
+  __shared__ int s_k;
   __shared__ float s_thr;
   __shared__ float cv[kCandCap], sv[kSampleCap];
   __shared__ int ci[kCandCap], si[kSampleCap];
   const int m = blockIdx.x, tid = threadIdx.x;
   const float* lg = p.logits + (size_t)m * p.V;
-  if (tid == 0) { s_cnt = 0; s_thr = -INFINITY; }
+  if (tid == 0) { s_cnt = 0; s_thr = -INFINITY; s_k = 0; }
   __syncthreads();
   const bool bound_ok = p.pval && p.nblk <= kCandCap && p.nblk >= p.top_k;   // the condition k_sample_scan ran under
   if (bound_ok) {
@@ -2334,8 +2335,17 @@ __global__ __launch_bounds__(1024) void k_sample(SampleP p) {
     if (r < kSampleCap) { sv[r] = v; si[r] = ix; }
   }
   __syncthreads();
+  // TopKLogitsWarper removes what is strictly BELOW the k-th largest value (logits_process.py: `scores < topk[..., -1]`), so
+  // every logit that ties with the k-th stays: the kept set is the sorted prefix of ranks < top_k plus the ranks behind it
+  // that hold the same value (up to the kSampleCap ranks this kernel sorts)
+  {
+    const int nn = n < kSampleCap ? n : kSampleCap, kb = n < p.top_k ? n : p.top_k;
+    if (tid < nn && (tid < kb || sv[tid] == sv[kb - 1])) atomicAdd(&s_k, 1);
+  }
+  __syncthreads();
+  const int ktop = s_k;
   {   // softmax numerators of the top-k of logits / T (fp32, like the warpers), one per thread
-    const int k = n < p.top_k ? n : p.top_k;
+    const int k = ktop;
     float e = 0.f;
     if (tid < k) e = expf(sv[tid] * p.inv_temp - sv[0] * p.inv_temp);
     __syncthreads();   // cv (the candidates) has been read by the rank sort
@@ -2346,7 +2356,7 @@ __global__ __launch_bounds__(1024) void k_sample(SampleP p) {
   // sums and prefix sums come from shuffles instead of four serial loops with a division each on one thread (15 us).
   if (tid < 64) {
     static_assert(kSampleCap == 256, "four ranks per lane");
-    const int k = n < p.top_k ? n : p.top_k;
+    const int k = ktop;
     const int i0 = tid * 4;
     float c[4];
 #pragma unroll
@@ -2489,8 +2499,10 @@ __global__ __launch_bounds__(256) void k_finalize(FinP p) {
 }
 
 }  // namespace
-#include "smi_eng.h"        // the one-row decode engine: all layers of a step in one persistent launch
+#ifdef SMI_DIAG   // the one-row decode engine (built, bit-exact, slower than the launch path: DESIGN 3.7) lives in the diagnostics build only
+#include "smi_eng.h"        // all layers of a step in one persistent launch
 #include "smi_eng_host.h"
+#endif
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -2536,11 +2548,12 @@ Layout make_layout(const smi_llm_cfg* c) {
   L.bytes[SMI_LLM_FINAL_NORM] = H * 4;
   L.bytes[SMI_LLM_LM_HEAD] = (size_t)L.vpad * H * 2;
   L.bytes[SMI_LLM_ROPE] = (size_t)c->max_positions * (kHeadDim / 2) * 8;
+  L.bytes[SMI_LLM_TAG] = sizeof(smi_llm_arena_tag);
   size_t o = 0;
   for (int s = SMI_LLM_LN1; s <= SMI_LLM_WD; ++s) { L.off[s] = o; o += smi_align_up(L.bytes[s], 256); }
   L.layer_stride = o;
   size_t g = 0;
-  for (int s = SMI_LLM_FINAL_NORM; s <= SMI_LLM_ROPE; ++s) { L.off[s] = g; g += smi_align_up(L.bytes[s], 256); }
+  for (int s = SMI_LLM_FINAL_NORM; s <= SMI_LLM_TAG; ++s) { L.off[s] = g; g += smi_align_up(L.bytes[s], 256); }
   L.layers_base = g;
   L.total = g + L.layer_stride * c->num_layers;
   return L;
@@ -2607,7 +2620,9 @@ struct smi_llm {
   int gu1_lo;           // rows from which (up to 16) gate_up runs the one-batch, three-tile shape with one m-tile (SPARKMI_GU1_LO; default 4)
   int gu1_rows;         // rows up to which gate_up runs its one-batch, three-tile shape (SPARKMI_GU1_ROWS; default 32)
   hipGraphExec_t graph; int graph_B, graph_seg, graph_ident;   // the step graph in use (owned by graph_cache)
-  hipStream_t graph_stream; int graph_launched;                // stream of the last replay (drained before execs are destroyed)
+  // every exec remembers the stream it last ran on: a caller may alternate streams, and an exec is destroyed only after THAT
+  // stream has drained (graphs_flush)
+  std::map<hipGraphExec_t, hipStream_t> graph_last;
   // One captured decode step per (row count, context segments, slots-are-rows): in-flight batching changes the row count at
   // every admission / retirement, and re-capturing the ~100-node step each time cost more than the steps saved.  Everything
   // else a step reads is device data (row descriptors, stop ids, seed) or fixed at create; the sampler's parameters and the
@@ -2616,8 +2631,10 @@ struct smi_llm {
   hipEvent_t ev0, ev1;
   // host staging
   std::vector<RowDesc> host_rows;
+#ifdef SMI_DIAG
   EngState eng;         // one-row decode engine (smi_eng.h); eng.enabled = 0: the launch path everywhere
   int eng_on;           // runtime switch (smi_llm_set_engine; SPARKMI_ENGINE=0 at create)
+#endif
 };
 
 namespace {
@@ -2654,8 +2671,15 @@ int pages_ensure(smi_llm* L, const int* slots, const int* tokens, int n, hipStre
 }
 KvMap kv_map(const smi_llm* L) { return KvMap{L->paged ? L->ptab : nullptr, L->pshift, L->ppslot}; }
 void graphs_flush(smi_llm* L) {
-  // an exec is never destroyed while a launch of it may still be running: the stream of the last replay drains first
-  if (L->graph_launched) { (void)hipStreamSynchronize(L->graph_stream); L->graph_launched = 0; }
+  // an exec is never destroyed while a launch of it may still be running: the stream each exec last ran on drains first
+  // (one synchronise per distinct stream)
+  std::vector<hipStream_t> drained;
+  for (auto& gl : L->graph_last) {
+    bool seen = false;
+    for (hipStream_t d : drained) seen |= d == gl.second;
+    if (!seen) { (void)hipStreamSynchronize(gl.second); drained.push_back(gl.second); }
+  }
+  L->graph_last.clear();
   for (auto& kv : L->graph_cache) if (kv.second) (void)hipGraphExecDestroy(kv.second);
   L->graph_cache.clear();
   L->graph = nullptr;
@@ -2801,6 +2825,12 @@ void* kv_layer(const smi_llm* L, void* base, int layer) {
   return (unsigned char*)base + (size_t)layer * L->kv_layer_elems * esz;
 }
 
+#ifndef SMI_DIAG   // product build: no engine (the launch path everywhere)
+inline void eng_destroy(smi_llm*) {}
+inline bool eng_usable(const smi_llm*, const RowDesc*, int) { return false; }
+inline int eng_launch(smi_llm*, hipStream_t) { return SMI_OK; }
+inline int eng_check(smi_llm*) { return SMI_OK; }
+#else
 // ---- one-row decode engine (smi_eng.h): build at create, launch in place of the 4 x layers launches of a one-row step
 void eng_destroy(smi_llm* L) {
   EngState& E = L->eng;
@@ -2817,14 +2847,14 @@ int eng_create(smi_llm* L) {
   const smi_llm_cfg& c = L->cfg;
   E.enabled = 0;
   auto skip = [&](const char* m) { snprintf(E.why, sizeof(E.why), "%s", m); return SMI_OK; };
-  { const char* e = getenv("SPARKMI_ENGINE"); if (e && e[0] == '0') return skip("SPARKMI_ENGINE=0"); }
+  { const char* e = smi_env("SPARKMI_ENGINE"); if (e && e[0] == '0') return skip("SPARKMI_ENGINE=0"); }
   if (c.kv_dtype != 0) return skip("f32 KV cache");
   if (L->paged) return skip("paged KV cache");
   if (L->tune[0] || L->tune[1] || L->tune[2] || L->tune[3]) return skip("SPARKMI_TUNE set");
   int dev = 0, ncu = 0;
   SMI_HIP(hipGetDevice(&dev));
   SMI_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-  { const char* e = getenv("SPARKMI_ENGINE_CUS"); if (e && atoi(e) > 0 && atoi(e) <= ncu) ncu = atoi(e); }
+  { const char* e = smi_env("SPARKMI_ENGINE_CUS"); if (e && atoi(e) > 0 && atoi(e) <= ncu) ncu = atoi(e); }
   EngPlanHost P;
   char why[128];
   if (!eng_build_plan(L->H, L->Q, L->KV, L->I, c.num_heads, ncu, P, why, sizeof(why))) return skip(why);
@@ -2832,11 +2862,11 @@ int eng_create(smi_llm* L) {
   if (lds.total > 160 * 1024 - 512) return skip("LDS image too large");
   E.ncu = ncu; E.maxlen = P.maxlen; E.lds = lds.total;
   E.gran_per_buf = 2 * L->H + (L->Q + 2 * L->KV) + L->Q + L->I;
-  { const char* e = getenv("SPARKMI_ENGINE_BURST"); E.ld_burst = e && atoi(e) > 0 ? atoi(e) : 16; }
-  { const char* e = getenv("SPARKMI_ENGINE_POLL"); E.poll_quiet = e ? atoi(e) : 1; }
-  { const char* e = getenv("SPARKMI_ENGINE_DELAYS"); for (int i = 0; i < 5; ++i) E.edge_delay[i] = 16; if (e) sscanf(e, "%d,%d,%d,%d,%d", &E.edge_delay[0], &E.edge_delay[1], &E.edge_delay[2], &E.edge_delay[3], &E.edge_delay[4]); }
-  { const char* e = getenv("SPARKMI_ENGINE_SLEEP"); E.ld_sleep = e && atoi(e) >= 0 ? atoi(e) : 0; }
-  { const char* e = getenv("SPARKMI_ENGINE_TIMEOUT_MS"); const double ms = e ? atof(e) : 500.0; E.timeout_ticks = (unsigned)((ms > 1.0 ? ms : 1.0) * 1e5); }
+  { const char* e = smi_env("SPARKMI_ENGINE_BURST"); E.ld_burst = e && atoi(e) > 0 ? atoi(e) : 16; }
+  { const char* e = smi_env("SPARKMI_ENGINE_POLL"); E.poll_quiet = e ? atoi(e) : 1; }
+  { const char* e = smi_env("SPARKMI_ENGINE_DELAYS"); for (int i = 0; i < 5; ++i) E.edge_delay[i] = 16; if (e) sscanf(e, "%d,%d,%d,%d,%d", &E.edge_delay[0], &E.edge_delay[1], &E.edge_delay[2], &E.edge_delay[3], &E.edge_delay[4]); }
+  { const char* e = smi_env("SPARKMI_ENGINE_SLEEP"); E.ld_sleep = e && atoi(e) >= 0 ? atoi(e) : 0; }
+  { const char* e = smi_env("SPARKMI_ENGINE_TIMEOUT_MS"); const double ms = e ? atof(e) : 500.0; E.timeout_ticks = (unsigned)((ms > 1.0 ? ms : 1.0) * 1e5); }
   const size_t ncw = (size_t)ncu;   // one stream per CU
   const size_t stream_bytes = (size_t)c.num_layers * ncw * P.maxlen * 1024;
   uint32_t* desc_dev = nullptr;
@@ -2855,12 +2885,15 @@ int eng_create(smi_llm* L) {
   if (hipMalloc((void**)&E.stamps, (size_t)3 * c.num_layers * 16 * 8) != hipSuccess) return oom("stamps", (size_t)3 * c.num_layers * 128);
   if (hipMalloc((void**)&desc_dev, P.desc.size() * 4) != hipSuccess) return oom("descriptors", P.desc.size() * 4);
   if (hipMalloc((void**)&lens_dev, P.lens.size() * 2) != hipSuccess) return oom("lengths", P.lens.size() * 2);
-  SMI_HIP(hipMemcpy(E.plan, P.cu.data(), P.cu.size() * sizeof(EngCuPlan), hipMemcpyHostToDevice));
-  SMI_HIP(hipMemcpy(desc_dev, P.desc.data(), P.desc.size() * 4, hipMemcpyHostToDevice));
-  SMI_HIP(hipMemcpy(lens_dev, P.lens.data(), P.lens.size() * 2, hipMemcpyHostToDevice));
-  SMI_HIP(hipMemset(E.gran, 0, (size_t)2 * E.gran_per_buf * 8));
-  SMI_HIP(hipMemset(E.words, 0, 256));
-  SMI_HIP(hipMemset(E.stamps, 0, (size_t)3 * c.num_layers * 128));
+  // (a failing copy / memset frees the two temporaries and the engine's buffers like a failing allocation does)
+#define SMI_ENG_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { smi_set_error("%s: %s", #call, hipGetErrorString(e_)); \
+    (void)hipFree(desc_dev); (void)hipFree(lens_dev); eng_destroy(L); return SMI_EHIP; } } while (0)
+  SMI_ENG_HIP(hipMemcpy(E.plan, P.cu.data(), P.cu.size() * sizeof(EngCuPlan), hipMemcpyHostToDevice));
+  SMI_ENG_HIP(hipMemcpy(desc_dev, P.desc.data(), P.desc.size() * 4, hipMemcpyHostToDevice));
+  SMI_ENG_HIP(hipMemcpy(lens_dev, P.lens.data(), P.lens.size() * 2, hipMemcpyHostToDevice));
+  SMI_ENG_HIP(hipMemset(E.gran, 0, (size_t)2 * E.gran_per_buf * 8));
+  SMI_ENG_HIP(hipMemset(E.words, 0, 256));
+  SMI_ENG_HIP(hipMemset(E.stamps, 0, (size_t)3 * c.num_layers * 128));
   EngPackP pk;
   memset(&pk, 0, sizeof(pk));
   pk.desc = desc_dev; pk.lens = lens_dev; pk.maxlen = P.maxlen; pk.ncw = (int)ncw;
@@ -2871,8 +2904,9 @@ int eng_create(smi_llm* L) {
   pk.out = (uint4*)E.stream;
   const size_t imgs = ncw * P.maxlen;
   hipLaunchKernelGGL(k_eng_pack, dim3((unsigned)((imgs + 3) / 4), (unsigned)c.num_layers), dim3(256), 0, 0, pk);
-  SMI_LAUNCH_CHECK();
-  SMI_HIP(hipDeviceSynchronize());
+  SMI_ENG_HIP(hipGetLastError());
+  SMI_ENG_HIP(hipDeviceSynchronize());
+#undef SMI_ENG_HIP
   (void)hipFree(desc_dev);
   (void)hipFree(lens_dev);
   if (hipFuncSetAttribute((const void*)k_engine, hipFuncAttributeMaxDynamicSharedMemorySize, E.lds) != hipSuccess) {
@@ -2910,7 +2944,7 @@ int eng_launch(smi_llm* L, hipStream_t st) {
   p.timeout_ticks = E.timeout_ticks;
   p.ld_burst = E.ld_burst; p.ld_sleep = E.ld_sleep; p.poll_quiet = E.poll_quiet;
   for (int i = 0; i < 5; ++i) p.edge_delay[i] = E.edge_delay[i];
-  p.stamps = getenv("SPARKMI_ENGINE_STAMPS") ? E.stamps : nullptr;
+  p.stamps = smi_env("SPARKMI_ENGINE_STAMPS") ? E.stamps : nullptr;
   hipLaunchKernelGGL(k_engine, dim3(E.ncu), dim3(kEngBlock), E.lds, st, p);
   SMI_LAUNCH_CHECK();
   return SMI_OK;
@@ -2928,6 +2962,7 @@ int eng_check(smi_llm* L) {
                 (e[1] - 1) / 8, (e[1] - 1) % 8, L->eng.ncu);
   return SMI_EHIP;
 }
+#endif   // SMI_DIAG
 
 enum { KQKV = 0, KATTN, KO, KGU, KD, KLM, KFIN };
 
@@ -3330,6 +3365,18 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   Layout lay = make_layout(cfg);
   SMI_REQUIRE(arena_dev && arena_bytes >= lay.total, "smi_llm_create: arena too small (%zu < %zu)", arena_bytes, lay.total);
   SMI_REQUIRE(((uintptr_t)arena_dev & 255) == 0, "smi_llm_create: arena must be 256-byte aligned");
+  {   // the arena says how it was packed (include/sparkmi.h: smi_llm_arena_tag); a mismatch with the config is an error, not wrong logits
+    static_assert(sizeof(smi_llm_arena_tag) == 256, "arena tag is one 256-byte section");
+    smi_llm_arena_tag tag;
+    SMI_HIP(hipMemcpy(&tag, (const unsigned char*)arena_dev + lay.off[SMI_LLM_TAG], sizeof(tag), hipMemcpyDeviceToHost));
+    SMI_REQUIRE(memcmp(tag.magic, "SMIARENA", 8) == 0, "smi_llm_create: the arena carries no layout tag (section SMI_LLM_TAG): not packed for this library, or for other dimensions");
+    SMI_REQUIRE(tag.abi_version == SMI_ABI_VERSION, "smi_llm_create: arena packed for ABI %d, this library is ABI %d", tag.abi_version, SMI_ABI_VERSION);
+    SMI_REQUIRE(tag.wd_plain == cfg->wd_plain, "smi_llm_create: the arena's W_down tiles are packed %s, the config says %s (smi_llm_cfg.wd_plain)",
+                tag.wd_plain ? "in the plain tile order" : "row-part-major", cfg->wd_plain ? "plain" : "row-part-major");
+    SMI_REQUIRE(tag.vocab_size == cfg->vocab_size && tag.hidden_size == cfg->hidden_size && tag.num_layers == cfg->num_layers &&
+                tag.num_heads == cfg->num_heads && tag.num_kv_heads == cfg->num_kv_heads && tag.intermediate_size == cfg->intermediate_size &&
+                tag.max_positions == cfg->max_positions, "smi_llm_create: the arena was packed for other dimensions than this config");
+  }
   smi_llm* L = new smi_llm();
   L->cfg = *cfg; L->lay = lay; L->arena = (const unsigned char*)arena_dev;
   L->H = cfg->hidden_size; L->Q = cfg->num_heads * cfg->head_dim; L->KV = cfg->num_kv_heads * cfg->head_dim;
@@ -3340,7 +3387,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->lm_blocks = L->lm_cap < 512 ? L->lm_cap : 512;    // persistent path: 2 resident blocks per CU
   L->max_steps = cfg->max_positions;
   L->do_sample = 0; L->top_k = 50; L->temperature = 0.8f; L->top_p = 0.95f; L->seed = 0; L->logits = nullptr; L->tok = nullptr; L->cand_v = nullptr; L->cand_i = nullptr; L->cand_n = nullptr; L->stamps = nullptr; L->stamps_on = 0;
-  { L->tune[0] = L->tune[1] = L->tune[2] = L->tune[3] = 0; const char* e = getenv("SPARKMI_TUNE"); if (e) sscanf(e, "%d,%d,%d,%d", &L->tune[0], &L->tune[1], &L->tune[2], &L->tune[3]); }
+  { L->tune[0] = L->tune[1] = L->tune[2] = L->tune[3] = 0; const char* e = smi_env("SPARKMI_TUNE"); if (e) sscanf(e, "%d,%d,%d,%d", &L->tune[0], &L->tune[1], &L->tune[2], &L->tune[3]); }
   L->bh = L->bq = nullptr; L->bxs_h = L->bxs_attn = L->bxs_act = nullptr; L->bss = nullptr; L->big_rows = 0;
   // helper-block prefetch per producer: bit 0 QKV (gate_up's first half), bit 1 attention (second half), bit 2 down_proj (the next
   // layer's QKV / o_proj); SPARKMI_PREFETCH=<mask> picks, SPARKMI_NO_PREFETCH=1 is mask 0
@@ -3348,30 +3395,29 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   // row: mask 0 566-571 us, 1 563-564, 2 581, 3 583, 4 597, 5 602, 6 658, 7 665 (down_proj's 256-thread blocks make slow helpers);
   // at 4 rows mask 0 727 us, 3 748, 7 739-745 (profiles/r03_prefetch.txt).  SPARKMI_PREFETCH=<mask> applies up to 8 rows as before.
   L->prefetch_mask = 1; L->prefetch_rows = 1;
-  if (const char* e = getenv("SPARKMI_PREFETCH")) { L->prefetch_mask = atoi(e) & 7; L->prefetch_rows = 8; }
-  if (getenv("SPARKMI_NO_PREFETCH")) L->prefetch_mask = 0;
-  { const char* e = getenv("SPARKMI_GRAPH_STEPS"); L->graph_steps = e ? atoi(e) : 8; if (L->graph_steps < 1 || L->graph_steps > 32) L->graph_steps = 8; }
-  { const char* e = getenv("SPARKMI_PF_INLINE"); L->pf_inline = !(e && e[0] == '0'); }
-  { const char* e = getenv("SPARKMI_PF_QKV"); L->pf_qkv_eighths = e ? atoi(e) : 2; if (L->pf_qkv_eighths < 0 || L->pf_qkv_eighths > 8) L->pf_qkv_eighths = 2; }
+  if (const char* e = smi_env("SPARKMI_PREFETCH")) { L->prefetch_mask = atoi(e) & 7; L->prefetch_rows = 8; }
+  if (smi_env("SPARKMI_NO_PREFETCH")) L->prefetch_mask = 0;
+  { const char* e = smi_env("SPARKMI_GRAPH_STEPS"); L->graph_steps = e ? atoi(e) : 8; if (L->graph_steps < 1 || L->graph_steps > 32) L->graph_steps = 8; }
+  { const char* e = smi_env("SPARKMI_PF_INLINE"); L->pf_inline = !(e && e[0] == '0'); }
+  { const char* e = smi_env("SPARKMI_PF_QKV"); L->pf_qkv_eighths = e ? atoi(e) : 2; if (L->pf_qkv_eighths < 0 || L->pf_qkv_eighths > 8) L->pf_qkv_eighths = 2; }
   L->part_o = nullptr; L->h2 = nullptr;
-  L->fuse_o = !getenv("SPARKMI_NO_FUSE_O") && (cfg->num_heads == 14 || cfg->num_heads == 4) && cfg->num_heads <= kMaxOHeads &&
+  L->fuse_o = !smi_env("SPARKMI_NO_FUSE_O") && (cfg->num_heads == 14 || cfg->num_heads == 4) && cfg->num_heads <= kMaxOHeads &&
               L->NTh % kFuseQB == 0 && L->NTh / kFuseQB <= kAttnWaves * kFuseOT && L->KTh * 8 <= 256;
-  { const char* e = getenv("SPARKMI_TUNE2"); L->tune2 = e ? atoi(e) : 0; }
-  { const char* e = getenv("SPARKMI_PGEMM_MIN_ROWS"); L->pgemm_min_rows = e ? atoi(e) : 1280; }
+  { const char* e = smi_env("SPARKMI_TUNE2"); L->tune2 = e ? atoi(e) : 0; }
+  { const char* e = smi_env("SPARKMI_PGEMM_MIN_ROWS"); L->pgemm_min_rows = e ? atoi(e) : 1280; }
   {
     const char* names[4] = {"SPARKMI_PGEMM_MIN_QKV", "SPARKMI_PGEMM_MIN_O", "SPARKMI_PGEMM_MIN_GU", "SPARKMI_PGEMM_MIN_D"};
     // measured crossovers (tools/prefill_time.py mix / mix2, profiles/README.md): gate_up from ~300 rows (its grouped form re-reads
     // the operand triples once per 32 columns), down_proj from ~900, the two short-K GEMMs from ~1300
     const int dflt[4] = {1280, 1280, 288, 896};
-    const bool common = getenv("SPARKMI_PGEMM_MIN_ROWS") != nullptr;
-    for (int i = 0; i < 4; ++i) { const char* e = getenv(names[i]); L->pg_min[i] = e ? atoi(e) : common ? L->pgemm_min_rows : dflt[i]; }
+    const bool common = smi_env("SPARKMI_PGEMM_MIN_ROWS") != nullptr;
+    for (int i = 0; i < 4; ++i) { const char* e = smi_env(names[i]); L->pg_min[i] = e ? atoi(e) : common ? L->pgemm_min_rows : dflt[i]; }
   }
-  { const char* e = getenv("SPARKMI_GU1_ROWS"); L->gu1_rows = e ? atoi(e) : 32; }
-  { const char* e = getenv("SPARKMI_GU1_LO"); L->gu1_lo = e ? atoi(e) : 4; }
+  { const char* e = smi_env("SPARKMI_GU1_ROWS"); L->gu1_rows = e ? atoi(e) : 32; }
+  { const char* e = smi_env("SPARKMI_GU1_LO"); L->gu1_lo = e ? atoi(e) : 4; }
   L->wd_parts = cfg->wd_plain ? 0 : 1;   // the arena's W_down tile order comes with its config (never from the environment)
   L->pf_tiles = nullptr; L->pf_tiles_cap = 0; L->pf_ntiles = 0;
-  { const char* e = getenv("SPARKMI_ATTN_PF2"); L->attn_pf2 = !(e && e[0] == '0'); }
-  L->graph_stream = nullptr; L->graph_launched = 0;
+  { const char* e = smi_env("SPARKMI_ATTN_PF2"); L->attn_pf2 = !(e && e[0] == '0'); }
   L->graph = nullptr; L->graph_B = 0; L->graph_seg = 1; L->graph_ident = 1; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->ctl = nullptr; L->admit_seq = 0; memset(&L->hctl, 0, sizeof(L->hctl));
   L->session = 0; L->identity_slots = 1; L->attn_seg = 1; L->apart = nullptr; L->apart_floats = 0; memset(L->slot_busy, 0, sizeof(L->slot_busy)); memset(L->slot_len, 0, sizeof(L->slot_len));
   const size_t esz = cfg->kv_dtype ? 4 : 2;
@@ -3449,15 +3495,17 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   // 0.8 GB of re-packed weights): measured on MI355X at the 0.5B shape a layer takes 26.3 us in the engine against 23.4 us
   // as four launches -- five in-launch hand-offs of 2.5-4.5 us cost more than the four kernel boundaries they replace
   // (profiles/r03_engine_ab.txt).
+#ifdef SMI_DIAG
   L->eng_on = 0;
   snprintf(L->eng.why, sizeof(L->eng.why), "off (opt-in: SPARKMI_ENGINE=1 or smi_llm_set_engine)");
-  { const char* e = getenv("SPARKMI_ENGINE");
+  { const char* e = smi_env("SPARKMI_ENGINE");
     if (e && e[0] == '1') {
       const int rce = eng_create(L);
       if (rce) { smi_llm_destroy(L); return rce; }
       L->eng_on = L->eng.enabled;
     }
   }
+#endif
   *out = L;
   return SMI_OK;
 }
@@ -3535,7 +3583,7 @@ static int prefill_prompts(smi_llm* L, const int64_t* ids, const int32_t* lens, 
   SMI_HIP(hipMemcpyAsync(L->plan, L->host_rows.data(), L->host_rows.size() * sizeof(RowDesc), hipMemcpyHostToDevice, st));
   // measured (tools/prefill_time.py, profiles/README.md): 32-row chunks ~1.4 ms each; row-grouped decode GEMMs
   // ~1.5 ms + 9 us/row; the prefill GEMM ~15 ms + 5 us/row (crossover near 3000 rows)
-  if (total > (size_t)kMaxRows && !getenv("SPARKMI_PREFILL_CHUNKS")) {
+  if (total > (size_t)kMaxRows && !smi_env("SPARKMI_PREFILL_CHUNKS")) {
     // many prompt rows: whole groups of up to kBigRows rows through the prefill GEMM (k_pgemm)
     constexpr size_t kBigRows = 4096;
     if ((rc = ensure_big(L, (int)(total < kBigRows ? total : kBigRows)))) return rc;
@@ -3919,14 +3967,14 @@ int smi_llm_decode(smi_llm* L, int n_steps, void* stream) {
     if (gk) {
       for (; s0 + K <= n_steps; s0 += K) {
         SMI_HIP(hipGraphLaunch(gk, st));
-        L->graph_stream = st; L->graph_launched = 1;
+        L->graph_last[gk] = st;
       }
     }
   }
   for (int s = s0; s < n_steps; ++s) {
     if (L->cfg.use_graph) {
       SMI_HIP(hipGraphLaunch(L->graph, st));
-      L->graph_stream = st; L->graph_launched = 1;
+      L->graph_last[L->graph] = st;
     } else if ((rc = launch_step(L, L->B, st))) {
       return rc;
     }
@@ -4024,6 +4072,7 @@ int smi_llm_forward_logits(smi_llm* L, const int64_t* ids, int S, float* logits_
   return SMI_OK;
 }
 
+#ifdef SMI_DIAG   // ---- everything below: include/sparkmi_debug.h, exported by libsparkmi_diag.so only
 // Diagnostics: one launch of a decode-step GEMM kernel with in-kernel s_memrealtime stamps
 // (10 ns ticks); out[0..7) = mean over blocks of (stamp i - earliest stamp 0), out[7] = blocks.
 int smi_llm_debug_stamps(smi_llm* L, int kernel, int layer, double* out) {
@@ -4251,6 +4300,46 @@ int smi_llm_debug_read(smi_llm* L, int what, void* out_host, size_t cap, size_t*
   return SMI_OK;
 }
 
+// Tests: the sampler alone on a caller's logits row (see sparkmi_debug.h).
+int smi_llm_debug_sample(smi_llm* L, const float* logits_host, int n_rows, uint64_t seed, int use_bound, int32_t* tokens_out) {
+  SMI_REQUIRE(L && tokens_out && n_rows >= 1 && n_rows <= kMaxRows, "smi_llm_debug_sample: bad argument");
+  SMI_REQUIRE(L->do_sample, "smi_llm_debug_sample: smi_llm_set_sampling(do_sample = 1, ...) first");
+  const int V = L->cfg.vocab_size;
+  const int nblk = lm_blocks_for(L, n_rows);
+  SMI_HIP(hipDeviceSynchronize());
+  if (logits_host) {
+    for (int m = 0; m < kMaxRows; ++m) SMI_HIP(hipMemcpy(L->logits + (size_t)m * V, logits_host, (size_t)V * 4, hipMemcpyHostToDevice));
+    // what the lm_head blocks would have left: one maximum per block; here block j holds the j-th contiguous share of the row
+    std::vector<float> pv((size_t)kMaxRows * L->lm_cap, -INFINITY);
+    const int per = (V + nblk - 1) / nblk;
+    for (int j = 0; j < nblk; ++j) {
+      float mx = -INFINITY;
+      for (int i = j * per; i < V && i < (j + 1) * per; ++i) mx = logits_host[i] > mx ? logits_host[i] : mx;
+      for (int m = 0; m < kMaxRows; ++m) pv[(size_t)m * nblk + j] = mx;
+    }
+    SMI_HIP(hipMemcpy(L->pval, pv.data(), (size_t)kMaxRows * nblk * 4, hipMemcpyHostToDevice));
+  }
+  std::vector<RowDesc> rows(kMaxRows, RowDesc{0, 0, 0, 0});
+  for (int m = 0; m < kMaxRows; ++m) { rows[m].slot = m; L->hctl.seqid[m] = m; }
+  L->hctl.seed = seed;
+  SMI_HIP(hipMemcpy(L->rows, rows.data(), rows.size() * sizeof(RowDesc), hipMemcpyHostToDevice));
+  SMI_HIP(hipMemcpy(L->ctl, &L->hctl, sizeof(Ctl), hipMemcpyHostToDevice));
+  SMI_HIP(hipMemset(L->cand_n, 0, kMaxRows * 4));
+  SampleP sp;
+  sp.logits = L->logits; sp.V = V; sp.top_k = L->top_k; sp.inv_temp = 1.0f / L->temperature;
+  sp.top_p = L->top_p; sp.ctl = L->ctl; sp.rows = L->rows; sp.tok = L->tok;
+  sp.pval = use_bound ? L->pval : nullptr; sp.nblk = nblk;
+  sp.cand_v = L->cand_v; sp.cand_i = L->cand_i; sp.cand_n = L->cand_n;
+  hipLaunchKernelGGL(k_sample_scan, dim3(kScanBlocks, n_rows), dim3(256), 0, 0, sp);
+  SMI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_sample, dim3(n_rows), dim3(1024), 0, 0, sp);
+  SMI_LAUNCH_CHECK();
+  SMI_HIP(hipDeviceSynchronize());
+  SMI_HIP(hipMemcpy(tokens_out, L->tok, (size_t)n_rows * 4, hipMemcpyDeviceToHost));
+  L->started = 0;   // rows, controls and the lm_head partials no longer belong to a generation
+  return SMI_OK;
+}
+
 // Diagnostics (SPARKMI_ENGINE_STAMPS=1): out[3][layers][16] microseconds since the first stamp of the last engine launch:
 // CU 0 and the first head CU after the hand-offs A (h), B (q|k|v), C (attention), D (h_mid), E (act).
 int smi_llm_engine_stamps(smi_llm* L, double* out, int cap) {
@@ -4265,5 +4354,6 @@ int smi_llm_engine_stamps(smi_llm* L, double* out, int cap) {
   for (int i = 0; i < n; ++i) out[i] = h[i] ? (double)(h[i] - t0) * 0.01 : -1.0;
   return SMI_OK;
 }
+#endif   // SMI_DIAG
 
 }  // extern "C"

@@ -810,7 +810,7 @@ Launch make_conv_w(const std::string& name, const float* W, const float* bias,
   p.Cin = Cin; p.CinP = pad8(Cin); p.Cout = Cout; p.S = S; p.act = act;
   p.xstride = xstride; p.ystride = ystride; p.xb = xb; p.yb = yb;
   p.out_scale = 1.0f;
-  { const char* e = getenv("SPARKMI_SNAKE_SINF"); p.fast_sin = bf && !(e && e[0] == '1'); }   // SPARKMI_SNAKE_SINF=1: library sine everywhere (A/B)
+  { const char* e = smi_env("SPARKMI_SNAKE_SINF"); p.fast_sin = bf && !(e && e[0] == '1'); }   // SPARKMI_SNAKE_SINF=1: library sine everywhere (A/B)
   p.istr = istr; p.olens = olens;
   for (int r = 0; r < S; ++r) {
     p.ntaps[r] = g.ntaps[r];
@@ -821,7 +821,7 @@ Launch make_conv_w(const std::string& name, const float* W, const float* bias,
   // waves split the input channels when there are few time tiles and many channels
   // 64-column time tiles unless that leaves most CUs idle (short sequences): then 32-column tiles double the blocks
   const long long blocks64 = (long long)((Lmax + 63) / 64) * cot * B * S;
-  const int qb = (Lmax <= 32 || (blocks64 < 256 && getenv("SPARKMI_QB2") == nullptr)) ? 1 : 2;
+  const int qb = (Lmax <= 32 || (blocks64 < 256 && smi_env("SPARKMI_QB2") == nullptr)) ? 1 : 2;
   const int qt = qb * 32, nq = (Lmax + qt - 1) / qt;
   const long long blocks_cosplit = (long long)nq * ((cot + 3) / 4) * B * S;
   // (a partial last group of output tiles just idles its spare waves).  The choice depends on the call's shape

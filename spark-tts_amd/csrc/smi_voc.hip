@@ -364,7 +364,7 @@ int smi_voc_create(const smi_voc_cfg* cfg, const void* arena_dev, size_t arena_b
   h->lastB = h->lastT = 0; h->small = nullptr; h->lens_dev = nullptr; h->ev0 = h->ev1 = nullptr;
   for (int i = 0; i < 4; ++i) h->buf[i] = nullptr;
   for (int i = 0; i < 8; ++i) { h->dbg[i] = nullptr; h->dbg_floats[i] = 0; }
-  const char* dbg = getenv("SPARKMI_VOC_DEBUG");
+  const char* dbg = smi_env("SPARKMI_VOC_DEBUG");
   h->debug = dbg && dbg[0] == '1';
   // largest activation: channels x length over all stages
   size_t mx = (size_t)cfg->vq_input_dim * cfg->max_frames;
@@ -563,7 +563,7 @@ int smi_voc_forward(smi_voc* h, const int64_t* sem_dev, const int32_t* lens_host
                           wav_dev, nullptr, nullptr, nullptr, Lcur, Lcur, lens_at(c.dec_nblocks), B, Lcur, ACT_TANH));
     {   // C -> 1: a thread per output sample instead of a 32-row MFMA tile with one live row (SPARKMI_VOC_C1=0: the MFMA kernel)
       Launch& L = P.back();
-      const char* e = getenv("SPARKMI_VOC_C1");
+      const char* e = smi_env("SPARKMI_VOC_C1");
       const ConvP& q = L.cp;
       if (!(e && e[0] == '0') && !L.bf && q.Cout == 1 && q.S == 1 && q.istr == 1 && q.ntaps[0] == 7 && !q.X2 && !q.bbias && !q.gamma &&
           !q.beta && !q.R && !q.Ys && q.Y && q.out_scale == 1.0f && q.Cin * 7 * 4 <= 48 * 1024) {

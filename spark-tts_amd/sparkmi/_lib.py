@@ -1,6 +1,10 @@
-"""ctypes binding of ``libsparkmi.so`` (``include/sparkmi.h``).
+"""ctypes binding of ``libsparkmi.so`` (``include/sparkmi.h``) and of ``libsparkmi_diag.so`` (the same sources built with
+``-DSMI_DIAG``: ``include/sparkmi_debug.h``'s entry points, the SPARKMI_* A/B switches, the experimental one-row engine).
 
-The library is built in-tree by ``spark-tts_amd/csrc/Makefile`` (``__graft_entry__.build()``).
+``lib()`` is the product library: what ``SparkTTS`` / ``SparkLLM`` / ``BiCodecVocoder`` / ``BiCodecEncoder`` run on by default; it
+reads no environment variable.  ``diag()`` is the diagnostics build: ``SparkLLM(..., diag=True)`` (and the vocoder / encoder
+likewise) put a handle on it -- tools/, bench.py's per-kernel probes and the tests that look inside a step do.  A handle belongs
+to the library that created it.  Both are built in-tree by ``spark-tts_amd/csrc/Makefile`` (``__graft_entry__.build()``).
 There is no fallback: a missing library raises at first use.
 """
 from __future__ import annotations
@@ -14,7 +18,7 @@ LIB_PATH = Path(os.environ["SPARKMI_LIB"]) if os.environ.get("SPARKMI_LIB") else
 
 SMI_MAX_ROWS = 64
 SMI_MAX_EOS = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class SparkMIError(RuntimeError):
@@ -58,7 +62,14 @@ class EncCfg(C.Structure):
 
 # section ids of enum smi_llm_section
 (LLM_LN1, LLM_WQKV, LLM_BQKV, LLM_WO, LLM_LN2, LLM_WGU, LLM_WD,
- LLM_FINAL_NORM, LLM_LM_HEAD, LLM_ROPE) = range(10)
+ LLM_FINAL_NORM, LLM_LM_HEAD, LLM_ROPE, LLM_TAG) = range(11)
+
+
+class LLMArenaTag(C.Structure):
+    """smi_llm_arena_tag: how an arena was packed (section LLM_TAG); smi_llm_create checks it against the config."""
+    _fields_ = [("magic", C.c_char * 8)] + [(n, C.c_int32) for n in (
+        "abi_version", "wd_plain", "vocab_size", "hidden_size", "num_layers", "num_heads", "num_kv_heads", "intermediate_size",
+        "max_positions")] + [("reserved", C.c_int32 * 53)]
 
 # every symbol include/sparkmi.h declares: (name, restype, argtypes)
 _VP, _I, _SZ = C.c_void_p, C.c_int, C.c_size_t
@@ -86,14 +97,6 @@ SYMBOLS = {
     "smi_llm_forward_logits": (_I, [_VP, _P(C.c_int64), _I, _VP, _VP]),
     "smi_llm_steps": (_I, [_VP]),
     "smi_llm_kv_pages": (_I, [_VP, _P(C.c_int32), _P(C.c_int32)]),
-    "smi_llm_time_kernel": (_I, [_VP, _I, _I, _I, _P(C.c_float), _VP]),
-    "smi_llm_debug_stamps": (_I, [_VP, _I, _I, _P(C.c_double)]),
-    "smi_llm_engine": (_I, [_VP, _P(C.c_int32), _P(C.c_int32), C.c_char_p, _I]),
-    "smi_llm_set_engine": (_I, [_VP, _I]),
-    "smi_llm_engine_plan": (_I, [_P(LLMCfg), _I, _P(C.c_int32)]),
-    "smi_llm_engine_stamps": (_I, [_VP, _P(C.c_double), _I]),
-    "smi_llm_debug_hidden": (_I, [_VP, _P(C.c_float), _I]),
-    "smi_llm_debug_read": (_I, [_VP, _I, _VP, _SZ, _P(_SZ)]),
     "smi_voc_arena_count": (_I, [_P(VocCfg)]),
     "smi_voc_arena_entry": (_I, [_P(VocCfg), _I, C.c_char_p, _I, _P(_SZ), _P(_SZ), _P(C.c_int32)]),
     "smi_voc_arena_bytes": (_SZ, [_P(VocCfg)]),
@@ -118,37 +121,86 @@ SYMBOLS = {
     "smi_enc_time_launch": (_I, [_VP, _I, _I, _P(C.c_float), _P(C.c_double), C.c_char_p, _I, _VP]),
 }
 
+# include/sparkmi_debug.h: exported by libsparkmi_diag.so only
+DEBUG_SYMBOLS = {
+    "smi_llm_time_kernel": (_I, [_VP, _I, _I, _I, _P(C.c_float), _VP]),
+    "smi_llm_debug_stamps": (_I, [_VP, _I, _I, _P(C.c_double)]),
+    "smi_llm_engine": (_I, [_VP, _P(C.c_int32), _P(C.c_int32), C.c_char_p, _I]),
+    "smi_llm_set_engine": (_I, [_VP, _I]),
+    "smi_llm_engine_plan": (_I, [_P(LLMCfg), _I, _P(C.c_int32)]),
+    "smi_llm_engine_stamps": (_I, [_VP, _P(C.c_double), _I]),
+    "smi_llm_debug_hidden": (_I, [_VP, _P(C.c_float), _I]),
+    "smi_llm_debug_read": (_I, [_VP, _I, _VP, _SZ, _P(_SZ)]),
+    "smi_llm_debug_sample": (_I, [_VP, _P(C.c_float), _I, C.c_uint64, _I, _P(C.c_int32)]),
+}
+
+DIAG_PATH = LIB_PATH.with_name("libsparkmi_diag.so")
+
+
+class _Lib:
+    """A loaded library: attribute access goes to the CDLL (``l.smi_llm_decode(...)``); ``check`` raises with THIS library's
+    thread-local error text."""
+
+    def __init__(self, cdll: C.CDLL, path: Path, is_diag: bool):
+        self._cdll, self.path, self.is_diag = cdll, path, is_diag
+
+    def __getattr__(self, name):
+        return getattr(self._cdll, name)
+
+    def check(self, rc: int, what: str = "") -> None:
+        if rc != 0:
+            msg = self._cdll.smi_last_error().decode(errors="replace")
+            raise SparkMIError(f"{what or self.path.name} failed (code {rc}): {msg}")
+
+
+def _load(path: Path, symbols, is_diag: bool) -> _Lib:
+    if not path.exists():
+        raise SparkMIError(
+            f"{path} is missing: build it with `make -C spark-tts_amd/csrc` "
+            "(or __graft_entry__.build()). sparkmi has no CPU fallback.")
+    # libsparkmi needs libamdhip64; PyTorch-ROCm ships its own copy and must own the process's
+    # HIP runtime (streams and device memory are shared), so torch is loaded first and the
+    # library then binds to the runtime that is already resident.
+    import torch  # noqa: F401
+    l = C.CDLL(str(path))
+    for name, (res, args) in symbols.items():
+        if os.environ.get("SPARKMI_LIB") and not hasattr(l, name):
+            continue            # A/B runs against an older build (diagnostics only)
+        fn = getattr(l, name)   # AttributeError here = header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    if l.smi_version() != ABI_VERSION:
+        raise SparkMIError(f"{path.name} ABI version {l.smi_version()} != {ABI_VERSION}")
+    return _Lib(l, path, is_diag)
+
+
 _lib = None
+_diag = None
 
 
-def lib() -> C.CDLL:
-    """Load (once) and return the library; raises SparkMIError when it is not built."""
+def lib() -> _Lib:
+    """Load (once) and return the product library; raises SparkMIError when it is not built."""
     global _lib
     if _lib is None:
-        if not LIB_PATH.exists():
-            raise SparkMIError(
-                f"{LIB_PATH} is missing: build it with `make -C spark-tts_amd/csrc` "
-                "(or __graft_entry__.build()). sparkmi has no CPU fallback.")
-        # libsparkmi needs libamdhip64; PyTorch-ROCm ships its own copy and must own the process's
-        # HIP runtime (streams and device memory are shared), so torch is loaded first and the
-        # library then binds to the runtime that is already resident.
-        import torch  # noqa: F401
-        l = C.CDLL(str(LIB_PATH))
-        for name, (res, args) in SYMBOLS.items():
-            if os.environ.get("SPARKMI_LIB") and not hasattr(l, name):
-                continue            # A/B runs against an older build (diagnostics only)
-            fn = getattr(l, name)   # AttributeError here = header/library mismatch
-            fn.restype, fn.argtypes = res, args
-        if l.smi_version() != ABI_VERSION:
-            raise SparkMIError(f"libsparkmi ABI version {l.smi_version()} != {ABI_VERSION}")
-        _lib = l
+        _lib = _load(LIB_PATH, SYMBOLS, False)
     return _lib
 
 
-def check(rc: int, what: str = "") -> None:
-    if rc != 0:
-        msg = lib().smi_last_error().decode(errors="replace")
-        raise SparkMIError(f"{what or 'libsparkmi'} failed (code {rc}): {msg}")
+def diag() -> _Lib:
+    """Load (once) and return the diagnostics build (every product symbol + include/sparkmi_debug.h).  With SPARKMI_LIB set
+    (an A/B variant build: `make variant` compiles with -DSMI_DIAG) that library is the diagnostics library."""
+    global _diag
+    if _diag is None:
+        path = LIB_PATH if os.environ.get("SPARKMI_LIB") else DIAG_PATH
+        _diag = _load(path, {**SYMBOLS, **DEBUG_SYMBOLS}, True)
+    return _diag
+
+
+def pick(use_diag: bool) -> _Lib:
+    return diag() if use_diag else lib()
+
+
+def check(rc: int, what: str = "", l: "_Lib | None" = None) -> None:
+    (l or lib()).check(rc, what)
 
 
 def require_gfx950() -> str:

@@ -158,6 +158,12 @@ def pack_llm_arena(cfg: LLMConfig, weights: Mapping[str, np.ndarray], cs: _lib.L
         raise NotImplementedError("untied lm_head: the kernels gather embeddings from the lm_head tiles")
     put(_lib.LLM_LM_HEAD, 0, pack_tiles(f32(weights[head]), rep, head))
     put(_lib.LLM_ROPE, 0, rope_table(cfg, cs.max_positions))
+    # how this arena was packed travels WITH it: smi_llm_create compares the tag with the config it is handed (an arena packed
+    # under one SPARKMI_WD_PLAIN setting and re-used under another is an error, not wrong logits)
+    tag = _lib.LLMArenaTag(magic=b"SMIARENA", abi_version=_lib.ABI_VERSION, wd_plain=cs.wd_plain, vocab_size=cs.vocab_size,
+                           hidden_size=cs.hidden_size, num_layers=cs.num_layers, num_heads=cs.num_heads, num_kv_heads=cs.num_kv_heads,
+                           intermediate_size=cs.intermediate_size, max_positions=cs.max_positions)
+    put(_lib.LLM_TAG, 0, np.frombuffer(bytes(tag), dtype=np.uint8))
     if rep.inexact:
         msg = (f"{rep.inexact} LLM matrices are not bf16-representable (an fp32 checkpoint?): rounded to bf16 for the "
                f"weight arena, max |w - bf16(w)| / max|w| = {rep.max_rel:.2e} at {rep.worst}; outputs will differ from an "

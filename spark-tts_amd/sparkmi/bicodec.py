@@ -175,7 +175,8 @@ class BiCodecVocoder:
 
     def __init__(self, cfg: BiCodecConfig, state: Mapping[str, np.ndarray],
                  device: Union[str, torch.device] = "cuda:0", max_batch: int = 1, max_frames: int = 512,
-                 state_is_folded: bool = False, arena: Optional[torch.Tensor] = None, exact_fp32: Optional[bool] = None):
+                 state_is_folded: bool = False, arena: Optional[torch.Tensor] = None, exact_fp32: Optional[bool] = None,
+                 diag: bool = False):
         """``exact_fp32``: run every contraction on the exact-fp32 matrix pipe (verification mode); default (None ->
         SPARKMI_VOC_EXACT) is the bf16-split pipe, 5e-5 max-abs from it on the waveform.  An ``arena`` must have been
         packed for the same mode."""
@@ -183,7 +184,7 @@ class BiCodecVocoder:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.SparkMIError("BiCodecVocoder runs on an MI355X only (device must be cuda:N); there is no CPU path")
-        self._lib = _lib.lib()
+        self._lib = _lib.pick(diag)   # diag: libsparkmi_diag.so (SPARKMI_VOC_DEBUG stage dumps and the other switches live there)
         torch.cuda.set_device(self.device)
         _lib.require_gfx950()
         self.max_batch, self.max_frames = max_batch, max_frames
@@ -194,7 +195,7 @@ class BiCodecVocoder:
             arena = torch.from_numpy(pack_voc_arena(cfg, folded, self._cs)).to(self.device)
         self.arena = arena   # float32 device tensor; must outlive the handle
         self._h = C.c_void_p()
-        _lib.check(self._lib.smi_voc_create(C.byref(self._cs), C.c_void_p(self.arena.data_ptr()),
+        self._lib.check(self._lib.smi_voc_create(C.byref(self._cs), C.c_void_p(self.arena.data_ptr()),
                                             self.arena.numel() * 4, C.byref(self._h)), "smi_voc_create")
         self.hop = cfg.hop
 
@@ -227,7 +228,7 @@ class BiCodecVocoder:
             raise ValueError(f"expected {self.cfg.spk_token_num} global tokens per row, got {glob.shape[1]}")
         lens = np.full(B, T, np.int32) if lengths is None else np.asarray(lengths, np.int32)
         wav = torch.empty((B, 1, self.hop * T), dtype=torch.float32, device=self.device)
-        _lib.check(self._lib.smi_voc_forward(
+        self._lib.check(self._lib.smi_voc_forward(
             self._h, C.c_void_p(sem.data_ptr()), lens.ctypes.data_as(C.POINTER(C.c_int32)),
             C.c_void_p(glob.data_ptr()), B, T, C.c_void_p(wav.data_ptr()), self._stream()), "smi_voc_forward")
         self._keep = (sem, glob)   # inputs must stay alive until the stream has consumed them
@@ -240,12 +241,12 @@ class BiCodecVocoder:
         n = C.c_size_t()
         if stage == -1:
             out = torch.empty(batch * self.cfg.spk_out_dim, dtype=torch.float32, device=self.device)
-            _lib.check(self._lib.smi_voc_debug_stage(self._h, -1, C.c_void_p(out.data_ptr()), out.numel(),
+            self._lib.check(self._lib.smi_voc_debug_stage(self._h, -1, C.c_void_p(out.data_ptr()), out.numel(),
                                                      C.byref(n), self._stream()), "smi_voc_debug_stage")
             return out.view(batch, -1)
         big = self._dbg_floats() * batch
         out = torch.empty(big, dtype=torch.float32, device=self.device)
-        _lib.check(self._lib.smi_voc_debug_stage(self._h, stage, C.c_void_p(out.data_ptr()), big, C.byref(n),
+        self._lib.check(self._lib.smi_voc_debug_stage(self._h, stage, C.c_void_p(out.data_ptr()), big, C.byref(n),
                                                  self._stream()), "smi_voc_debug_stage")
         per = n.value // batch
         return out.view(batch, per)[:, : channels * length].reshape(batch, channels, length)
@@ -265,7 +266,7 @@ class BiCodecVocoder:
     def time_launch(self, index: int, iters: int = 10):
         ms, fl = C.c_float(0), C.c_double(0)
         name = C.create_string_buffer(256)
-        _lib.check(self._lib.smi_voc_time_launch(self._h, index, iters, C.byref(ms), C.byref(fl), name, 256,
+        self._lib.check(self._lib.smi_voc_time_launch(self._h, index, iters, C.byref(ms), C.byref(fl), name, 256,
                                                  self._stream()), "smi_voc_time_launch")
         return name.value.decode(), float(ms.value), float(fl.value)
 

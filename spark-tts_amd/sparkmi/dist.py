@@ -23,6 +23,24 @@ def arena_sizes(cs_llm, cs_voc) -> Tuple[int, int]:
     return int(l.smi_llm_arena_bytes(C.byref(cs_llm))), int(l.smi_voc_arena_bytes(C.byref(cs_voc))) // 4
 
 
+def physical_device_id(device: torch.device) -> Tuple[str, str]:
+    """(host name, physical id of the card): uuid where the runtime reports one, else the PCI bus id, else the visible
+    index qualified by HIP_VISIBLE_DEVICES -- equal on two ranks only when they really share a card."""
+    import os
+    import socket
+    host = socket.gethostname()
+    if device.type != "cuda":
+        return host, f"{device.type}:{os.getpid()}"
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    p = torch.cuda.get_device_properties(idx)
+    for attr in ("uuid", "pci_bus_id"):
+        v = getattr(p, attr, None)
+        if v is not None and str(v) not in ("", "0", "00000000-0000-0000-0000-000000000000"):
+            extra = f"{getattr(p, 'pci_domain_id', 0)}:{getattr(p, 'pci_device_id', 0)}" if attr == "pci_bus_id" else ""
+            return host, f"{attr}={v}{(':' + extra) if extra else ''}"
+    return host, f"visible={os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('ROCR_VISIBLE_DEVICES', '*'))}#{idx}"
+
+
 def preflight(device: torch.device, rank: int, world: int, expect_world: int) -> dict:
     """Fail loudly and early on a multi-GPU launch that is not what was asked for -- nobody can rehearse the 8-GPU run on a
     one-GPU lease, so everything that can be checked before the 1.4 GB broadcast is: the rank count, one distinct device per
@@ -43,11 +61,13 @@ def preflight(device: torch.device, rank: int, world: int, expect_world: int) ->
             info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:   # noqa: BLE001 -- the version is for the record only
             info["rccl_version"] = "unknown"
-    # one distinct device per rank (a launcher that maps two ranks to one card would halve the node silently)
-    mine = (device.type, device.index if device.index is not None else -1, torch.cuda.current_device() if device.type == "cuda" else -1)
+    # one distinct PHYSICAL device per rank (a launcher that maps two ranks to one card would halve the node silently).  The
+    # identity is (host name, the card's uuid / PCI bus id): device indices alone say nothing across nodes, nor under a
+    # launcher that gives every rank its own HIP_VISIBLE_DEVICES (each then sees its card as cuda:0)
+    mine = physical_device_id(device)
     everyone = [None] * world
     dist.all_gather_object(everyone, mine)
-    info["devices"] = [f"{t}:{i}" for t, i, _ in everyone]
+    info["devices"] = [f"{h}/{d}" for h, d in everyone]
     if device.type == "cuda" and dist.get_backend() == "nccl" and len(set(everyone)) != world:
         raise RuntimeError(f"preflight: ranks share devices: {everyone}")
     # a small broadcast before the big one: pattern checked on every rank, time recorded
@@ -70,32 +90,41 @@ def preflight(device: torch.device, rank: int, world: int, expect_world: int) ->
     return info
 
 
-def broadcast_arenas(llm_arena: Optional[torch.Tensor], voc_arena: Optional[torch.Tensor], sizes: Tuple[int, int],
-                     device: torch.device, rank: int, world: int):
-    """Rank 0 passes its arenas, the others pass None; returns (llm_arena, voc_arena, milliseconds)."""
+def broadcast_tensors(tensors: Sequence[Optional[torch.Tensor]], shapes: Sequence[Tuple[int, torch.dtype]],
+                      device: torch.device, rank: int, world: int):
+    """Rank 0 passes its flat arenas, the others pass None (they allocate [n] of the given dtype); returns (list, ms).
+    One broadcast per arena -- the only collective of the whole path."""
+    out = list(tensors)
     if rank != 0:
-        llm_arena = torch.empty(sizes[0], dtype=torch.uint8, device=device)
-        voc_arena = torch.empty(sizes[1], dtype=torch.float32, device=device)
+        out = [torch.empty(n, dtype=dt, device=device) for n, dt in shapes]
     if world == 1:
-        return llm_arena, voc_arena, 0.0
+        return out, 0.0
     if device.type == "cuda":
         torch.cuda.synchronize(device)
     dist.barrier()
     t0 = time.perf_counter()
     if dist.get_backend() == "gloo" and device.type == "cuda":
         # gloo rehearsal path: stage through host memory
-        for a in (llm_arena, voc_arena):
+        for a in out:
             h = a.cpu()
             dist.broadcast(h, src=0)
             if rank != 0:
                 a.copy_(h)
     else:
-        dist.broadcast(llm_arena, src=0)
-        dist.broadcast(voc_arena, src=0)
+        for a in out:
+            dist.broadcast(a, src=0)
     if device.type == "cuda":
         torch.cuda.synchronize(device)
     dist.barrier()
-    return llm_arena, voc_arena, (time.perf_counter() - t0) * 1e3
+    return out, (time.perf_counter() - t0) * 1e3
+
+
+def broadcast_arenas(llm_arena: Optional[torch.Tensor], voc_arena: Optional[torch.Tensor], sizes: Tuple[int, int],
+                     device: torch.device, rank: int, world: int):
+    """Rank 0 passes its arenas, the others pass None; returns (llm_arena, voc_arena, milliseconds)."""
+    (llm_arena, voc_arena), ms = broadcast_tensors([llm_arena, voc_arena], [(sizes[0], torch.uint8), (sizes[1], torch.float32)],
+                                                   device, rank, world)
+    return llm_arena, voc_arena, ms
 
 
 def shard_indices(lengths: Sequence[int], rank: int, world: int) -> List[int]:

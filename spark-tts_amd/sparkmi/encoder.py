@@ -206,12 +206,12 @@ class BiCodecEncoder:
     def __init__(self, wcfg: Wav2Vec2Cfg, tcfg: TokCfg, w2v_state: Optional[Mapping[str, np.ndarray]],
                  tok_state_folded: Optional[Mapping[str, np.ndarray]], device: Union[str, torch.device] = "cuda:0",
                  max_seconds: float = 30.0, ref_seconds: float = 6.0, arena: Optional[torch.Tensor] = None,
-                 exact_fp32: Optional[bool] = None):
+                 exact_fp32: Optional[bool] = None, diag: bool = False):
         self.wcfg, self.tcfg = wcfg, tcfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.SparkMIError("BiCodecEncoder runs on an MI355X only (device must be cuda:N); there is no CPU path")
-        self._lib = _lib.lib()
+        self._lib = _lib.pick(diag)
         torch.cuda.set_device(self.device)
         _lib.require_gfx950()
         self.max_samples = int(max_seconds * tcfg.sample_rate)
@@ -222,7 +222,7 @@ class BiCodecEncoder:
             arena = torch.from_numpy(pack_enc_arena(tcfg, w2v_state, tok_state_folded, self._cs)).to(self.device)
         self.arena = arena
         self._h = C.c_void_p()
-        _lib.check(self._lib.smi_enc_create(C.byref(self._cs), C.c_void_p(arena.data_ptr()), arena.numel() * 4,
+        self._lib.check(self._lib.smi_enc_create(C.byref(self._cs), C.c_void_p(arena.data_ptr()), arena.numel() * 4,
                                             C.byref(self._h)), "smi_enc_create")
 
     def close(self) -> None:
@@ -252,7 +252,7 @@ class BiCodecEncoder:
         sem = torch.empty((1, max(frames, 1)), dtype=torch.int64, device=self.device)
         glob = torch.empty((1, 1, self.tcfg.spk_token_num), dtype=torch.int32, device=self.device)
         n = C.c_int(0)
-        _lib.check(self._lib.smi_enc_forward(self._h, C.c_void_p(w.data_ptr()), w.numel(), C.c_void_p(r.data_ptr()), r.numel(),
+        self._lib.check(self._lib.smi_enc_forward(self._h, C.c_void_p(w.data_ptr()), w.numel(), C.c_void_p(r.data_ptr()), r.numel(),
                                              C.c_void_p(sem.data_ptr()), C.c_void_p(glob.data_ptr()), C.byref(n), self._stream()),
                    "smi_enc_forward")
         assert n.value == frames
@@ -295,7 +295,7 @@ class BiCodecEncoder:
     def debug_stage(self, name: str) -> torch.Tensor:
         out = torch.empty(64 * 1024 * 1024 // 4, dtype=torch.float32, device=self.device)
         dims = (C.c_int32 * 2)()
-        _lib.check(self._lib.smi_enc_debug_stage(self._h, name.encode(), C.c_void_p(out.data_ptr()), out.numel(), dims, self._stream()),
+        self._lib.check(self._lib.smi_enc_debug_stage(self._h, name.encode(), C.c_void_p(out.data_ptr()), out.numel(), dims, self._stream()),
                    "smi_enc_debug_stage")
         return out[: dims[0] * dims[1]].reshape(dims[0], dims[1]).clone()
 
@@ -305,6 +305,6 @@ class BiCodecEncoder:
     def time_launch(self, index: int, iters: int = 5):
         ms, fl = C.c_float(0), C.c_double(0)
         name = C.create_string_buffer(512)
-        _lib.check(self._lib.smi_enc_time_launch(self._h, index, iters, C.byref(ms), C.byref(fl), name, 512, self._stream()),
+        self._lib.check(self._lib.smi_enc_time_launch(self._h, index, iters, C.byref(ms), C.byref(fl), name, 512, self._stream()),
                    "smi_enc_time_launch")
         return name.value.decode(), float(ms.value), float(fl.value)

@@ -47,11 +47,13 @@ class SparkLLM:
                  device: Union[str, torch.device] = "cuda:0", max_slots: int = 1,
                  max_positions: int = 4096, kv_dtype: str = "bf16", use_graph: bool = True,
                  arena: Optional[torch.Tensor] = None, eos_token_ids: EosLike = None,
-                 kv_page_tokens: int = 0, kv_pages: int = 0):
+                 kv_page_tokens: int = 0, kv_pages: int = 0, diag: bool = False):
         """``eos_token_ids``: the model's default stop ids (``generation_config.json``; see
         ``eos_ids_from_generation_config``).  ``generate()`` falls back to them when the caller passes none, like HF.
         ``kv_page_tokens`` / ``kv_pages``: paged KV cache -- a pool of ``kv_pages`` pages of ``kv_page_tokens`` tokens
-        shared by the ``max_slots`` sequences instead of ``max_positions`` reserved tokens per slot (sparkmi.h)."""
+        shared by the ``max_slots`` sequences instead of ``max_positions`` reserved tokens per slot (sparkmi.h).
+        ``diag``: put the handle on ``libsparkmi_diag.so`` (timing probes, scratch dumps, SPARKMI_* switches, the one-row engine:
+        ``include/sparkmi_debug.h``) instead of the product library -- tools, bench probes and tests only."""
         cfg.validate()
         self.cfg = cfg
         if eos_token_ids is None and cfg.eos_token_id is not None:
@@ -60,7 +62,7 @@ class SparkLLM:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.SparkMIError("SparkLLM runs on an MI355X only (device must be cuda:N); there is no CPU path")
-        self._lib = _lib.lib()
+        self._lib = _lib.pick(diag)
         torch.cuda.set_device(self.device)
         _lib.require_gfx950()
         self.max_slots, self.max_positions = max_slots, max_positions
@@ -68,9 +70,19 @@ class SparkLLM:
         if arena is None:
             host = pack_llm_arena(cfg, weights, self._cs)
             arena = torch.from_numpy(host).to(self.device)
+        else:
+            # a packed arena says how it was packed (section LLM_TAG): its W_down tile order wins over what the environment
+            # would choose now; any other disagreement with the config is refused by smi_llm_create
+            off, nb = C.c_size_t(), C.c_size_t()
+            self._lib.check(self._lib.smi_llm_arena_section(C.byref(self._cs), _lib.LLM_TAG, 0, C.byref(off), C.byref(nb)),
+                            "smi_llm_arena_section")
+            if arena.numel() >= off.value + nb.value:
+                tag = _lib.LLMArenaTag.from_buffer_copy(arena[off.value: off.value + nb.value].cpu().numpy().tobytes())
+                if tag.magic == b"SMIARENA":
+                    self._cs.wd_plain = tag.wd_plain
         self.arena = arena  # uint8 device tensor; must outlive the handle
         self._h = C.c_void_p()
-        _lib.check(self._lib.smi_llm_create(C.byref(self._cs), C.c_void_p(arena.data_ptr()),
+        self._lib.check(self._lib.smi_llm_create(C.byref(self._cs), C.c_void_p(arena.data_ptr()),
                                             arena.numel(), C.byref(self._h)), "smi_llm_create")
 
     # ------------------------------------------------------------------ plumbing
@@ -121,23 +133,23 @@ class SparkLLM:
         for b, p in enumerate(prompts):
             ids[b, : len(p)] = np.asarray(p, dtype=np.int64)
         eos_arr, n_eos = self._eos_args(eos_token_id)
-        _lib.check(self._lib.smi_llm_prefill(
+        self._lib.check(self._lib.smi_llm_prefill(
             self._h, ids.ctypes.data_as(C.POINTER(C.c_int64)), lens.ctypes.data_as(C.POINTER(C.c_int32)),
             B, pmax, eos_arr, n_eos, self._stream()), "smi_llm_prefill")
         self._B, self._lens = B, lens
 
     def decode(self, n_steps: int) -> None:
-        _lib.check(self._lib.smi_llm_decode(self._h, int(n_steps), self._stream()), "smi_llm_decode")
+        self._lib.check(self._lib.smi_llm_decode(self._h, int(n_steps), self._stream()), "smi_llm_decode")
 
     def all_done(self) -> bool:
         d = C.c_int(0)
-        _lib.check(self._lib.smi_llm_all_done(self._h, C.byref(d), self._stream()), "smi_llm_all_done")
+        self._lib.check(self._lib.smi_llm_all_done(self._h, C.byref(d), self._stream()), "smi_llm_all_done")
         return bool(d.value)
 
     def tokens(self, cap: int) -> List[List[int]]:
         out = np.zeros((self._B, cap), dtype=np.int64)
         lens = np.zeros(self._B, dtype=np.int32)
-        _lib.check(self._lib.smi_llm_get_tokens(
+        self._lib.check(self._lib.smi_llm_get_tokens(
             self._h, out.ctypes.data_as(C.POINTER(C.c_int64)), lens.ctypes.data_as(C.POINTER(C.c_int32)),
             cap, self._stream()), "smi_llm_get_tokens")
         return [out[b, : lens[b]].tolist() for b in range(self._B)]
@@ -146,7 +158,7 @@ class SparkLLM:
                      seed: Optional[int] = None) -> None:
         if seed is None:
             seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0]) if do_sample else 0
-        _lib.check(self._lib.smi_llm_set_sampling(self._h, int(bool(do_sample)), float(temperature), int(top_k),
+        self._lib.check(self._lib.smi_llm_set_sampling(self._h, int(bool(do_sample)), float(temperature), int(top_k),
                                                   float(top_p), int(seed) & (2 ** 64 - 1)), "smi_llm_set_sampling")
 
     def generate_ids(self, prompts: Sequence[Sequence[int]], max_new_tokens: int,
@@ -210,7 +222,7 @@ class SparkLLM:
     def session_begin(self, eos_token_id: EosLike = None) -> None:
         """Empty in-flight-batching session: sequences are admitted and retired between decode steps."""
         eos_arr, n_eos = self._eos_args(eos_token_id)
-        _lib.check(self._lib.smi_llm_session_begin(self._h, eos_arr, n_eos, self._stream()), "smi_llm_session_begin")
+        self._lib.check(self._lib.smi_llm_session_begin(self._h, eos_arr, n_eos, self._stream()), "smi_llm_session_begin")
 
     def admit(self, prompts: Sequence[Sequence[int]]) -> List[int]:
         """Prefill new prompts into free KV slots (first token emitted); returns their slot ids."""
@@ -221,17 +233,17 @@ class SparkLLM:
         for b, p in enumerate(prompts):
             ids[b, : len(p)] = np.asarray(p, dtype=np.int64)
         slots = np.zeros(n, dtype=np.int32)
-        _lib.check(self._lib.smi_llm_admit(self._h, ids.ctypes.data_as(C.POINTER(C.c_int64)), lens.ctypes.data_as(C.POINTER(C.c_int32)),
+        self._lib.check(self._lib.smi_llm_admit(self._h, ids.ctypes.data_as(C.POINTER(C.c_int64)), lens.ctypes.data_as(C.POINTER(C.c_int32)),
                                            n, pmax, slots.ctypes.data_as(C.POINTER(C.c_int32)), self._stream()), "smi_llm_admit")
         return slots.tolist()
 
     def retire(self, slot: int) -> None:
-        _lib.check(self._lib.smi_llm_retire(self._h, int(slot), self._stream()), "smi_llm_retire")
+        self._lib.check(self._lib.smi_llm_retire(self._h, int(slot), self._stream()), "smi_llm_retire")
 
     def retire_many(self, slots: Sequence[int]) -> None:
         """Several sequences leave at once; no host round trip (the device row list is compacted in place)."""
         arr = np.asarray(list(slots), dtype=np.int32)
-        _lib.check(self._lib.smi_llm_retire_many(self._h, arr.ctypes.data_as(C.POINTER(C.c_int32)), len(arr), self._stream()),
+        self._lib.check(self._lib.smi_llm_retire_many(self._h, arr.ctypes.data_as(C.POINTER(C.c_int32)), len(arr), self._stream()),
                    "smi_llm_retire_many")
 
     def slots_tokens(self, slots: Sequence[int], cap: int):
@@ -240,7 +252,7 @@ class SparkLLM:
         out = np.zeros((len(arr), max(cap, 1)), dtype=np.int64)
         n = np.zeros(len(arr), dtype=np.int32)
         fin = np.zeros(len(arr), dtype=np.int32)
-        _lib.check(self._lib.smi_llm_slots_tokens(self._h, arr.ctypes.data_as(C.POINTER(C.c_int32)), len(arr),
+        self._lib.check(self._lib.smi_llm_slots_tokens(self._h, arr.ctypes.data_as(C.POINTER(C.c_int32)), len(arr),
                                                   out.ctypes.data_as(C.POINTER(C.c_int64)), max(cap, 1), n.ctypes.data_as(C.POINTER(C.c_int32)),
                                                   fin.ctypes.data_as(C.POINTER(C.c_int32)), self._stream()), "smi_llm_slots_tokens")
         return [(out[i, : n[i]].tolist(), bool(fin[i])) for i in range(len(arr))]
@@ -249,21 +261,21 @@ class SparkLLM:
         """(tokens emitted so far by the sequence in ``slot``, finished flag)."""
         out = np.zeros(max(cap, 1), dtype=np.int64)
         n, fin = C.c_int32(0), C.c_int32(0)
-        _lib.check(self._lib.smi_llm_slot_tokens(self._h, int(slot), out.ctypes.data_as(C.POINTER(C.c_int64)), cap, C.byref(n),
+        self._lib.check(self._lib.smi_llm_slot_tokens(self._h, int(slot), out.ctypes.data_as(C.POINTER(C.c_int64)), cap, C.byref(n),
                                                  C.byref(fin), self._stream()), "smi_llm_slot_tokens")
         return out[: n.value].tolist(), bool(fin.value)
 
     def kv_pages(self):
         """(pages in the pool, pages free) of a paged KV cache; (0, 0) when the cache is not paged."""
         tot, free = C.c_int32(0), C.c_int32(0)
-        _lib.check(self._lib.smi_llm_kv_pages(self._h, C.byref(tot), C.byref(free)), "smi_llm_kv_pages")
+        self._lib.check(self._lib.smi_llm_kv_pages(self._h, C.byref(tot), C.byref(free)), "smi_llm_kv_pages")
         return tot.value, free.value
 
     def status(self):
         """(tokens emitted, finished flag) per KV slot, as two int32 arrays of SMI_MAX_ROWS -- one device round trip."""
         cnt = np.zeros(_lib.SMI_MAX_ROWS, dtype=np.int32)
         fin = np.zeros(_lib.SMI_MAX_ROWS, dtype=np.int32)
-        _lib.check(self._lib.smi_llm_status(self._h, cnt.ctypes.data_as(C.POINTER(C.c_int32)), fin.ctypes.data_as(C.POINTER(C.c_int32)),
+        self._lib.check(self._lib.smi_llm_status(self._h, cnt.ctypes.data_as(C.POINTER(C.c_int32)), fin.ctypes.data_as(C.POINTER(C.c_int32)),
                                             self._stream()), "smi_llm_status")
         return cnt, fin
 
@@ -344,45 +356,69 @@ class SparkLLM:
         """Teacher-forced logits (S, V) for one sequence fed at positions 0..S-1."""
         a = np.asarray(ids, dtype=np.int64)
         out = torch.empty((a.shape[0], self.cfg.vocab_size), dtype=torch.float32, device=self.device)
-        _lib.check(self._lib.smi_llm_forward_logits(
+        self._lib.check(self._lib.smi_llm_forward_logits(
             self._h, a.ctypes.data_as(C.POINTER(C.c_int64)), a.shape[0], C.c_void_p(out.data_ptr()),
             self._stream()), "smi_llm_forward_logits")
         return out
 
-    # ------------------------------------------------------------------ one-row decode engine (csrc/smi_eng.h)
+    # ------------------------------------------------------------------ diagnostics (include/sparkmi_debug.h; diag=True handles)
+    def _need_diag(self, what: str) -> None:
+        if not self._lib.is_diag:
+            raise _lib.SparkMIError(f"SparkLLM.{what} is a diagnostics entry (include/sparkmi_debug.h): construct the engine with "
+                                    "diag=True (libsparkmi_diag.so); the product library does not export it")
+
     def engine_info(self) -> dict:
         """Whether one-row decode steps run as one persistent launch, and why / why not."""
+        self._need_diag("engine_info")
         on = C.c_int32(0)
         info = (C.c_int32 * 4)()
         why = C.create_string_buffer(200)
-        _lib.check(self._lib.smi_llm_engine(self._h, C.byref(on), info, why, 200), "smi_llm_engine")
+        self._lib.check(self._lib.smi_llm_engine(self._h, C.byref(on), info, why, 200), "smi_llm_engine")
         return {"enabled": bool(on.value), "built": bool(info[3]), "cus": int(info[0]), "images_per_wave": int(info[1]),
                 "lds_bytes": int(info[2]), "why": why.value.decode(errors="replace")}
 
     def set_engine(self, on: bool) -> None:
         """Runtime switch between the engine and the four-launches-per-layer path (same bits; A/B runs and tests)."""
-        _lib.check(self._lib.smi_llm_set_engine(self._h, 1 if on else 0), "smi_llm_set_engine")
+        self._need_diag("set_engine")
+        self._lib.check(self._lib.smi_llm_set_engine(self._h, 1 if on else 0), "smi_llm_set_engine")
 
     def engine_stamps(self) -> np.ndarray:
         """(3, layers, 16) microseconds of the last engine launch (needs SPARKMI_ENGINE_STAMPS=1 in the environment)."""
+        self._need_diag("engine_stamps")
         n = 3 * self.cfg.num_hidden_layers * 16
         out = (C.c_double * n)()
-        _lib.check(self._lib.smi_llm_engine_stamps(self._h, out, n), "smi_llm_engine_stamps")
+        self._lib.check(self._lib.smi_llm_engine_stamps(self._h, out, n), "smi_llm_engine_stamps")
         return np.array(out, dtype=np.float64).reshape(3, self.cfg.num_hidden_layers, 16)
 
     def debug_hidden(self) -> np.ndarray:
         """The residual row of row 0 as the last step left it (tests)."""
+        self._need_diag("debug_hidden")
         out = np.zeros(self.cfg.hidden_size, dtype=np.float32)
-        _lib.check(self._lib.smi_llm_debug_hidden(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), out.size), "smi_llm_debug_hidden")
+        self._lib.check(self._lib.smi_llm_debug_hidden(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), out.size), "smi_llm_debug_hidden")
         return out
 
     def debug_read(self, what: int) -> np.ndarray:
-        """Raw bytes of one scratch buffer (include/sparkmi.h: smi_llm_debug_read)."""
+        """Raw bytes of one scratch buffer (include/sparkmi_debug.h: smi_llm_debug_read)."""
+        self._need_diag("debug_read")
         buf = np.zeros(1 << 22, dtype=np.uint8)
         got = C.c_size_t(0)
-        _lib.check(self._lib.smi_llm_debug_read(self._h, int(what), buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(got)),
+        self._lib.check(self._lib.smi_llm_debug_read(self._h, int(what), buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(got)),
                    "smi_llm_debug_read")
         return buf[: got.value].copy()
+
+    def debug_sample(self, logits_row: Optional[np.ndarray], n_rows: int, seed: int, use_bound: bool = True) -> np.ndarray:
+        """The device sampler alone on a caller's logits row (``smi_llm_debug_sample``): ``n_rows`` independent draws with
+        the parameters of the last ``set_sampling``; ``logits_row`` None keeps the previous call's row."""
+        self._need_diag("debug_sample")
+        out = np.zeros(n_rows, dtype=np.int32)
+        ptr = None
+        if logits_row is not None:
+            row = np.ascontiguousarray(logits_row, dtype=np.float32)
+            assert row.shape == (self.cfg.vocab_size,)
+            ptr = row.ctypes.data_as(C.POINTER(C.c_float))
+        self._lib.check(self._lib.smi_llm_debug_sample(self._h, ptr, int(n_rows), C.c_uint64(int(seed)), 1 if use_bound else 0,
+                                                       out.ctypes.data_as(C.POINTER(C.c_int32))), "smi_llm_debug_sample")
+        return out
 
     KERNELS = ("qkv", "attn", "o_proj", "gate_up", "down", "lm_head", "finalize", "step", "layers")
 
@@ -390,8 +426,9 @@ class SparkLLM:
         """Average milliseconds per launch of one decode-step kernel (HIP events on this stream).
         ``in_sequence`` times a layer kernel where it runs -- after its producers, which prefetch
         part of its weights into L2 -- as (iters layers) - (the same layers without it)."""
+        self._need_diag("time_kernel")
         ms = C.c_float(0)
-        _lib.check(self._lib.smi_llm_time_kernel(self._h, self.KERNELS.index(name) + (16 if in_sequence else 0), layer, iters,
+        self._lib.check(self._lib.smi_llm_time_kernel(self._h, self.KERNELS.index(name) + (16 if in_sequence else 0), layer, iters,
                                                  C.byref(ms), self._stream()), "smi_llm_time_kernel")
         return float(ms.value)
 

@@ -1,4 +1,5 @@
-"""libsparkmi.so loads and exports every symbol include/sparkmi.h declares (no compute calls)."""
+"""libsparkmi.so loads and exports every symbol include/sparkmi.h declares -- and nothing else; libsparkmi_diag.so exports those
+plus include/sparkmi_debug.h's (no compute calls)."""
 import ctypes
 import os
 import re
@@ -11,8 +12,8 @@ from sparkmi import _lib, arena, config as C, weights as W
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_symbols():
-    txt = open(os.path.join(ROOT, "include", "sparkmi.h")).read()
+def _header_symbols(name="sparkmi.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(smi_[a-z0-9_]+)\s*\(", txt)))
 
@@ -28,7 +29,28 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(l, n), f"{n} declared in sparkmi.h but not exported"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes signature in sparkmi/_lib.py"
-    assert l.smi_version() == _lib.ABI_VERSION == 3
+    assert l.smi_version() == _lib.ABI_VERSION == 4
+
+
+def test_diagnostics_live_in_their_own_library():
+    """include/sparkmi_debug.h (timing probes, stamps, scratch dumps, the one-row engine) is exported by libsparkmi_diag.so only."""
+    dbg = _header_symbols("sparkmi_debug.h")
+    assert "smi_llm_time_kernel" in dbg and "smi_llm_debug_read" in dbg and not set(dbg) & set(_header_symbols())
+    d = _lib.diag()
+    for n in dbg + _header_symbols():
+        assert hasattr(d, n), f"{n} missing from libsparkmi_diag.so"
+    for n in dbg:
+        assert n in _lib.DEBUG_SYMBOLS, f"{n} has no ctypes signature in sparkmi/_lib.py"
+        assert not hasattr(_lib.lib()._cdll, n), f"{n} leaked into the product library"
+    assert d.smi_version() == _lib.ABI_VERSION and d.is_diag and not _lib.lib().is_diag
+
+
+def test_product_library_reads_no_environment():
+    """The product build compiles smi_env() to nullptr: no getenv in its import table (the diagnostics build has it)."""
+    import subprocess
+    und = lambda p: subprocess.run(["nm", "-D", "--undefined-only", str(p)], capture_output=True, text=True, check=True).stdout  # noqa: E731
+    assert "getenv" not in und(_lib.LIB_PATH)
+    assert "getenv" in und(_lib.DIAG_PATH)
 
 
 def test_product_library_exports_only_the_declared_abi():
@@ -52,7 +74,7 @@ def test_llm_arena_layout_is_consistent():
             off, nb = ctypes.c_size_t(), ctypes.c_size_t()
             assert l.smi_llm_arena_section(ctypes.byref(cs), s, layer, ctypes.byref(off), ctypes.byref(nb)) == 0
             spans.append((off.value, nb.value))
-    for s in (_lib.LLM_FINAL_NORM, _lib.LLM_LM_HEAD, _lib.LLM_ROPE):
+    for s in (_lib.LLM_FINAL_NORM, _lib.LLM_LM_HEAD, _lib.LLM_ROPE, _lib.LLM_TAG):
         off, nb = ctypes.c_size_t(), ctypes.c_size_t()
         assert l.smi_llm_arena_section(ctypes.byref(cs), s, 0, ctypes.byref(off), ctypes.byref(nb)) == 0
         spans.append((off.value, nb.value))
@@ -100,6 +122,12 @@ def test_arena_packs_full_tiny_model():
     cs = arena.llm_cfg_struct(cfg, 2, 96, "bf16", False)
     a = arena.pack_llm_arena(cfg, W.SyntheticLLM(cfg), cs)
     assert a.dtype == np.uint8 and a.size == _lib.lib().smi_llm_arena_bytes(ctypes.byref(cs))
+    # the arena says how it was packed (smi_llm_arena_tag): smi_llm_create checks it against the config
+    off, nb = ctypes.c_size_t(), ctypes.c_size_t()
+    assert _lib.lib().smi_llm_arena_section(ctypes.byref(cs), _lib.LLM_TAG, 0, ctypes.byref(off), ctypes.byref(nb)) == 0
+    tag = _lib.LLMArenaTag.from_buffer_copy(a[off.value: off.value + nb.value].tobytes())
+    assert nb.value == 256 and tag.magic == b"SMIARENA" and tag.abi_version == _lib.ABI_VERSION
+    assert (tag.wd_plain, tag.hidden_size, tag.num_layers, tag.max_positions) == (cs.wd_plain, cfg.hidden_size, cfg.num_hidden_layers, 96)
 
 
 def test_no_cpu_fallback():

@@ -20,13 +20,13 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.join(os.environ["SMI_ROOT"], "spark-tts_amd"))
 from sparkmi import _lib, config as Cf
 from sparkmi.arena import llm_cfg_struct
-l = _lib.lib()                                   # SPARKMI_LIB points at the ASAN build
+l = _lib.diag()                                  # SPARKMI_LIB points at the ASAN build (compiled -DSMI_DIAG: the engine's plan builder is in it)
 assert l.smi_version() == _lib.ABI_VERSION
 for cfg in (Cf.tiny_llm(), Cf.spark_0p5b_llm()):
     cs = llm_cfg_struct(cfg, 4, 512, "bf16", True)
     assert l.smi_llm_arena_bytes(C.byref(cs)) > 0
     off, n = C.c_size_t(), C.c_size_t()
-    for sec in range(10):
+    for sec in range(11):
         for layer in ((0,) if sec >= 7 else range(cfg.num_hidden_layers)):
             assert l.smi_llm_arena_section(C.byref(cs), sec, layer, C.byref(off), C.byref(n)) == 0
     assert l.smi_llm_arena_section(C.byref(cs), 99, 0, C.byref(off), C.byref(n)) != 0      # error path + message

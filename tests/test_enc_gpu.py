@@ -22,6 +22,7 @@ def _build(wcfg, tcfg, vcfg, **kw):
     from sparkmi.encoder import BiCodecEncoder
     wsd = W.wav2vec2_state(wcfg)
     tsd = W.fold_weight_norm(W.bicodec_tok_state(tcfg, vcfg.vq_input_dim))
+    kw.setdefault("diag", any(k.startswith("SPARKMI_") for k in os.environ))   # SPARKMI_* switches exist in the diagnostics build only
     enc = BiCodecEncoder(wcfg, tcfg, W.fold_pos_conv_weight_norm(wsd), tsd, "cuda:0", **kw)
     return enc, wsd, tsd
 

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 def _llm(cfg, syn, **kw):
     from sparkmi.llm import SparkLLM
-    return SparkLLM(cfg, syn, device="cuda:0", **kw)
+    return SparkLLM(cfg, syn, device="cuda:0", diag=True, **kw)   # the engine and the residual-row dump: include/sparkmi_debug.h
 
 
 @pytest.fixture(scope="module")

@@ -13,8 +13,8 @@ from sparkmi.arena import llm_cfg_struct
 def _plan(cfg, ncu):
     cs = llm_cfg_struct(cfg, 1, 512, "bf16", True)
     st = (C.c_int32 * 8)()
-    rc = _lib.lib().smi_llm_engine_plan(C.byref(cs), ncu, st)
-    return rc, list(st), _lib.lib().smi_last_error().decode()
+    rc = _lib.diag().smi_llm_engine_plan(C.byref(cs), ncu, st)      # include/sparkmi_debug.h: the diagnostics build
+    return rc, list(st), _lib.diag().smi_last_error().decode()
 
 
 def _images_per_layer(cfg):

@@ -19,6 +19,7 @@ WAV_ATOL = 1e-4
 
 def _voc(cfg, sd, **kw):
     from sparkmi.bicodec import BiCodecVocoder
+    kw.setdefault("diag", any(k.startswith("SPARKMI_") for k in os.environ))   # SPARKMI_* switches exist in the diagnostics build only
     return BiCodecVocoder(cfg, sd, device="cuda:0", **kw)
 
 

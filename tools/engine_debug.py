@@ -13,7 +13,7 @@ from sparkmi.llm import SparkLLM
 layers = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 cfg = C.tiny_llm(layers=layers)
 syn = W.SyntheticLLM(cfg)
-llm = SparkLLM(cfg, syn, "cuda:0", max_positions=320, use_graph=False)
+llm = SparkLLM(cfg, syn, "cuda:0", max_positions=320, use_graph=False, diag=True)
 llm.set_engine(True)
 print(llm.engine_info())
 H, Q, KV, I = cfg.hidden_size, cfg.q_dim, cfg.kv_dim, cfg.intermediate_size

@@ -23,7 +23,7 @@ prompt = np.random.Generator(np.random.PCG64(1234)).integers(0, cfg.vocab_size, 
 for knob in sys.argv[1:]:
     b, z, q = (knob.split(",") + ["1"])[:3]
     os.environ["SPARKMI_ENGINE_BURST"], os.environ["SPARKMI_ENGINE_SLEEP"], os.environ["SPARKMI_ENGINE_POLL"] = b, z, q
-    v = SparkLLM(cfg, None, "cuda:0", max_positions=MAXPOS, arena=arena)
+    v = SparkLLM(cfg, None, "cuda:0", max_positions=MAXPOS, arena=arena, diag=True)
     v.set_engine(True)
     v.prefill([prompt]); v.decode(20)
     lay = v.time_kernel("layers", iters=32) * 1e3
@@ -31,7 +31,7 @@ for knob in sys.argv[1:]:
     v.close()
 for k in ("SPARKMI_ENGINE_BURST", "SPARKMI_ENGINE_SLEEP", "SPARKMI_ENGINE_POLL"):
     os.environ.pop(k, None)
-llm = SparkLLM(cfg, None, "cuda:0", max_positions=MAXPOS, arena=arena)
+llm = SparkLLM(cfg, None, "cuda:0", max_positions=MAXPOS, arena=arena, diag=True)
 llm.set_engine(True)
 print("engine:", llm.engine_info(), flush=True)
 res = {}

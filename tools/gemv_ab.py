@@ -50,7 +50,7 @@ for shape, (name, N, K, parts) in enumerate([("down_proj 896 x 4864", 896, 4864,
 
 from sparkmi.llm import SparkLLM
 cfg = Cf.spark_0p5b_llm()
-llm = SparkLLM(cfg, W.SyntheticLLM(cfg), "cuda:0", max_positions=512)
+llm = SparkLLM(cfg, W.SyntheticLLM(cfg), "cuda:0", max_positions=512, diag=True)
 llm.prefill([rng.integers(0, cfg.vocab_size, size=128).tolist()]); llm.decode(8); torch.cuda.synchronize()
 for k in ("down", "qkv"):
     print(f"product {k:5s} kernel, same kind of probe (eager back to back, walking the 24 layers): {llm.time_kernel(k, iters=480) * 1e3:.2f} us/launch")

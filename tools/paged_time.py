@@ -15,7 +15,7 @@ for B in (1, 8, 32):
     prompts = [np.random.Generator(np.random.PCG64(1 + b)).integers(0, cfg.vocab_size, size=128).tolist() for b in range(B)]
     row = []
     for name, kw in (("contiguous", {}), ("paged, 64-token pages", dict(kv_page_tokens=64, kv_pages=B * 8 + 8))):
-        llm = SparkLLM(cfg, syn if arena is None else None, "cuda:0", max_slots=B, max_positions=512, arena=arena, **kw)
+        llm = SparkLLM(cfg, syn if arena is None else None, "cuda:0", max_slots=B, max_positions=512, arena=arena, **kw, diag=True)
         arena = llm.arena
         llm.prefill(prompts); llm.decode(8); torch.cuda.synchronize()
         us = min(llm.time_kernel("step", iters=100) for _ in range(3)) * 1e3

@@ -14,7 +14,7 @@ res = []
 llm = None
 for B, P in ((32, 128), (64, 128), (8, 400)):
     del llm
-    llm = SparkLLM(cfg, W.SyntheticLLM(cfg), "cuda:0", max_slots=B, max_positions=512)
+    llm = SparkLLM(cfg, W.SyntheticLLM(cfg), "cuda:0", max_slots=B, max_positions=512, diag=True)
     prompts = [np.random.Generator(np.random.PCG64(1 + b)).integers(0, cfg.vocab_size, size=P).tolist() for b in range(B)]
     ts = []
     for it in range(5):

@@ -14,7 +14,7 @@ import numpy as np, torch
 from sparkmi import config as Cf, weights as W
 from sparkmi.llm import SparkLLM
 cfg = Cf.spark_0p5b_llm()
-llm = SparkLLM(cfg, W.SyntheticLLM(cfg), "cuda:0", max_positions=512)
+llm = SparkLLM(cfg, W.SyntheticLLM(cfg), "cuda:0", max_positions=512, diag=True)
 llm.prefill([np.random.Generator(np.random.PCG64(1)).integers(0, cfg.vocab_size, size=128).tolist()]); llm.decode(20); torch.cuda.synchronize()
 f = llm._lib.smi_llm_debug_stamps
 f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]

@@ -15,7 +15,7 @@ arena = torch.from_numpy(pack_llm_arena(cfg, W.SyntheticLLM(cfg), llm_cfg_struct
 res = []
 sizes = [tuple(int(v) for v in x.split("x")) for x in os.environ.get("PF_SIZES", "1x128,1x64,1x400,4x128,8x128,16x128,32x128").split(",")]
 for B, P in sizes:
-    llm = SparkLLM(cfg, None, "cuda:0", max_slots=B, max_positions=1024, arena=arena)
+    llm = SparkLLM(cfg, None, "cuda:0", max_slots=B, max_positions=1024, arena=arena, diag=True)
     prompts = [np.random.Generator(np.random.PCG64(1 + b)).integers(0, cfg.vocab_size, size=P).tolist() for b in range(B)]
     ts = []
     for it in range(4):

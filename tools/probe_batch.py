@@ -10,7 +10,7 @@ from sparkmi.arena import llm_cfg_struct, pack_llm_arena
 cfg = Cf.spark_0p5b_llm()
 arena = torch.from_numpy(pack_llm_arena(cfg, W.SyntheticLLM(cfg), llm_cfg_struct(cfg, 1, 512, "bf16", True))).to("cuda:0")
 for B in [int(a) for a in sys.argv[1:]] or [1, 8, 32]:
-    llm = SparkLLM(cfg, None, "cuda:0", max_slots=B, max_positions=512, arena=arena)
+    llm = SparkLLM(cfg, None, "cuda:0", max_slots=B, max_positions=512, arena=arena, diag=True)
     rng = np.random.Generator(np.random.PCG64(1))
     prompts = [rng.integers(0, cfg.vocab_size, size=128).tolist() for _ in range(B)]
     torch.cuda.synchronize(); import time; t0 = time.perf_counter()

@@ -8,7 +8,7 @@ from sparkmi import config as Cf, weights as W
 from sparkmi.llm import SparkLLM
 cfg = Cf.spark_0p5b_llm()
 for B in (1, 8):
-    llm = SparkLLM(cfg, W.SyntheticLLM(cfg), "cuda:0", max_slots=B, max_positions=512)
+    llm = SparkLLM(cfg, W.SyntheticLLM(cfg), "cuda:0", max_slots=B, max_positions=512, diag=True)
     prompts = [np.random.Generator(np.random.PCG64(1 + b)).integers(0, cfg.vocab_size, size=128).tolist() for b in range(B)]
     for mode in (False, True):
         ts = []

@@ -8,7 +8,7 @@ import torch
 from sparkmi import config as Cf, weights as W
 from sparkmi.llm import SparkLLM
 cfg = Cf.spark_0p5b_llm()
-llm = SparkLLM(cfg, W.SyntheticLLM(cfg), "cuda:0", max_positions=512)
+llm = SparkLLM(cfg, W.SyntheticLLM(cfg), "cuda:0", max_positions=512, diag=True)
 prompt = np.random.Generator(np.random.PCG64(1)).integers(0, cfg.vocab_size, size=128).tolist()
 llm.prefill([prompt]); llm.decode(40); torch.cuda.synchronize()
 f = llm._lib.smi_llm_debug_stamps

@@ -13,7 +13,7 @@ from sparkmi.llm import SparkLLM
 cfg = Cf.spark_0p5b_llm()
 names = {0: "entry", 1: "prologue", 4: "mfma", 5: "reduce-barrier", 6: "epilogue"}
 for B in [int(a) for a in sys.argv[1:]] or [32]:
-    llm = SparkLLM(cfg, W.SyntheticLLM(cfg), "cuda:0", max_slots=B, max_positions=512)
+    llm = SparkLLM(cfg, W.SyntheticLLM(cfg), "cuda:0", max_slots=B, max_positions=512, diag=True)
     rng = np.random.Generator(np.random.PCG64(1))
     prompts = [rng.integers(0, cfg.vocab_size, size=128).tolist() for _ in range(B)]
     llm.prefill(prompts); llm.decode(20); torch.cuda.synchronize()
