@@ -83,6 +83,13 @@ typedef struct smi_llm_cfg {
    * sets this field).  The library reads the layout from here, never from the environment: an arena and the handle that
    * reads it cannot disagree silently. */
   int32_t wd_plain;
+  /* Exact-weights verification mode: 1 = the arena holds every matrix as fp32 [N][K] row-major (same row / column orders as
+   * the bf16 tiles; 2x the bytes) and every GEMM of the path runs as an exact fp32 multiply-add chain over k
+   * (v_mfma_f32_16x16x4_f32), activations exact as always.  For checkpoints SAVED in fp32 -- the published Spark-TTS-0.5B
+   * LLM/model.safetensors is: the reference loads it as saved (cli/SparkTTS.py:48-51) and the default bf16 arena ROUNDS it
+   * (logits move ~1e-2) -- this mode reproduces the fp32 PyTorch CPU path's greedy tokens (north_star's acceptance sentence
+   * on such a checkpoint).  Opt-in and slow (~4x the step time at one row); 0 (default) = bf16 weights, north_star's arithmetic. */
+  int32_t weights_exact;
 } smi_llm_cfg;
 
 /* Arena sections.  The arena is one device buffer the caller fills (see sparkmi/arena.py):
@@ -112,7 +119,8 @@ typedef struct smi_llm_arena_tag {
   int32_t abi_version;       /* SMI_ABI_VERSION of the packer */
   int32_t wd_plain;          /* = smi_llm_cfg.wd_plain the matrices were packed with */
   int32_t vocab_size, hidden_size, num_layers, num_heads, num_kv_heads, intermediate_size, max_positions;
-  int32_t reserved[53];
+  int32_t weights_exact;     /* = smi_llm_cfg.weights_exact: fp32 [N][K] matrices instead of bf16 tiles */
+  int32_t reserved[52];
 } smi_llm_arena_tag;
 /* Total arena size in bytes for this config (0 on invalid config). */
 size_t smi_llm_arena_bytes(const smi_llm_cfg* cfg);

@@ -51,12 +51,30 @@ int smi_llm_engine_plan(const smi_llm_cfg* cfg, int ncu, int32_t* stats);
 int smi_llm_engine_stamps(smi_llm* h, double* out, int cap);
 /* Tests: synchronises and copies the residual row (hidden_size floats) of row 0 as the last step left it. */
 int smi_llm_debug_hidden(smi_llm* h, float* out_host, int n);
-/* Tests / debugging: synchronises and copies one scratch buffer as raw bytes.  what: 0 q [q_dim] f32, 1 / 2 / 3 the operand
- * triples of o_proj / down_proj / the next norm ([K / 32][3][4][16 B] at one row), 4 the residual row, 5 the engine's
+/* Tests / debugging: synchronises and copies one scratch buffer as raw bytes (buffers 0..4 and 6 hold one entry per live row:
+ * M rows after smi_llm_debug_layer).  what: 0 q [M][q_dim] f32, 1 / 2 / 3 the operand
+ * triples of o_proj / down_proj / the next norm ([K / 32][3][4][M][16 B]), 4 the residual rows, 5 the engine's
  * granules [2][per buffer] u64 {tag << 32 | f32 bits}, 6 partial sums of squares [hidden / 4], 7 K rows of layer 0, slot 0,
  * kv head 0 (bf16), 8 h + o_proj of the fused one-row path. */
 int smi_llm_debug_read(smi_llm* h, int what, void* out_host, size_t cap, size_t* got);
 
+/* Op-level tests of the LLM half: ONE decoder layer's kernels, stage by stage, on caller-given rows -- launched by the functions a
+ * real step launches them with (same kernel choices per row count, launch geometry, prologue / epilogue fusions), so the classes
+ * of transformers' modeling_qwen2.py can be checked one at a time (tests/test_llm_ops_gpu.py on tests/golden/llm_ops.npz):
+ * Qwen2RMSNorm + q/k/v_proj + apply_rotary_pos_emb (MQ:247-252, 91-135), eager_attention_forward (MQ:150-173), o_proj + residual,
+ * Qwen2MLP (MQ:46-48).
+ *   smi_llm_debug_set_kv / _get_kv: write / read cache rows of (layer, slot) as fp32 [n][num_kv_heads][64] in transformers' dim
+ *     order (keys rotated, as a cache holds them); the cache's own dtype and row order are converted on the host.
+ *   smi_llm_debug_layer: rows_host = M (slot, pos) pairs, hidden_host [M][hidden] = the residual rows entering `layer`; runs its
+ *     kernels up to and including `stage`: 0 QKV (+ bias, RoPE, K/V append: read q with smi_llm_debug_read(0), K/V with _get_kv),
+ *     1 attention (buffer 1: the o_proj operand triples, head-interleaved k tiles), 2 o_proj + residual (buffer 4; one fused row:
+ *     buffer 8), 3 gate_up + SwiGLU (buffer 2: act triples), 4 down_proj + residual (buffer 4).  smi_llm_debug_read's buffers
+ *     0..4 and 6 then hold M rows.  Contiguous KV cache only.  Ends the current generation. */
+int smi_llm_debug_set_kv(smi_llm* h, int layer, int slot, int pos0, int n, const float* k_host, const float* v_host);
+int smi_llm_debug_get_kv(smi_llm* h, int layer, int slot, int pos0, int n, float* k_host, float* v_host);
+int smi_llm_debug_layer(smi_llm* h, int layer, int M, const int32_t* rows_host, const float* hidden_host, int stage);
+/* Diagnostics: the raw stamp buffer (u64 s_memrealtime ticks, 10 ns) after smi_llm_debug_stamps; n entries. */
+int smi_llm_debug_raw_stamps(smi_llm* h, unsigned long long* out, int n);
 /* Tests: the sampler alone (k_sample_scan + k_sample, exactly as a decode step launches them) on a caller's logits row --
  * the reference's default decoding chain, cli/SparkTTS.py:166-168,197-204 -> transformers' TemperatureLogitsWarper ->
  * TopKLogitsWarper -> TopPLogitsWarper -> multinomial.  logits_host [vocab_size] is replicated to every row (null: the rows

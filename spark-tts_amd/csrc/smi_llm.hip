@@ -261,6 +261,28 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
       if (LEAN != 2) erd[mt] = p.rows[m < M ? m : M - 1];
     }
   }
+  // Non-LEAN PRO_NORM kernels (QKV / gate_up at 6+ rows): the partial sums of squares of the rows whose RMSNorm factor this wave
+  // computes (rows wave, wave + NW, ...) are requested HERE, before the weight stream, and summed only after the MFMA loop (the
+  // factor is an epilogue operand).  As a row-by-row loop in front of the MFMAs (where the compiler kept it: round-4 ISA of the
+  // 32-row gate_up) every row was a dependent L2 round trip behind a vmcnt(0) that also covered all weight and operand loads:
+  // four round trips per wave between the last operand byte and the first MFMA.
+  constexpr int RPW = (MT * 16 + NW - 1) / NW;
+  constexpr bool SS_EARLY = !LEAN && PRO == PRO_NORM && RPW <= 4;
+  float ssv[SS_EARLY ? RPW : 1][4];
+  const bool ss_early = SS_EARLY && p.npart <= 256;
+  if constexpr (SS_EARLY) {
+    if (ss_early) {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        int m = mbase + wave + i * NW;
+        m = m < M ? m : M - 1;
+        const float* sp = p.sspart + (size_t)m * p.npart;
+        const int last = p.npart - 1;
+        ssv[i][0] = sp[lane < last ? lane : last]; ssv[i][1] = sp[lane + 64 < last ? lane + 64 : last];
+        ssv[i][2] = sp[lane + 128 < last ? lane + 128 : last]; ssv[i][3] = sp[lane + 192 < last ? lane + 192 : last];
+      }
+    }
+  }
   // PRO_FUSEDO: the per-head o_proj partials, the residual row and gamma of this wave's k tiles (two tiles per round, lane =
   // one k) are requested BEFORE the weight tiles: loads return in issue order, so behind the (cold) weights they would only
   // arrive after them and the whole operand build would sit between the weights' arrival and the first MFMA
@@ -430,7 +452,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
   }
 
   // ---- RMSNorm factor per row from the producer's partial sums (fixed order: DPP tree over partials)
-  if (PRO == PRO_NORM) {
+  if (PRO == PRO_NORM && !ss_early) {
     for (int ml = wave; ml < MT * 16 && mbase + ml < M; ml += NW) {
       float v;
       if (ss_pre && ml == wave) {   // same order as smi_ss_lane_sum
@@ -503,6 +525,21 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
     compute(w[0], j0);
   }
   if constexpr (PRO == PRO_FUSEDO) asm volatile("" ::"v"(pf2v));
+  if constexpr (SS_EARLY) {
+    if (ss_early) {   // the partials requested at entry: same order as smi_ss_lane_sum + smi_wave_sum
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int ml = wave + i * NW;
+        asm volatile("" : "+v"(ssv[i][0]), "+v"(ssv[i][1]), "+v"(ssv[i][2]), "+v"(ssv[i][3]));   // first looked at here, behind the MFMAs
+        float v = lane < p.npart ? ssv[i][0] : 0.f;
+        v += lane + 64 < p.npart ? ssv[i][1] : 0.f;
+        v += lane + 128 < p.npart ? ssv[i][2] : 0.f;
+        v += lane + 192 < p.npart ? ssv[i][3] : 0.f;
+        v = smi_wave_sum(v);
+        if (lane == 0 && ml < MT * 16 && mbase + ml < M) rarr[ml] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
+      }
+    }
+  }
   SMI_STAMP(4);
   // ---- split-K reduction across the block's waves (fixed order => deterministic)
 #pragma unroll
@@ -525,11 +562,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_gemm(GemmP p) {
   SMI_STAMP(5);
 
   const int N = NT * 16;
-  for (int nb = wave; nb < NTB; nb += NW) {
+  // SPREAD (gate_up with two m-tiles): the NTB * MT (tile, m-tile) pairs go to NTB * MT different waves instead of NTB waves
+  // finishing MT pairs each (five of the eight waves used to idle through the epilogue: two expf, two divides, two exact splits
+  // per pair).  Only kernels whose epilogue needs no per-wave prefetched operands (SWIGLU) do this.
+  constexpr bool SPREAD = EPI == EPI_SWIGLU && MT == 2 && NTB * MT <= NW;
+  for (int nb = SPREAD ? wave / MT : wave; nb < NTB; nb += NW) {
     const int nt = nt0 + nb;
     if (nt >= NT) continue;  // wave-uniform
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+      if (SPREAD && mt != wave % MT) continue;   // wave-uniform
       float4 s = red[((0 * NTB + nb) * MT + mt) * 64 + lane];
 #pragma unroll
       for (int wv = 1; wv < NW; ++wv) {
@@ -840,6 +882,321 @@ __global__ __launch_bounds__(256) void k_downS(GemmP p) {
     *(uint2*)(p.XSout + o + 2 * pl) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
     p.ssout[((size_t)m * NT + nt) * 4 + part] = ssq;
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Exact-weights verification mode (smi_llm_cfg.weights_exact = 1; round 4).  The reference loads the checkpoint as saved
+// (cli/SparkTTS.py:48-51) and the published LLM/model.safetensors is fp32: the bf16 arena rounds it (logits move ~1e-2, a
+// tenth of the greedy decisions of a synthetic model change).  In this mode the arena holds the matrices as fp32 [N][K]
+// (same row / column orders as the bf16 tiles) and every GEMM of the path runs here: one wave per (16-row weight tile, 16-row
+// m-tile), v_mfma_f32_16x16x4_f32 -- an exact fp32 fused multiply-add chain over k, like the CPU's -- on operands rebuilt
+// exactly from the triples (x = hi + mid + lo), with k_gemm's own prologue scalars and epilogues (RMSNorm factor, bias, RoPE,
+// KV append, residual, SwiGLU, arg-max partials, the next operand's triples).  Throughput is not a goal (a weight byte is
+// read once per 16 rows through 64-byte row segments: ~1.5 ms per step at one row); north_star's acceptance sentence --
+// waveform within 1e-3 of the PyTorch CPU path for fixed greedy seeds -- on an fp32-saved checkpoint is.
+// ------------------------------------------------------------------------------------------
+template <int PRO, int EPI, int KVF32>
+__global__ __launch_bounds__(256) void k_gemm_x(GemmP p, const float* W32) {
+  __shared__ float bestv[4][16];
+  __shared__ int besti[4][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int KT = p.KT, K = KT * 32, M = p.M, NT = p.NT, N = NT * 16;
+  const int nt = (int)blockIdx.x * 4 + wave, mbase = (int)blockIdx.y * 16;
+  const int em = lane & 15, kq = lane >> 4;
+  const int m = mbase + em, mc = m < M ? m : M - 1;
+  const bool live = nt < NT;                       // wave-uniform
+  const int ntc = live ? nt : NT - 1;
+  // ---- y[n][m] = sum_k W[n][k] x[m][k]: 16 k per step, lane (kq, i) holds W[16 nt + i][k0 + 4 kq .. + 3] and x[m = i][same k]
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* wrow = W32 + (size_t)(ntc * 16 + em) * K + 4 * kq;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    const float4 wv = *(const float4*)(wrow + k0);
+    const int k = k0 + 4 * kq;                     // this lane's four k: tile k >> 5, octet (k >> 3) & 3, elements k & 7 .. + 3
+    const unsigned char* xp = p.XS + xs_off(k >> 5, 0, (k >> 3) & 3, mc, M) + (k & 7) * 2;
+    const size_t pl = (size_t)4 * M * 16;
+    const uint2 h2 = *(const uint2*)xp, m2 = *(const uint2*)(xp + pl), l2 = *(const uint2*)(xp + 2 * pl);
+    const uint32_t hb[4] = {h2.x << 16, h2.x & 0xffff0000u, h2.y << 16, h2.y & 0xffff0000u};
+    const uint32_t mb[4] = {m2.x << 16, m2.x & 0xffff0000u, m2.y << 16, m2.y & 0xffff0000u};
+    const uint32_t lb[4] = {l2.x << 16, l2.x & 0xffff0000u, l2.y << 16, l2.y & 0xffff0000u};
+    const float wa[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float x = (__uint_as_float(hb[c]) + __uint_as_float(mb[c])) + __uint_as_float(lb[c]);   // exact: the split terms do not overlap
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c], x, acc, 0, 0, 0);
+    }
+  }
+  // ---- k_gemm's epilogue for (tile nt, rows mbase ..): lane (g = lane >> 4, m) holds columns n .. n + 3 of row m
+  float4 s = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  const int n = ntc * 16 + 4 * (lane >> 4);
+  const bool valid = live && m < M;
+  if (PRO == PRO_NORM) {
+    // every lane needs ITS row's factor: rows differ across the 16 lanes of a group, so each row is summed by the whole wave in turn
+    float r = 0.f;
+    for (int j = 0; j < 16; ++j) {
+      const int mj = mbase + j < M ? mbase + j : M - 1;
+      float vj = smi_ss_lane_sum(p.sspart + (size_t)mj * p.npart, p.npart, lane);
+      vj = smi_wave_sum(vj);
+      const float rj = 1.0f / sqrtf(vj / (float)K + p.eps);
+      r = em == j ? rj : r;
+    }
+    s.x *= r; s.y *= r; s.z *= r; s.w *= r;
+  }
+  if (EPI == EPI_RESID) {
+    if (valid) {
+      const float4 egam = *(const float4*)(p.gamma_next + n);
+      float4 h = *(const float4*)((p.Yin ? p.Yin : p.Y) + (size_t)m * N + n);
+      h.x += s.x; h.y += s.y; h.z += s.z; h.w += s.w;
+      *(float4*)(p.Y + (size_t)m * N + n) = h;
+      const float ssq = (h.x * h.x + h.y * h.y) + (h.z * h.z + h.w * h.w);
+      const float t[4] = {egam.x * h.x, egam.y * h.y, egam.z * h.z, egam.w * h.w};
+      uint32_t hi[4], mi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split3(t[e], hi[e], mi[e], lo[e]);
+      const size_t o = xs_off(n >> 5, 0, (n >> 3) & 3, m, M) + ((n >> 2) & 1) * 8;
+      const size_t pl = (size_t)4 * M * 16;
+      *(uint2*)(p.XSout + o) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+      *(uint2*)(p.XSout + o + pl) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
+      *(uint2*)(p.XSout + o + 2 * pl) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+      p.ssout[((size_t)m * NT + nt) * 4 + (lane >> 4)] = ssq;
+    }
+  } else if (EPI == EPI_SWIGLU) {
+    if (valid) {
+      const float a0 = (s.x / (1.0f + expf(-s.x))) * s.y;
+      const float a1 = (s.z / (1.0f + expf(-s.z))) * s.w;
+      uint32_t h0, m0, l0, h1, m1, l1;
+      split3(a0, h0, m0, l0);
+      split3(a1, h1, m1, l1);
+      const int k = n >> 1;
+      const size_t o = xs_off(k >> 5, 0, (k >> 3) & 3, m, M) + ((k >> 1) & 3) * 4;
+      const size_t pl = (size_t)4 * M * 16;
+      *(uint32_t*)(p.XSout + o) = h0 | (h1 << 16);
+      *(uint32_t*)(p.XSout + o + pl) = m0 | (m1 << 16);
+      *(uint32_t*)(p.XSout + o + 2 * pl) = l0 | (l1 << 16);
+    }
+  } else if (EPI == EPI_QKV) {
+    if (valid) {
+      const float4 b = *(const float4*)(p.bias + n);
+      s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+      const RowDesc rd = p.rows[m];
+      if (n < p.q_dim + p.kv_dim) {
+        const int i0 = (n & 63) >> 1;
+        const float2 c0 = p.rope[(size_t)rd.pos * 32 + i0], c1 = p.rope[(size_t)rd.pos * 32 + i0 + 1];
+        float4 r;
+        r.x = __fadd_rn(__fmul_rn(s.x, c0.x), __fmul_rn(-s.y, c0.y));
+        r.y = __fadd_rn(__fmul_rn(s.y, c0.x), __fmul_rn(s.x, c0.y));
+        r.z = __fadd_rn(__fmul_rn(s.z, c1.x), __fmul_rn(-s.w, c1.y));
+        r.w = __fadd_rn(__fmul_rn(s.w, c1.x), __fmul_rn(s.z, c1.y));
+        s = r;
+      }
+      if (n < p.q_dim) {
+        *(float4*)(p.Y + (size_t)m * p.q_dim + n) = s;
+      } else {
+        const bool isk = n < p.q_dim + p.kv_dim;
+        const int c = n - p.q_dim - (isk ? 0 : p.kv_dim);
+        const size_t off = kv_row(p.km, rd.slot, c >> 6, p.n_kv, p.max_pos, rd.pos) * 64 + (c & 63);
+        void* base = isk ? p.kcache : p.vcache;
+        if (KVF32) {
+          *(float4*)((float*)base + off) = s;
+        } else {
+          uint2 pk;
+          pk.x = smi_f32_to_bf16(s.x) | (smi_f32_to_bf16(s.y) << 16);
+          pk.y = smi_f32_to_bf16(s.z) | (smi_f32_to_bf16(s.w) << 16);
+          *(uint2*)((uint16_t*)base + off) = pk;
+        }
+      }
+    }
+  } else {  // EPI_LM
+    if (valid && p.Y) {
+      float* y = p.Y + (size_t)m * p.V + n;
+      if (n + 0 < p.V) y[0] = s.x;
+      if (n + 1 < p.V) y[1] = s.y;
+      if (n + 2 < p.V) y[2] = s.z;
+      if (n + 3 < p.V) y[3] = s.w;
+    }
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (live && n + r < p.V && sv[r] > bv) { bv = sv[r]; bi = n + r; }
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane < 16) { bestv[wave][lane] = bv; besti[wave][lane] = bi; }
+    __syncthreads();
+    if (tid < 16 && mbase + tid < M) {
+      bv = bestv[0][tid]; bi = besti[0][tid];
+#pragma unroll
+      for (int w2 = 1; w2 < 4; ++w2) {
+        const float ov = bestv[w2][tid];
+        const int oi = besti[w2][tid];
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      p.pval[(size_t)(mbase + tid) * gridDim.x + blockIdx.x] = bv;
+      p.pidx[(size_t)(mbase + tid) * gridDim.x + blockIdx.x] = bi;
+    }
+  }
+}
+
+// the embedding row of `token` from the fp32 lm_head of the exact-weights arena ([vocab padded][K] row-major): h, the first
+// norm's operand triples and the row's sum of squares, as embed_row leaves them
+__device__ __forceinline__ void embed_row_x(const float* W32, int KT, int token, int m, int M, const float* gamma,
+                                            float* h, unsigned char* xs, float* sspart, int npart, int lane) {
+  const int K = KT * 32;
+  float ss = 0.f;
+  for (int pc = lane; pc < KT * 4; pc += 64) {
+    const float4 a = *(const float4*)(W32 + (size_t)token * K + pc * 8), b = *(const float4*)(W32 + (size_t)token * K + pc * 8 + 4);
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float* dst = h + (size_t)m * K + pc * 8;
+    *(float4*)dst = a;
+    *(float4*)(dst + 4) = b;
+    const float4 g0 = *(const float4*)(gamma + pc * 8), g1 = *(const float4*)(gamma + pc * 8 + 4);
+    const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    uint32_t hi[8], mi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ss += x[e] * x[e]; split3(g[e] * x[e], hi[e], mi[e], lo[e]); }
+    const size_t o = xs_off(pc >> 2, 0, pc & 3, m, M);
+    const size_t pl = (size_t)4 * M * 16;
+    *(uint4*)(xs + o) = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+    *(uint4*)(xs + o + pl) = make_uint4(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16), mi[4] | (mi[5] << 16), mi[6] | (mi[7] << 16));
+    *(uint4*)(xs + o + 2 * pl) = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+  }
+  ss = smi_wave_sum(ss);
+  for (int i = lane; i < npart; i += 64) sspart[(size_t)m * npart + i] = i == 0 ? ss : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------
+// down_proj at 9 .. 64 rows: the 16 chains go to 16 DIFFERENT blocks (round 4).
+// k_gemm<.., H> gives a block all 16 chains of its rows of a weight tile, so every block pulls the WHOLE operand of its 16 rows
+// (K = 4864: 467 KB of triples per block at 32 rows, 105 MB of L2 -> CU traffic per launch: its loads land 5.6 us after the
+// first wave starts, profiles/r03_stamps_batch.txt) and the two 16-row block rows both stream the weights from HBM (16.6 MB for
+// 8.7 MB, r03_pmc_traffic_g_b32.json).  Here block (column group cg, chain c) takes chain c's k tiles (kt = c, c + 16, ...) of
+// four weight tiles for ALL rows: 40 KB of weights (every weight byte leaves HBM once per launch) and 1/16 of the operand
+// (61 KB at 32 rows), staged once per block in LDS.  A wave owns one weight tile -- no cross-wave reduction -- and leaves the
+// chain's sum, (lo + mid) + hi exactly as k_gemm forms it, in `part` [chain][n tile][m tile][lane] (the accumulator's own
+// layout: 1-KiB stores).  k_down_comb then adds the 16 chains IN ORDER and runs the RESID epilogue: the same sums in the same
+// order as k_gemm<RESID, NW = 16> / k_downS / k_down1, so a row keeps its bits whatever the batch.  Blocks of one chain sit on
+// one XCD (block id = cg * 16 + c): they share the operand slice through one L2.
+// ------------------------------------------------------------------------------------------
+struct DownCP {
+  const uint4* W; int NT, KT, M, wperm;
+  const unsigned char* XS;          // act triples [KT][3][4][M][16 B]
+  float4* part;                     // [16][NT][MTN][64]
+  // combine
+  float* Y; const float* Yin; const float* gamma_next; unsigned char* XSout; float* ssout;
+};
+
+template <int TPC, int MTN>
+__global__ __launch_bounds__(256) void k_downC(DownCP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [tiles of the chain][12 * M] 16-byte operand pieces
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int KT = p.KT, M = p.M, NT = p.NT;
+  const int c = (int)blockIdx.x & 15, cg = (int)blockIdx.x >> 4;
+  const int ntile = c < KT ? (KT - c + 15) >> 4 : 0;    // k tiles of this chain
+  if (ntile == 0) {   // block-uniform: fewer than 16 k tiles -- this chain adds zeros, as an idle wave of k_gemm does
+    const int nt0 = cg * 4 + (tid >> 6);
+    if (nt0 < NT)
+      for (int mt = 0; mt < MTN; ++mt) p.part[(((size_t)c * NT + nt0) * MTN + mt) * 64 + (tid & 63)] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  const int pm = 12 * M, npieces = ntile * pm;
+  const float pm_inv = 1.0f / (float)pm;
+  // ---- operand slice: every piece requested before the weights (L2 hits; loads return in issue order)
+  constexpr int PPT = (TPC * 12 * MTN * 16 + 255) / 256; // pieces per thread at most
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 pc[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    int q = tid + 256 * i;
+    q = q < npieces ? q : npieces - 1;
+    const int u = (int)(((float)q + 0.5f) * pm_inv), r = q - u * pm;   // q / pm, exact: q < 2^13, (q + 0.5) / pm is never within 6e-4 of an integer
+    pc[i] = *(const u32x4*)(p.XS + ((size_t)(c + 16 * u) * pm + r) * 16);
+  }
+  // ---- this wave's weight tile, chain c's k tiles: full 1-KiB loads, all in flight
+  const int nt = cg * 4 + wave;
+  const int ntc = nt < NT ? nt : NT - 1;
+  const int wl = smi_wlane(lane, p.wperm);
+  uint4 w[TPC];
+#pragma unroll
+  for (int u = 0; u < TPC; ++u) {
+    const int t = c + 16 * u;
+    w[u] = smi_ldw(p.W + ((size_t)ntc * KT + (t < KT ? t : KT - 1)) * 64 + wl);
+  }
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) asm volatile("" : "+v"(pc[i]));   // the loads above stay above (not sunk into the guarded stores)
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int q = tid + 256 * i;
+    if (q < npieces) *(u32x4*)(smem + (size_t)q * 16) = pc[i];
+  }
+  __syncthreads();
+  f32x4 acc[3][MTN];
+#pragma unroll
+  for (int s2 = 0; s2 < 3; ++s2)
+#pragma unroll
+    for (int mt = 0; mt < MTN; ++mt) acc[s2][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int k8 = lane >> 4, em = lane & 15;
+#pragma unroll
+  for (int u = 0; u < TPC; ++u) {
+    if (u < ntile) {   // block-uniform
+      const bf16x8 a = __builtin_bit_cast(bf16x8, w[u]);
+#pragma unroll
+      for (int mt = 0; mt < MTN; ++mt) {
+        int m = mt * 16 + em;
+        m = m < M ? m : M - 1;
+        const unsigned char* bp = smem + ((size_t)u * pm + (size_t)k8 * M + m) * 16;
+        const bf16x8 b0 = *(const bf16x8*)bp, b1 = *(const bf16x8*)(bp + (size_t)4 * M * 16), b2 = *(const bf16x8*)(bp + (size_t)8 * M * 16);
+        acc[2][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2, acc[2][mt], 0, 0, 0);
+        acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[1][mt], 0, 0, 0);
+        acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[0][mt], 0, 0, 0);
+      }
+    }
+  }
+  if (nt < NT) {
+#pragma unroll
+    for (int mt = 0; mt < MTN; ++mt) {
+      const f32x4 t = (acc[2][mt] + acc[1][mt]) + acc[0][mt];   // (lo + mid) + hi
+      p.part[(((size_t)c * NT + nt) * MTN + mt) * 64 + lane] = make_float4(t[0], t[1], t[2], t[3]);
+    }
+  }
+}
+
+// One wave per (n tile, m tile): the 16 chain sums in order, then k_gemm's RESID epilogue (residual add, h, the next norm's
+// operand triples and partial sums of squares).
+template <int MTN>
+__global__ __launch_bounds__(64) void k_down_comb(DownCP p) {
+  const int lane = threadIdx.x, unit = (int)blockIdx.x;
+  const int nt = unit / MTN, mt = unit - nt * MTN;
+  const int NT = p.NT, M = p.M, N = NT * 16;
+  const int m = mt * 16 + (lane & 15), n = nt * 16 + 4 * (lane >> 4);
+  const bool valid = m < M;
+  const int mc = valid ? m : M - 1;
+  const float4 egam = *(const float4*)(p.gamma_next + n);
+  const float4 epre = *(const float4*)((p.Yin ? p.Yin : p.Y) + (size_t)mc * N + n);
+  float4 q[16];
+#pragma unroll
+  for (int ch = 0; ch < 16; ++ch) q[ch] = p.part[(((size_t)ch * NT + nt) * MTN + mt) * 64 + lane];
+  float4 s = q[0];
+#pragma unroll
+  for (int ch = 1; ch < 16; ++ch) { s.x += q[ch].x; s.y += q[ch].y; s.z += q[ch].z; s.w += q[ch].w; }
+  if (!valid) return;
+  float4 h = epre;
+  h.x += s.x; h.y += s.y; h.z += s.z; h.w += s.w;
+  *(float4*)(p.Y + (size_t)m * N + n) = h;
+  const float ssq = (h.x * h.x + h.y * h.y) + (h.z * h.z + h.w * h.w);
+  const float t[4] = {egam.x * h.x, egam.y * h.y, egam.z * h.z, egam.w * h.w};
+  uint32_t hi[4], mi[4], lo[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split3(t[e], hi[e], mi[e], lo[e]);
+  const size_t o = xs_off(n >> 5, 0, (n >> 3) & 3, m, M) + ((n >> 2) & 1) * 8;
+  const size_t pl = (size_t)4 * M * 16;
+  *(uint2*)(p.XSout + o) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+  *(uint2*)(p.XSout + o + pl) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
+  *(uint2*)(p.XSout + o + 2 * pl) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+  p.ssout[((size_t)m * NT + nt) * 4 + (lane >> 4)] = ssq;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1399,8 +1756,14 @@ __global__ __launch_bounds__(256 * HV) void k_lm(GemmP p, int ngroups, int m0_la
 // read as MFMA B operands straight from there (3 KB of LDS reads per 1 KB weight tile -- far below the LDS rate).  k_lm<2>
 // gave each 16-row group its own four waves, i.e. every weight tile was pulled into registers twice per CU (72 us at 32
 // rows); here it is pulled once.  Same k-tile -> wave map, chains and reduction order per row as k_lm<1>: same logits bits.
+// Round 4: TWO weight register sets (one wave per SIMD: the 512-register budget holds them).  With one set a group's tiles were
+// requested only after the previous group's 84 MFMAs per wave had consumed the registers, so the stream stood still during the
+// MFMAs, the reduction and the epilogue (3.2 us per group against 2.3 us for the 56 KB at the CU's share of the HBM rate); now
+// the tiles of group g + 2 are requested as soon as group g's MFMAs are issued and the tiles of g + 1 are already in flight.
+// UW = k tiles per wave (ceil(KT / 4)): no clamped duplicate loads (U = 8 at KT = 28 re-requested tile 27 once per wave and n tile).
+template <int UW>
 __global__ __launch_bounds__(256) void k_lm32(GemmP p, int ngroups, int m0) {
-  constexpr int NTB = 2, NW = 4, U = 8;
+  constexpr int NTB = 2, NW = 4, U = UW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int KT = p.KT, NT = p.NT;
@@ -1420,8 +1783,14 @@ __global__ __launch_bounds__(256) void k_lm32(GemmP p, int ngroups, int m0) {
 #pragma unroll
     for (int s = 0; s < 3; ++s) bf[u][s] = *(const bf16x8*)(p.XS + xs_off(j, s, k8, row0, p.M));
   }
-  uint4 w[U][NTB];
-  auto load_w = [&](int g) {
+  uint4 w0[U][NTB], w1[U][NTB];
+  // EVERY request below is unconditional (group and tile indices are clamped, a block's surplus requests re-read the last group
+  // out of L2): with `if (gn < ngroups) load_w(..)` the number of loads in flight depends on the path, the compiler's counted
+  // waits must assume the smallest -- and the wait for one register set then drained the other set's requests too (round-3's
+  // "two register sets change nothing", and this kernel's first round-4 build: s_waitcnt vmcnt(13) .. vmcnt(0) in front of a
+  // group's MFMAs with 28 loads outstanding).
+  auto load_w = [&](uint4 (&w)[U][NTB], int gq) {
+    const int g = gq < ngroups ? gq : ngroups - 1;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       int j = wave + u * NW;
@@ -1434,8 +1803,10 @@ __global__ __launch_bounds__(256) void k_lm32(GemmP p, int ngroups, int m0) {
       }
     }
   };
+  const int G = (int)gridDim.x;
   int g = blockIdx.x;
-  if (g < ngroups) load_w(g);
+  load_w(w0, g);
+  load_w(w1, g + G);
   // m-tile 1's operand pieces -> LDS (rows beyond M repeat the last row; their results are never stored)
   for (int i = tid; i < KT * 12 * 16; i += 256) {
     const int r = i & 15, pc = i >> 4;                             // pc = (kt * 3 + s) * 4 + k8
@@ -1453,7 +1824,14 @@ __global__ __launch_bounds__(256) void k_lm32(GemmP p, int ngroups, int m0) {
   const int nb_e = wave & 1, mt_e = wave >> 1;                     // the (n tile, m tile) this wave finishes
   const int ml = mt_e * 16 + em;                                   // its row (local)
   const float rn = rarr[ml < M ? ml : 0];
-  for (; g < ngroups; g += gridDim.x) {
+  int gi = 0;   // (diagnostics) groups this block has finished
+#ifdef SMI_DIAG
+#define SMI_LMSTAMP(i) do { if (p.stamps && blockIdx.x == 0 && tid == 0 && gi < 32) p.stamps[gi * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SMI_LMSTAMP(i) do { } while (0)
+#endif
+  auto group = [&](uint4 (&w)[U][NTB], int gcur) {
+    SMI_LMSTAMP(0);
     f32x4 acc[3][NTB][2];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -1478,8 +1856,7 @@ __global__ __launch_bounds__(256) void k_lm32(GemmP p, int ngroups, int m0) {
         }
       }
     }
-    const int gn = g + gridDim.x;
-    if (gn < ngroups) load_w(gn);          // overlaps the reduction and the epilogue below
+    load_w(w, gcur + 2 * G);               // this set's registers are free again: the group after next, while the other set's tiles are in flight
 #pragma unroll
     for (int nb = 0; nb < NTB; ++nb)
 #pragma unroll
@@ -1487,9 +1864,11 @@ __global__ __launch_bounds__(256) void k_lm32(GemmP p, int ngroups, int m0) {
         const f32x4 t = (acc[2][nb][mt] + acc[1][nb][mt]) + acc[0][nb][mt];
         red[((wave * NTB + nb) * 2 + mt) * 64 + lane] = make_float4(t[0], t[1], t[2], t[3]);
       }
+    SMI_LMSTAMP(1);
     __syncthreads();
+    SMI_LMSTAMP(2);
     {
-      const int nt = g * NTB + nb_e;
+      const int nt = gcur * NTB + nb_e;
       if (nt < NT) {
         float4 s = red[((0 * NTB + nb_e) * 2 + mt_e) * 64 + lane];
 #pragma unroll
@@ -1527,6 +1906,13 @@ __global__ __launch_bounds__(256) void k_lm32(GemmP p, int ngroups, int m0) {
       }
     }
     __syncthreads();   // red is rewritten by the next group
+    SMI_LMSTAMP(3);
+    ++gi;
+  };
+#undef SMI_LMSTAMP
+  for (; g < ngroups; g += 2 * G) {   // block-uniform trip counts (every wave keeps the barriers); a group beyond the last stores nothing
+    group(w0, g);
+    group(w1, g + G);
   }
   if (tid < M) {
     float bv = -INFINITY;
@@ -2138,11 +2524,44 @@ __global__ __launch_bounds__(64) void k_rows_drop(RowDesc* rows, int B, unsigned
 }
 
 __global__ __launch_bounds__(256) void k_embed(const uint16_t* Wlm, int KT, const RowDesc* rows, int M, const float* gamma,
-                                               float* h, unsigned char* xs, float* sspart, int npart) {
+                                               float* h, unsigned char* xs, float* sspart, int npart, int exact) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4)
-    embed_row(Wlm, KT, rows[m].token, m, M, gamma, h, xs, sspart, npart, lane);
+  for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
+    if (exact) embed_row_x((const float*)Wlm, KT, rows[m].token, m, M, gamma, h, xs, sspart, npart, lane);   // exact-weights arena: fp32 [vocab][K]
+    else embed_row(Wlm, KT, rows[m].token, m, M, gamma, h, xs, sspart, npart, lane);
+  }
 }
+
+#ifdef SMI_DIAG
+// Tests (smi_llm_debug_layer): caller-given fp32 residual rows -> the state a layer starts from (h, the first norm's operand
+// triples, the row's sum of squares in partial slot 0), exactly as embed_row leaves it for an embedding row.
+__global__ __launch_bounds__(256) void k_load_hidden(const float* src, int KT, int M, const float* gamma, float* h, unsigned char* xs,
+                                                     float* sspart, int npart) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int K = KT * 32;
+  for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
+    float ss = 0.f;
+    for (int pc = lane; pc < KT * 4; pc += 64) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = src[(size_t)m * K + pc * 8 + e];
+      float* dst = h + (size_t)m * K + pc * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dst[e] = x[e];
+      uint32_t hi[8], mi[8], lo[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { ss += x[e] * x[e]; split3(gamma[pc * 8 + e] * x[e], hi[e], mi[e], lo[e]); }
+      const size_t o = xs_off(pc >> 2, 0, pc & 3, m, M);
+      const size_t pl = (size_t)4 * M * 16;
+      *(uint4*)(xs + o) = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+      *(uint4*)(xs + o + pl) = make_uint4(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16), mi[4] | (mi[5] << 16), mi[6] | (mi[7] << 16));
+      *(uint4*)(xs + o + 2 * pl) = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+    }
+    ss = smi_wave_sum(ss);
+    for (int i = lane; i < npart; i += 64) sspart[(size_t)m * npart + i] = i == 0 ? ss : 0.f;
+  }
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Sampling (the reference's default: do_sample=True, top_k=50, top_p=0.95, temperature=0.8 at
@@ -2430,6 +2849,7 @@ struct FinP {
   const float* gamma0;   // first layer's input norm weight
   unsigned char* xs;     // first layer's operand
   float* sspart; int npart;
+  int exact;             // exact-weights arena: Wlm is fp32 [vocab][K]
 };
 
 // One block per row: arg-max over the lm_head blocks' partials (or the sampled token), per-row
@@ -2495,7 +2915,10 @@ __global__ __launch_bounds__(256) void k_finalize(FinP p) {
     if (m == 0) *p.step = step + 1;
   }
   __syncthreads();
-  if (wave == 0) embed_row(p.Wlm, p.KT, tok_s, m, p.M, p.gamma0, p.h, p.xs, p.sspart, p.npart, lane);
+  if (wave == 0) {
+    if (p.exact) embed_row_x((const float*)p.Wlm, p.KT, tok_s, m, p.M, p.gamma0, p.h, p.xs, p.sspart, p.npart, lane);
+    else embed_row(p.Wlm, p.KT, tok_s, m, p.M, p.gamma0, p.h, p.xs, p.sspart, p.npart, lane);
+  }
 }
 
 }  // namespace
@@ -2525,6 +2948,7 @@ bool cfg_ok(const smi_llm_cfg* c) {
   if ((c->num_heads * c->head_dim) % 32) return false;
   if (c->kv_dtype != 0 && c->kv_dtype != 1) return false;
   if (c->wd_plain != 0 && c->wd_plain != 1) return false;
+  if (c->weights_exact != 0 && c->weights_exact != 1) return false;
   if (c->kv_page_tokens != 0) {   // paged KV: a power of two in 16..1024 that divides max_positions, and a pool of at least one page
     const int t = c->kv_page_tokens;
     if (t < 16 || t > 1024 || (t & (t - 1)) || c->max_positions % t || c->kv_pages < 1) return false;
@@ -2539,14 +2963,15 @@ Layout make_layout(const smi_llm_cfg* c) {
   const size_t I = c->intermediate_size;
   L.vpad = (c->vocab_size + 15) / 16 * 16;
   L.bytes[SMI_LLM_LN1] = H * 4;
-  L.bytes[SMI_LLM_WQKV] = (Q + 2 * KV) * H * 2;
+  const size_t wb = c->weights_exact ? 4 : 2;   // exact-weights mode: fp32 [N][K] row-major instead of bf16 tiles
+  L.bytes[SMI_LLM_WQKV] = (Q + 2 * KV) * H * wb;
   L.bytes[SMI_LLM_BQKV] = (Q + 2 * KV) * 4;
-  L.bytes[SMI_LLM_WO] = H * Q * 2;
+  L.bytes[SMI_LLM_WO] = H * Q * wb;
   L.bytes[SMI_LLM_LN2] = H * 4;
-  L.bytes[SMI_LLM_WGU] = 2 * I * H * 2;
-  L.bytes[SMI_LLM_WD] = H * I * 2;
+  L.bytes[SMI_LLM_WGU] = 2 * I * H * wb;
+  L.bytes[SMI_LLM_WD] = H * I * wb;
   L.bytes[SMI_LLM_FINAL_NORM] = H * 4;
-  L.bytes[SMI_LLM_LM_HEAD] = (size_t)L.vpad * H * 2;
+  L.bytes[SMI_LLM_LM_HEAD] = (size_t)L.vpad * H * wb;
   L.bytes[SMI_LLM_ROPE] = (size_t)c->max_positions * (kHeadDim / 2) * 8;
   L.bytes[SMI_LLM_TAG] = sizeof(smi_llm_arena_tag);
   size_t o = 0;
@@ -2573,6 +2998,8 @@ struct smi_llm {
   // prefill workspace for up to big_rows rows at once (allocated at the first multi-chunk prefill)
   float *bh, *bq; unsigned char *bxs_h, *bxs_attn, *bxs_act; float* bss; int big_rows;
   float *part_o, *h2;  // fused o_proj (one row): per-head partials [heads][H]; h + o_proj [H]
+  float4* dpart;       // chain-split down_proj (k_downC): [16 chains][NTh][4 m-tiles][64] chain sums
+  int dc_min;          // rows from which down_proj runs chain-split (default 5; SPARKMI_DC_MIN in the diagnostics build)
   int fuse_o;          // config allows the fused o_proj (SPARKMI_NO_FUSE_O=1 turns it off)
   RowDesc* rows;       // live decode rows [kMaxRows]
   RowDesc* plan;       // prefill plan
@@ -2617,6 +3044,7 @@ struct smi_llm {
   int pgemm_min_rows;   // prompt rows from which the prefill GEMM replaces row-grouped decode GEMMs (SPARKMI_PGEMM_MIN_ROWS)
   int pg_min[4];        // ... per kernel (QKV, o_proj, gate_up, down; SPARKMI_PGEMM_MIN_QKV / _O / _GU / _D override the common value)
   int wd_parts;         // W_down tiles are stored row-part-major (smi_llm_cfg.wd_plain == 0; include/sparkmi.h)
+  int exact;            // smi_llm_cfg.weights_exact: fp32 matrices, every GEMM on k_gemm_x (verification mode)
   int gu1_lo;           // rows from which (up to 16) gate_up runs the one-batch, three-tile shape with one m-tile (SPARKMI_GU1_LO; default 4)
   int gu1_rows;         // rows up to which gate_up runs its one-batch, three-tile shape (SPARKMI_GU1_ROWS; default 32)
   hipGraphExec_t graph; int graph_B, graph_seg, graph_ident;   // the step graph in use (owned by graph_cache)
@@ -2849,6 +3277,7 @@ int eng_create(smi_llm* L) {
   auto skip = [&](const char* m) { snprintf(E.why, sizeof(E.why), "%s", m); return SMI_OK; };
   { const char* e = smi_env("SPARKMI_ENGINE"); if (e && e[0] == '0') return skip("SPARKMI_ENGINE=0"); }
   if (c.kv_dtype != 0) return skip("f32 KV cache");
+  if (L->exact) return skip("exact-weights mode");
   if (L->paged) return skip("paged KV cache");
   if (L->tune[0] || L->tune[1] || L->tune[2] || L->tune[3]) return skip("SPARKMI_TUNE set");
   int dev = 0, ncu = 0;
@@ -2978,7 +3407,7 @@ int ensure_apart(smi_llm* L, size_t floats) {
 
 // lm_head partial columns (= persistent blocks) finalize / the sampler read for M live rows
 int lm_blocks_for(const smi_llm* L, int M) {
-  if (L->KTh > 32) return L->lm_cap;
+  if (L->KTh > 32 || L->exact) return L->lm_cap;
   return M <= 16 ? L->lm_blocks : (L->lm_blocks < 256 ? L->lm_blocks : 256);
 }
 
@@ -3038,12 +3467,84 @@ int launch_oproj(const smi_llm* L, const GemmP& p, int M, hipStream_t st) {
   }
 }
 
+// down_proj with the chains split over blocks (k_downC) and the in-order combine + RESID epilogue (k_down_comb)
+template <int TPC, int MTN>
+int launch_down_chains_t(const smi_llm* L, const DownCP& d, hipStream_t st) {
+  const size_t lds = (size_t)TPC * 12 * (d.M < MTN * 16 ? d.M : MTN * 16) * 16;
+  if (lds > 64 * 1024) {   // opt in once per instantiation and device (as in launch_gemm_kv)
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    SMI_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev >= 0 && dev < 64 && !done[dev]) {
+      SMI_HIP(hipFuncSetAttribute((const void*)k_downC<TPC, MTN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      done[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL((k_downC<TPC, MTN>), dim3(d.NT / 4 * 16), dim3(256), lds, st, d);
+  SMI_LAUNCH_CHECK();
+  hipLaunchKernelGGL((k_down_comb<MTN>), dim3(d.NT * MTN), dim3(64), 0, st, d);
+  SMI_LAUNCH_CHECK();
+  return SMI_OK;
+}
+
+int launch_down_chains(const smi_llm* L, const GemmP& p, hipStream_t st) {
+  DownCP d;
+  d.W = p.W; d.NT = p.NT; d.KT = p.KT; d.M = p.M; d.wperm = p.wperm; d.XS = p.XS; d.part = L->dpart;
+  d.Y = p.Y; d.Yin = p.Yin; d.gamma_next = p.gamma_next; d.XSout = p.XSout; d.ssout = p.ssout;
+#define SMI_DC(TPC_) (p.M <= 16 ? launch_down_chains_t<TPC_, 1>(L, d, st) : p.M <= 32 ? launch_down_chains_t<TPC_, 2>(L, d, st) : launch_down_chains_t<TPC_, 4>(L, d, st))
+  if (p.KT <= 32) return SMI_DC(2);
+  if (p.KT <= 96) return SMI_DC(6);
+  return SMI_DC(10);
+#undef SMI_DC
+}
+
+// exact-weights mode: the GEMM of launch_one's kernel `which` on k_gemm_x (p prepared as for k_gemm; W = fp32 [N][K])
+template <int PRO, int EPI>
+int launch_gemm_x(const smi_llm* L, const GemmP& p, hipStream_t st) {
+  const dim3 grid((p.NT + 3) / 4, (p.M + 15) / 16);
+  if (L->cfg.kv_dtype) hipLaunchKernelGGL((k_gemm_x<PRO, EPI, 1>), grid, dim3(256), 0, st, p, (const float*)p.W);
+  else hipLaunchKernelGGL((k_gemm_x<PRO, EPI, 0>), grid, dim3(256), 0, st, p, (const float*)p.W);
+  SMI_LAUNCH_CHECK();
+  return SMI_OK;
+}
+
 int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, float* logits, hipStream_t st) {
   const smi_llm_cfg& c = L->cfg;
   const bool fused = fuse_o_now(L, rows, M);
   GemmP p;
   memset(&p, 0, sizeof(p));
   p.M = M; p.rows = rows; p.eps = c.rms_eps; p.sspart = L->sspart; p.npart = L->NTh * 4;
+  if (L->exact && which != KATTN && which != KFIN) {
+    // verification mode: same operands, scalars and epilogues, fp32 weights, one exact fp32 FMA chain per output (k_gemm_x)
+    switch (which) {
+      case KQKV:
+        p.W = (const uint4*)sec(L, SMI_LLM_WQKV, layer); p.NT = L->NTqkv; p.KT = L->KTh; p.XS = L->xs_h;
+        p.Y = L->qbuf; p.bias = (const float*)sec(L, SMI_LLM_BQKV, layer); p.rope = (const float2*)sec(L, SMI_LLM_ROPE, 0);
+        p.kcache = kv_layer(L, L->kcache, layer); p.vcache = kv_layer(L, L->vcache, layer);
+        p.q_dim = L->Q; p.kv_dim = L->KV; p.n_kv = c.num_kv_heads; p.max_pos = c.max_positions; p.km = kv_map(L);
+        return launch_gemm_x<PRO_NORM, EPI_QKV>(L, p, st);
+      case KO:
+        p.W = (const uint4*)sec(L, SMI_LLM_WO, layer); p.NT = L->NTh; p.KT = L->KTq; p.XS = L->xs_attn; p.Y = L->h;
+        p.XSout = L->xs_h; p.gamma_next = (const float*)sec(L, SMI_LLM_LN2, layer); p.ssout = L->sspart;
+        return launch_gemm_x<PRO_PLAIN, EPI_RESID>(L, p, st);
+      case KGU:
+        p.W = (const uint4*)sec(L, SMI_LLM_WGU, layer); p.NT = L->NTgu; p.KT = L->KTh; p.XS = L->xs_h; p.XSout = L->xs_act;
+        return launch_gemm_x<PRO_NORM, EPI_SWIGLU>(L, p, st);
+      case KD:
+        p.W = (const uint4*)sec(L, SMI_LLM_WD, layer); p.NT = L->NTh; p.KT = L->KTi; p.XS = L->xs_act; p.Y = L->h;
+        p.XSout = L->xs_h; p.ssout = L->sspart;
+        p.gamma_next = layer + 1 < c.num_layers ? (const float*)sec(L, SMI_LLM_LN1, layer + 1) : (const float*)sec(L, SMI_LLM_FINAL_NORM, 0);
+        return launch_gemm_x<PRO_PLAIN, EPI_RESID>(L, p, st);
+      case KLM:
+        p.W = (const uint4*)sec(L, SMI_LLM_LM_HEAD, 0); p.NT = L->NTlm; p.KT = L->KTh; p.XS = L->xs_h;
+        p.Y = logits ? logits : (L->do_sample ? L->logits : nullptr);
+        p.V = c.vocab_size; p.pval = L->pval; p.pidx = L->pidx;
+        SMI_REQUIRE((L->NTlm + 3) / 4 <= L->lm_cap, "lm_head partial buffer too small");
+        return launch_gemm_x<PRO_NORM, EPI_LM>(L, p, st);
+    }
+  }
   switch (which) {
     case KQKV:
       p.W = (const uint4*)sec(L, SMI_LLM_WQKV, layer); p.NT = L->NTqkv; p.KT = L->KTh;
@@ -3117,6 +3618,8 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
                                               : (const float*)sec(L, SMI_LLM_FINAL_NORM, 0);
       // helpers: the next layer's QKV slices (its o_proj slices ride along: same slice size, contiguous-ish)
       if (layer + 1 < c.num_layers) p.pf = PfDesc{sec(L, SMI_LLM_WQKV, layer + 1), L->KTh * 1024, L->NTqkv, 0, (L->NTqkv + 7) / 8};
+      if (M >= L->dc_min && M <= kMaxRows && !L->tune[3] && !L->stamps_on && p.KT <= 160 && p.NT % 4 == 0)
+        return launch_down_chains(L, p, st);   // 9 .. 64 rows: the 16 chains on 16 different blocks + an in-order combine (k_downC)
       switch (L->tune[3]) {
         case 2: return launch_gemm<1, 16, 3, 4, PRO_PLAIN, EPI_RESID>(L, p, st);
         case 4: return launch_gemm<1, 8, 10, 2, PRO_PLAIN, EPI_RESID>(L, p, st);
@@ -3135,6 +3638,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       p.XS = L->xs_h;
       p.Y = logits ? logits : (L->do_sample ? L->logits : nullptr);
       p.V = c.vocab_size; p.pval = L->pval; p.pidx = L->pidx;
+      p.stamps = L->stamps_on ? L->stamps : nullptr;
       if (L->KTh <= 32) {   // persistent path: 16 rows' operand resident in the registers of a 4-wave group
         const int ngroups = (L->NTlm + 1) / 2;
         const size_t lds = (size_t)4 * 2 * 1024 + 32 * 4 + 2 * 32 * 8;
@@ -3145,9 +3649,10 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
                               // SPARKMI_TUNE2 bit 8192: the two-group kernel (k_lm<2>) for A/B
           const size_t lds32 = (size_t)4 * 2 * 2 * 1024 + 32 * 4 + 2 * 32 * 8 + (size_t)L->KTh * 12 * 16 * 16;
           for (int m0 = 0; m0 < M; m0 += 32) {
-            if (!(L->tune2 & 8192) && lds32 <= 150 * 1024)
-              hipLaunchKernelGGL(k_lm32, dim3(lm_blocks_for(L, M)), dim3(256), lds32, st, p, ngroups, m0);
-            else
+            if (!(L->tune2 & 8192) && lds32 <= 150 * 1024) {
+              if (L->KTh <= 28) hipLaunchKernelGGL(k_lm32<7>, dim3(lm_blocks_for(L, M)), dim3(256), lds32, st, p, ngroups, m0);
+              else hipLaunchKernelGGL(k_lm32<8>, dim3(lm_blocks_for(L, M)), dim3(256), lds32, st, p, ngroups, m0);
+            } else
               hipLaunchKernelGGL(k_lm<2>, dim3(lm_blocks_for(L, M)), dim3(512), 2 * lds, st, p, ngroups, m0);
             SMI_LAUNCH_CHECK();
           }
@@ -3175,7 +3680,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       f.nblk = lm_blocks_for(L, M);
       f.rows = L->rows; f.hist = L->hist; f.count = L->count; f.finished = L->finished; f.step = L->step;
       f.ctl = L->ctl; f.Wlm = (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0); f.h = L->h; f.max_steps = L->max_steps;
-      f.gamma0 = (const float*)sec(L, SMI_LLM_LN1, 0); f.xs = L->xs_h; f.sspart = L->sspart; f.npart = L->NTh * 4;
+      f.gamma0 = (const float*)sec(L, SMI_LLM_LN1, 0); f.xs = L->xs_h; f.sspart = L->sspart; f.npart = L->NTh * 4; f.exact = L->exact;
       hipLaunchKernelGGL(k_finalize, dim3(M), dim3(256), 0, st, f);
       SMI_LAUNCH_CHECK();
       return SMI_OK;
@@ -3292,7 +3797,7 @@ int ensure_big(smi_llm* L, int rows) {
 
 int launch_embed(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
   hipLaunchKernelGGL(k_embed, dim3((M + 3) / 4), dim3(256), 0, st, (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0), L->KTh, rows, M,
-                     (const float*)sec(L, SMI_LLM_LN1, 0), L->h, L->xs_h, L->sspart, L->NTh * 4);
+                     (const float*)sec(L, SMI_LLM_LN1, 0), L->h, L->xs_h, L->sspart, L->NTh * 4, L->exact);
   SMI_LAUNCH_CHECK();
   return SMI_OK;
 }
@@ -3371,6 +3876,8 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
     SMI_HIP(hipMemcpy(&tag, (const unsigned char*)arena_dev + lay.off[SMI_LLM_TAG], sizeof(tag), hipMemcpyDeviceToHost));
     SMI_REQUIRE(memcmp(tag.magic, "SMIARENA", 8) == 0, "smi_llm_create: the arena carries no layout tag (section SMI_LLM_TAG): not packed for this library, or for other dimensions");
     SMI_REQUIRE(tag.abi_version == SMI_ABI_VERSION, "smi_llm_create: arena packed for ABI %d, this library is ABI %d", tag.abi_version, SMI_ABI_VERSION);
+    SMI_REQUIRE(tag.weights_exact == cfg->weights_exact, "smi_llm_create: the arena holds %s matrices, the config asks for %s (smi_llm_cfg.weights_exact)",
+                tag.weights_exact ? "fp32 (exact-weights)" : "bf16-tiled", cfg->weights_exact ? "fp32" : "bf16 tiles");
     SMI_REQUIRE(tag.wd_plain == cfg->wd_plain, "smi_llm_create: the arena's W_down tiles are packed %s, the config says %s (smi_llm_cfg.wd_plain)",
                 tag.wd_plain ? "in the plain tile order" : "row-part-major", cfg->wd_plain ? "plain" : "row-part-major");
     SMI_REQUIRE(tag.vocab_size == cfg->vocab_size && tag.hidden_size == cfg->hidden_size && tag.num_layers == cfg->num_layers &&
@@ -3400,7 +3907,10 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   { const char* e = smi_env("SPARKMI_GRAPH_STEPS"); L->graph_steps = e ? atoi(e) : 8; if (L->graph_steps < 1 || L->graph_steps > 32) L->graph_steps = 8; }
   { const char* e = smi_env("SPARKMI_PF_INLINE"); L->pf_inline = !(e && e[0] == '0'); }
   { const char* e = smi_env("SPARKMI_PF_QKV"); L->pf_qkv_eighths = e ? atoi(e) : 2; if (L->pf_qkv_eighths < 0 || L->pf_qkv_eighths > 8) L->pf_qkv_eighths = 2; }
-  L->part_o = nullptr; L->h2 = nullptr;
+  L->part_o = nullptr; L->h2 = nullptr; L->dpart = nullptr;
+  // rows from which down_proj runs chain-split (k_downC): graph step at 0.5B, same box (profiles/r04_batch_ab.txt): 4 rows 641 (k_downS) vs
+  // 692 us (chains), 8 rows 728 vs 713, 16 rows 790 (k_gemm<.., H = 4>) vs 744, 32 rows 892 vs 859
+  { const char* e = smi_env("SPARKMI_DC_MIN"); L->dc_min = e ? atoi(e) : 5; }
   L->fuse_o = !smi_env("SPARKMI_NO_FUSE_O") && (cfg->num_heads == 14 || cfg->num_heads == 4) && cfg->num_heads <= kMaxOHeads &&
               L->NTh % kFuseQB == 0 && L->NTh / kFuseQB <= kAttnWaves * kFuseOT && L->KTh * 8 <= 256;
   { const char* e = smi_env("SPARKMI_TUNE2"); L->tune2 = e ? atoi(e) : 0; }
@@ -3416,6 +3926,8 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   { const char* e = smi_env("SPARKMI_GU1_ROWS"); L->gu1_rows = e ? atoi(e) : 32; }
   { const char* e = smi_env("SPARKMI_GU1_LO"); L->gu1_lo = e ? atoi(e) : 4; }
   L->wd_parts = cfg->wd_plain ? 0 : 1;   // the arena's W_down tile order comes with its config (never from the environment)
+  L->exact = cfg->weights_exact;
+  if (L->exact) L->fuse_o = 0;           // (the fused o_proj reads bf16 tiles)
   L->pf_tiles = nullptr; L->pf_tiles_cap = 0; L->pf_ntiles = 0;
   { const char* e = smi_env("SPARKMI_ATTN_PF2"); L->attn_pf2 = !(e && e[0] == '0'); }
   L->graph = nullptr; L->graph_B = 0; L->graph_seg = 1; L->graph_ident = 1; L->plan = nullptr; L->plan_cap = 0; L->B = 0; L->started = 0; L->ctl = nullptr; L->admit_seq = 0; memset(&L->hctl, 0, sizeof(L->hctl));
@@ -3446,6 +3958,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   SMI_ALLOC(L->sspart, (size_t)kMaxRows * L->NTh * 4 * 4);
   SMI_ALLOC(L->part_o, (size_t)kMaxOHeads * L->H * 4);
   SMI_ALLOC(L->h2, (size_t)L->H * 4);
+  SMI_ALLOC(L->dpart, (size_t)16 * L->NTh * 4 * 64 * 16);
   SMI_ALLOC(L->rows, kMaxRows * sizeof(RowDesc));
   SMI_ALLOC(L->pval, (size_t)L->lm_cap * kMaxRows * 4);
   SMI_ALLOC(L->pidx, (size_t)L->lm_cap * kMaxRows * 4);
@@ -3485,7 +3998,8 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   }
   // k_lm32 stages 16 rows' operand triples in LDS (86 KB at K = 896): opt in to the large dynamic window here, once per
   // handle (= per device), outside any stream capture
-  if (hipFuncSetAttribute((const void*)k_lm32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
+  if (hipFuncSetAttribute((const void*)k_lm32<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
+  if (hipFuncSetAttribute((const void*)k_lm32<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
   if (hipEventCreate(&L->ev0) != hipSuccess || hipEventCreate(&L->ev1) != hipSuccess) {
     smi_set_error("hipEventCreate failed");
     smi_llm_destroy(L);
@@ -3514,7 +4028,7 @@ int smi_llm_destroy(smi_llm* L) {
   if (!L) return SMI_OK;
   graphs_flush(L);
   eng_destroy(L);
-  void* ptrs[] = {L->h, L->qbuf, L->xs_h, L->xs_attn, L->xs_act, L->sspart, L->part_o, L->h2, L->rows, L->plan, L->pf_tiles, L->pval, L->pidx, L->hist,
+  void* ptrs[] = {L->h, L->qbuf, L->xs_h, L->xs_attn, L->xs_act, L->sspart, L->part_o, L->h2, L->dpart, L->rows, L->plan, L->pf_tiles, L->pval, L->pidx, L->hist,
                   L->count, L->finished, L->step, L->ctl, L->ptab, L->kcache, L->vcache, L->logits, L->tok, L->cand_v, L->cand_i, L->cand_n, L->stamps, L->bh, L->bq, L->bxs_h, L->bxs_attn, L->bxs_act, L->bss, L->apart};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
@@ -3583,7 +4097,7 @@ static int prefill_prompts(smi_llm* L, const int64_t* ids, const int32_t* lens, 
   SMI_HIP(hipMemcpyAsync(L->plan, L->host_rows.data(), L->host_rows.size() * sizeof(RowDesc), hipMemcpyHostToDevice, st));
   // measured (tools/prefill_time.py, profiles/README.md): 32-row chunks ~1.4 ms each; row-grouped decode GEMMs
   // ~1.5 ms + 9 us/row; the prefill GEMM ~15 ms + 5 us/row (crossover near 3000 rows)
-  if (total > (size_t)kMaxRows && !smi_env("SPARKMI_PREFILL_CHUNKS")) {
+  if (total > (size_t)kMaxRows && !smi_env("SPARKMI_PREFILL_CHUNKS") && !L->exact) {   // (exact-weights mode: 64-row chunks through k_gemm_x)
     // many prompt rows: whole groups of up to kBigRows rows through the prefill GEMM (k_pgemm)
     constexpr size_t kBigRows = 4096;
     if ((rc = ensure_big(L, (int)(total < kBigRows ? total : kBigRows)))) return rc;
@@ -3614,7 +4128,7 @@ static int prefill_prompts(smi_llm* L, const int64_t* ids, const int32_t* lens, 
         L->pf_ntiles = (int)T.size();
       }
       hipLaunchKernelGGL(k_embed, dim3((M + 3) / 4), dim3(256), 0, st, (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0), L->KTh, rows, M,
-                         (const float*)sec(L, SMI_LLM_LN1, 0), L->bh, L->bxs_h, L->bss, M < L->pg_min[3] ? L->NTh * 4 : L->NTh);
+                         (const float*)sec(L, SMI_LLM_LN1, 0), L->bh, L->bxs_h, L->bss, M < L->pg_min[3] ? L->NTh * 4 : L->NTh, 0);
       SMI_LAUNCH_CHECK();
       if ((rc = launch_layers_big(L, rows, M, st))) return rc;
     }
@@ -4281,14 +4795,15 @@ int smi_llm_debug_read(smi_llm* L, int what, void* out_host, size_t cap, size_t*
   SMI_REQUIRE(L && out_host && got, "smi_llm_debug_read: null argument");
   const void* src = nullptr;
   size_t n = 0;
+  const size_t R = L->B > 0 ? (size_t)L->B : 1;   // buffers 0..4 and 6 hold one entry per live row
   switch (what) {
-    case 0: src = L->qbuf; n = (size_t)L->Q * 4; break;
-    case 1: src = L->xs_attn; n = (size_t)L->Q * 6; break;
-    case 2: src = L->xs_act; n = (size_t)L->I * 6; break;
-    case 3: src = L->xs_h; n = (size_t)L->H * 6; break;
-    case 4: src = L->h; n = (size_t)L->H * 4; break;
+    case 0: src = L->qbuf; n = R * L->Q * 4; break;
+    case 1: src = L->xs_attn; n = R * L->Q * 6; break;
+    case 2: src = L->xs_act; n = R * L->I * 6; break;
+    case 3: src = L->xs_h; n = R * L->H * 6; break;
+    case 4: src = L->h; n = R * L->H * 4; break;
     case 5: src = L->eng.gran; n = L->eng.gran ? (size_t)2 * L->eng.gran_per_buf * 8 : 0; break;
-    case 6: src = L->sspart; n = (size_t)L->H; break;
+    case 6: src = L->sspart; n = R * L->H; break;
     case 7: src = L->kcache; n = (size_t)L->cfg.max_positions * kHeadDim * 2; break;
     case 8: src = L->h2; n = (size_t)L->H * 4; break;
     default: smi_set_error("smi_llm_debug_read: what=%d", what); return SMI_EINVAL;
@@ -4297,6 +4812,116 @@ int smi_llm_debug_read(smi_llm* L, int what, void* out_host, size_t cap, size_t*
   SMI_HIP(hipDeviceSynchronize());
   SMI_HIP(hipMemcpy(out_host, src, n, hipMemcpyDeviceToHost));
   *got = n;
+  return SMI_OK;
+}
+
+// ---- op-level tests (sparkmi_debug.h): one layer's kernels, stage by stage, on caller-given rows -- through launch_one, i.e. the
+// launch builders, kernel choices and epilogue fusions of a real step
+static int debug_kv_check(const smi_llm* L, int layer, int slot, int pos0, int n) {
+  SMI_REQUIRE(L && !L->paged, "debug KV access needs a contiguous KV cache (kv_page_tokens = 0)");
+  SMI_REQUIRE(layer >= 0 && layer < L->cfg.num_layers && slot >= 0 && slot < L->cfg.max_slots && pos0 >= 0 && n >= 0 &&
+              pos0 + n <= L->cfg.max_positions, "debug KV access: layer %d slot %d positions %d..%d out of range", layer, slot, pos0, pos0 + n);
+  return SMI_OK;
+}
+
+// k_host / v_host [n][num_kv_heads][64] fp32 in transformers' dim order, keys ALREADY rotated (what a KV cache holds); written to
+// positions pos0 .. pos0 + n - 1 of `slot` in the cache's own dtype and row order (K: RoPE pairs adjacent, include/sparkmi.h)
+int smi_llm_debug_set_kv(smi_llm* L, int layer, int slot, int pos0, int n, const float* k_host, const float* v_host) {
+  { const int rc = debug_kv_check(L, layer, slot, pos0, n); if (rc) return rc; }
+  SMI_REQUIRE(k_host && v_host, "smi_llm_debug_set_kv: null argument");
+  SMI_HIP(hipDeviceSynchronize());
+  const int nkv = L->cfg.num_kv_heads, f32 = L->cfg.kv_dtype;
+  const size_t esz = f32 ? 4 : 2;
+  std::vector<unsigned char> buf((size_t)n * kHeadDim * esz);
+  for (int isv = 0; isv < 2; ++isv)
+    for (int kh = 0; kh < nkv; ++kh) {
+      for (int t = 0; t < n; ++t)
+        for (int i = 0; i < kHeadDim; ++i) {
+          const int d = isv ? i : (i >> 1) + 32 * (i & 1);   // K rows sit as RoPE pairs (0, 32, 1, 33, ...)
+          const float x = (isv ? v_host : k_host)[((size_t)t * nkv + kh) * kHeadDim + d];
+          if (f32) ((float*)buf.data())[(size_t)t * kHeadDim + i] = x;
+          else {
+            uint32_t u; memcpy(&u, &x, 4);
+            ((uint16_t*)buf.data())[(size_t)t * kHeadDim + i] = (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+          }
+        }
+      unsigned char* base = (unsigned char*)kv_layer(L, isv ? L->vcache : L->kcache, layer);
+      const size_t row0 = ((size_t)slot * nkv + kh) * L->cfg.max_positions + pos0;
+      SMI_HIP(hipMemcpy(base + row0 * kHeadDim * esz, buf.data(), buf.size(), hipMemcpyHostToDevice));
+    }
+  return SMI_OK;
+}
+
+// the reverse: positions pos0 .. pos0 + n - 1 of `slot` as fp32 [n][num_kv_heads][64] in transformers' dim order
+int smi_llm_debug_get_kv(smi_llm* L, int layer, int slot, int pos0, int n, float* k_host, float* v_host) {
+  { const int rc = debug_kv_check(L, layer, slot, pos0, n); if (rc) return rc; }
+  SMI_REQUIRE(k_host && v_host, "smi_llm_debug_get_kv: null argument");
+  SMI_HIP(hipDeviceSynchronize());
+  const int nkv = L->cfg.num_kv_heads, f32 = L->cfg.kv_dtype;
+  const size_t esz = f32 ? 4 : 2;
+  std::vector<unsigned char> buf((size_t)n * kHeadDim * esz);
+  for (int isv = 0; isv < 2; ++isv)
+    for (int kh = 0; kh < nkv; ++kh) {
+      const unsigned char* base = (const unsigned char*)kv_layer(L, isv ? L->vcache : L->kcache, layer);
+      const size_t row0 = ((size_t)slot * nkv + kh) * L->cfg.max_positions + pos0;
+      SMI_HIP(hipMemcpy(buf.data(), base + row0 * kHeadDim * esz, buf.size(), hipMemcpyDeviceToHost));
+      for (int t = 0; t < n; ++t)
+        for (int i = 0; i < kHeadDim; ++i) {
+          const int d = isv ? i : (i >> 1) + 32 * (i & 1);
+          float x;
+          if (f32) x = ((const float*)buf.data())[(size_t)t * kHeadDim + i];
+          else { const uint32_t u = (uint32_t)((const uint16_t*)buf.data())[(size_t)t * kHeadDim + i] << 16; memcpy(&x, &u, 4); }
+          (isv ? v_host : k_host)[((size_t)t * nkv + kh) * kHeadDim + d] = x;
+        }
+    }
+  return SMI_OK;
+}
+
+// rows_host: M (slot, pos) pairs; hidden_host [M][hidden] fp32 = the residual rows entering `layer`.  Runs that layer's kernels up
+// to and including `stage` (0 QKV + bias + RoPE + KV append, 1 attention, 2 o_proj + residual, 3 gate_up + SwiGLU, 4 down_proj +
+// residual) for those rows through launch_one; results are then read with smi_llm_debug_read / smi_llm_debug_get_kv.  Ends the
+// current generation (the handle needs a prefill before it generates again).
+int smi_llm_debug_layer(smi_llm* L, int layer, int M, const int32_t* rows_host, const float* hidden_host, int stage) {
+  SMI_REQUIRE(L && rows_host && hidden_host && M >= 1 && M <= kMaxRows, "smi_llm_debug_layer: bad argument");
+  SMI_REQUIRE(layer >= 0 && layer < L->cfg.num_layers && stage >= 0 && stage <= 4, "smi_llm_debug_layer: layer %d stage %d", layer, stage);
+  SMI_REQUIRE(!L->paged, "smi_llm_debug_layer needs a contiguous KV cache");
+  SMI_HIP(hipDeviceSynchronize());
+  graphs_flush(L);
+  std::vector<RowDesc> rows(kMaxRows, RowDesc{0, 0, 0, 0});
+  int maxpos = 0, ident = 1;
+  for (int m = 0; m < M; ++m) {
+    const int sl = rows_host[2 * m], ps = rows_host[2 * m + 1];
+    SMI_REQUIRE(sl >= 0 && sl < L->cfg.max_slots && ps >= 0 && ps < L->cfg.max_positions, "smi_llm_debug_layer: row %d = (slot %d, pos %d)", m, sl, ps);
+    rows[m] = RowDesc{sl, ps, 0, 0};
+    maxpos = ps > maxpos ? ps : maxpos;
+    ident &= sl == m;
+  }
+  SMI_HIP(hipMemcpy(L->rows, rows.data(), rows.size() * sizeof(RowDesc), hipMemcpyHostToDevice));
+  L->B = M; L->identity_slots = ident; L->session = 0; L->started = 0;
+  L->attn_seg = segs_for(maxpos + 1);
+  float* src = nullptr;
+  SMI_HIP(hipMalloc((void**)&src, (size_t)M * L->H * 4));
+  int rc = SMI_OK;
+  if (hipMemcpy(src, hidden_host, (size_t)M * L->H * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = SMI_EHIP; smi_set_error("smi_llm_debug_layer: upload failed"); }
+  if (rc == SMI_OK) {
+    hipLaunchKernelGGL(k_load_hidden, dim3((M + 3) / 4), dim3(256), 0, 0, src, L->KTh, M, (const float*)sec(L, SMI_LLM_LN1, layer), L->h, L->xs_h,
+                       L->sspart, L->NTh * 4);
+    if (hipGetLastError() != hipSuccess) { rc = SMI_EHIP; smi_set_error("smi_llm_debug_layer: k_load_hidden launch failed"); }
+  }
+  const bool fused = fuse_o_now(L, L->rows, M);
+  const int last = (fused && stage == 2) ? KGU : KQKV + stage;   // one fused row: h + o_proj is formed by gate_up's prologue (read buffer 8)
+  for (int k = KQKV; k <= last && rc == SMI_OK; ++k) rc = launch_one(L, k, layer, L->rows, M, nullptr, 0);
+  if (hipDeviceSynchronize() != hipSuccess && rc == SMI_OK) { rc = SMI_EHIP; smi_set_error("smi_llm_debug_layer: kernels failed: %s", hipGetErrorString(hipGetLastError())); }
+  (void)hipFree(src);
+  return rc;
+}
+
+// Diagnostics: the stamp buffer of the last smi_llm_debug_stamps launch as it is (10 ns ticks of s_memrealtime; k_lm32 leaves
+// four stamps per streamed group of its block 0: group start, MFMAs issued + partial sums written, reduce barrier passed, group done)
+int smi_llm_debug_raw_stamps(smi_llm* L, unsigned long long* out, int n) {
+  SMI_REQUIRE(L && out && n > 0 && n <= 4096 * 8, "smi_llm_debug_raw_stamps: bad argument");
+  SMI_HIP(hipDeviceSynchronize());
+  SMI_HIP(hipMemcpy(out, L->stamps, (size_t)n * 8, hipMemcpyDeviceToHost));
   return SMI_OK;
 }
 

@@ -29,7 +29,8 @@ class LLMCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "vocab_size", "hidden_size", "num_layers", "num_heads", "num_kv_heads", "head_dim",
         "intermediate_size", "max_slots", "max_positions", "kv_dtype", "use_graph")] + [("rms_eps", C.c_float),
-                                                                                        ("kv_page_tokens", C.c_int32), ("kv_pages", C.c_int32), ("wd_plain", C.c_int32)]
+                                                                                        ("kv_page_tokens", C.c_int32), ("kv_pages", C.c_int32), ("wd_plain", C.c_int32),
+                                                                                        ("weights_exact", C.c_int32)]
 
 
 class VocCfg(C.Structure):
@@ -69,7 +70,7 @@ class LLMArenaTag(C.Structure):
     """smi_llm_arena_tag: how an arena was packed (section LLM_TAG); smi_llm_create checks it against the config."""
     _fields_ = [("magic", C.c_char * 8)] + [(n, C.c_int32) for n in (
         "abi_version", "wd_plain", "vocab_size", "hidden_size", "num_layers", "num_heads", "num_kv_heads", "intermediate_size",
-        "max_positions")] + [("reserved", C.c_int32 * 53)]
+        "max_positions", "weights_exact")] + [("reserved", C.c_int32 * 52)]
 
 # every symbol include/sparkmi.h declares: (name, restype, argtypes)
 _VP, _I, _SZ = C.c_void_p, C.c_int, C.c_size_t
@@ -131,7 +132,11 @@ DEBUG_SYMBOLS = {
     "smi_llm_engine_stamps": (_I, [_VP, _P(C.c_double), _I]),
     "smi_llm_debug_hidden": (_I, [_VP, _P(C.c_float), _I]),
     "smi_llm_debug_read": (_I, [_VP, _I, _VP, _SZ, _P(_SZ)]),
+    "smi_llm_debug_raw_stamps": (_I, [_VP, _P(C.c_uint64), _I]),
     "smi_llm_debug_sample": (_I, [_VP, _P(C.c_float), _I, C.c_uint64, _I, _P(C.c_int32)]),
+    "smi_llm_debug_set_kv": (_I, [_VP, _I, _I, _I, _I, _P(C.c_float), _P(C.c_float)]),
+    "smi_llm_debug_get_kv": (_I, [_VP, _I, _I, _I, _I, _P(C.c_float), _P(C.c_float)]),
+    "smi_llm_debug_layer": (_I, [_VP, _I, _I, _P(C.c_int32), _P(C.c_float), _I]),
 }
 
 DIAG_PATH = LIB_PATH.with_name("libsparkmi_diag.so")

@@ -104,8 +104,11 @@ def rope_table(cfg: LLMConfig, max_positions: int) -> np.ndarray:
 
 
 def llm_cfg_struct(cfg: LLMConfig, max_slots: int, max_positions: int, kv_dtype: str,
-                   use_graph: bool, kv_page_tokens: int = 0, kv_pages: int = 0) -> _lib.LLMCfg:
+                   use_graph: bool, kv_page_tokens: int = 0, kv_pages: int = 0, weights_exact: bool = False) -> _lib.LLMCfg:
+    """``weights_exact``: the verification mode of include/sparkmi.h -- fp32 matrices in the arena, exact fp32 GEMMs (for
+    checkpoints saved in fp32, which the bf16 arena would round)."""
     return _lib.LLMCfg(
+        weights_exact=int(bool(weights_exact)),
         vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_layers=cfg.num_hidden_layers,
         num_heads=cfg.num_attention_heads, num_kv_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
         intermediate_size=cfg.intermediate_size, max_slots=max_slots, max_positions=max_positions,
@@ -135,6 +138,17 @@ def pack_llm_arena(cfg: LLMConfig, weights: Mapping[str, np.ndarray], cs: _lib.L
         arena[off.value: off.value + raw.size] = raw
 
     f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+
+    def pack(w, report, name, row_parts=False):
+        """bf16 MFMA tiles (default) or, in the exact-weights mode, the matrix as it is: fp32 [N padded to 16][K] row-major"""
+        if not cs.weights_exact:
+            return pack_tiles(w, report, name, row_parts=row_parts)
+        n, k = w.shape
+        if k % 32:
+            raise ValueError(f"K={k} must be a multiple of 32")
+        npad = (n + 15) // 16 * 16
+        return np.ascontiguousarray(w if npad == n else np.concatenate([w, np.zeros((npad - n, k), np.float32)], axis=0))
+
     pq = rope_pair_perm(cfg.num_attention_heads, cfg.head_dim)
     pk = rope_pair_perm(cfg.num_key_value_heads, cfg.head_dim)
     po = o_proj_col_perm(cfg.num_attention_heads, cfg.head_dim)
@@ -143,26 +157,26 @@ def pack_llm_arena(cfg: LLMConfig, weights: Mapping[str, np.ndarray], cs: _lib.L
         wq, wk, wv = (f32(weights[p + f"self_attn.{n}_proj.weight"]) for n in "qkv")
         bq, bk, bv = (f32(weights[p + f"self_attn.{n}_proj.bias"]) for n in "qkv")
         put(_lib.LLM_LN1, i, f32(weights[p + "input_layernorm.weight"]))
-        put(_lib.LLM_WQKV, i, pack_tiles(np.concatenate([wq[pq], wk[pk], wv], axis=0), rep, p + "self_attn.qkv"))
+        put(_lib.LLM_WQKV, i, pack(np.concatenate([wq[pq], wk[pk], wv], axis=0), rep, p + "self_attn.qkv"))
         put(_lib.LLM_BQKV, i, np.concatenate([bq[pq], bk[pk], bv]))
-        put(_lib.LLM_WO, i, pack_tiles(f32(weights[p + "self_attn.o_proj.weight"])[:, po], rep, p + "self_attn.o_proj"))
+        put(_lib.LLM_WO, i, pack(f32(weights[p + "self_attn.o_proj.weight"])[:, po], rep, p + "self_attn.o_proj"))
         put(_lib.LLM_LN2, i, f32(weights[p + "post_attention_layernorm.weight"]))
         g, u = f32(weights[p + "mlp.gate_proj.weight"]), f32(weights[p + "mlp.up_proj.weight"])
         gu = np.empty((2 * g.shape[0], g.shape[1]), np.float32)
         gu[0::2], gu[1::2] = g, u
-        put(_lib.LLM_WGU, i, pack_tiles(gu, rep, p + "mlp.gate_up"))
-        put(_lib.LLM_WD, i, pack_tiles(f32(weights[p + "mlp.down_proj.weight"]), rep, p + "mlp.down_proj", row_parts=not cs.wd_plain))
+        put(_lib.LLM_WGU, i, pack(gu, rep, p + "mlp.gate_up"))
+        put(_lib.LLM_WD, i, pack(f32(weights[p + "mlp.down_proj.weight"]), rep, p + "mlp.down_proj", row_parts=not cs.wd_plain))
     put(_lib.LLM_FINAL_NORM, 0, f32(weights["model.norm.weight"]))
     head = "model.embed_tokens.weight" if cfg.tie_word_embeddings else "lm_head.weight"
     if not cfg.tie_word_embeddings:
         raise NotImplementedError("untied lm_head: the kernels gather embeddings from the lm_head tiles")
-    put(_lib.LLM_LM_HEAD, 0, pack_tiles(f32(weights[head]), rep, head))
+    put(_lib.LLM_LM_HEAD, 0, pack(f32(weights[head]), rep, head))
     put(_lib.LLM_ROPE, 0, rope_table(cfg, cs.max_positions))
     # how this arena was packed travels WITH it: smi_llm_create compares the tag with the config it is handed (an arena packed
     # under one SPARKMI_WD_PLAIN setting and re-used under another is an error, not wrong logits)
     tag = _lib.LLMArenaTag(magic=b"SMIARENA", abi_version=_lib.ABI_VERSION, wd_plain=cs.wd_plain, vocab_size=cs.vocab_size,
                            hidden_size=cs.hidden_size, num_layers=cs.num_layers, num_heads=cs.num_heads, num_kv_heads=cs.num_kv_heads,
-                           intermediate_size=cs.intermediate_size, max_positions=cs.max_positions)
+                           intermediate_size=cs.intermediate_size, max_positions=cs.max_positions, weights_exact=cs.weights_exact)
     put(_lib.LLM_TAG, 0, np.frombuffer(bytes(tag), dtype=np.uint8))
     if rep.inexact:
         msg = (f"{rep.inexact} LLM matrices are not bf16-representable (an fp32 checkpoint?): rounded to bf16 for the "

@@ -47,11 +47,14 @@ class SparkLLM:
                  device: Union[str, torch.device] = "cuda:0", max_slots: int = 1,
                  max_positions: int = 4096, kv_dtype: str = "bf16", use_graph: bool = True,
                  arena: Optional[torch.Tensor] = None, eos_token_ids: EosLike = None,
-                 kv_page_tokens: int = 0, kv_pages: int = 0, diag: bool = False):
+                 kv_page_tokens: int = 0, kv_pages: int = 0, diag: bool = False, weights_exact: bool = False):
         """``eos_token_ids``: the model's default stop ids (``generation_config.json``; see
         ``eos_ids_from_generation_config``).  ``generate()`` falls back to them when the caller passes none, like HF.
         ``kv_page_tokens`` / ``kv_pages``: paged KV cache -- a pool of ``kv_pages`` pages of ``kv_page_tokens`` tokens
         shared by the ``max_slots`` sequences instead of ``max_positions`` reserved tokens per slot (sparkmi.h).
+        ``weights_exact``: the verification mode of ``smi_llm_cfg.weights_exact`` -- the arena keeps the matrices in fp32 and every
+        GEMM is an exact fp32 chain, so a checkpoint SAVED in fp32 (the published Spark-TTS-0.5B LLM is) gives the fp32 PyTorch
+        CPU path's tokens instead of those of its bf16 rounding; opt-in, ~4x slower, 2x the weight bytes.
         ``diag``: put the handle on ``libsparkmi_diag.so`` (timing probes, scratch dumps, SPARKMI_* switches, the one-row engine:
         ``include/sparkmi_debug.h``) instead of the product library -- tools, bench probes and tests only."""
         cfg.validate()
@@ -66,7 +69,7 @@ class SparkLLM:
         torch.cuda.set_device(self.device)
         _lib.require_gfx950()
         self.max_slots, self.max_positions = max_slots, max_positions
-        self._cs = llm_cfg_struct(cfg, max_slots, max_positions, kv_dtype, use_graph, kv_page_tokens, kv_pages)
+        self._cs = llm_cfg_struct(cfg, max_slots, max_positions, kv_dtype, use_graph, kv_page_tokens, kv_pages, weights_exact)
         if arena is None:
             host = pack_llm_arena(cfg, weights, self._cs)
             arena = torch.from_numpy(host).to(self.device)
@@ -405,6 +408,69 @@ class SparkLLM:
         self._lib.check(self._lib.smi_llm_debug_read(self._h, int(what), buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(got)),
                    "smi_llm_debug_read")
         return buf[: got.value].copy()
+
+    # ---- op-level entries (include/sparkmi_debug.h: smi_llm_debug_layer / _set_kv / _get_kv)
+    def debug_set_kv(self, layer: int, slot: int, k: np.ndarray, v: np.ndarray, pos0: int = 0) -> None:
+        """k, v: (n, num_kv_heads, 64) fp32 in transformers' dim order (keys already rotated) -> cache positions pos0.."""
+        self._need_diag("debug_set_kv")
+        k = np.ascontiguousarray(k, dtype=np.float32)
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        assert k.shape == v.shape == (k.shape[0], self.cfg.num_key_value_heads, 64)
+        fp = C.POINTER(C.c_float)
+        self._lib.check(self._lib.smi_llm_debug_set_kv(self._h, layer, slot, pos0, k.shape[0], k.ctypes.data_as(fp), v.ctypes.data_as(fp)),
+                        "smi_llm_debug_set_kv")
+
+    def debug_get_kv(self, layer: int, slot: int, pos0: int, n: int):
+        self._need_diag("debug_get_kv")
+        k = np.zeros((n, self.cfg.num_key_value_heads, 64), dtype=np.float32)
+        v = np.zeros_like(k)
+        fp = C.POINTER(C.c_float)
+        self._lib.check(self._lib.smi_llm_debug_get_kv(self._h, layer, slot, pos0, n, k.ctypes.data_as(fp), v.ctypes.data_as(fp)),
+                        "smi_llm_debug_get_kv")
+        return k, v
+
+    @staticmethod
+    def _from_triples(raw: np.ndarray, K: int, M: int) -> np.ndarray:
+        """[K / 32][3][4][M][8] bf16 (hi, mid, lo planes of an exact split) -> (M, K) fp32, k = 32 * tile + 8 * k8 + e."""
+        from .weights import bf16_bits_to_f32
+        a = bf16_bits_to_f32(raw.view(np.uint16)).reshape(K // 32, 3, 4, M, 8)
+        x = (a[:, 0] + a[:, 1]) + a[:, 2]                       # exact: the three terms do not overlap
+        return np.ascontiguousarray(x.transpose(2, 0, 1, 3)).reshape(M, K)
+
+    def debug_layer(self, layer: int, rows, hidden: np.ndarray, stage: int) -> dict:
+        """One layer's kernels up to ``stage`` on caller rows (``rows``: (slot, pos) pairs; ``hidden``: (M, hidden) fp32) through
+        the step's own launch builders; returns that stage's outputs in transformers' layouts:
+        0 {"q" (M, heads, 64), "k" / "v" (M, kv heads, 64)}, 1 {"attn" (M, heads * 64)}, 2 {"h" (M, hidden)},
+        3 {"act" (M, intermediate)}, 4 {"h" (M, hidden)}."""
+        self._need_diag("debug_layer")
+        c = self.cfg
+        rows = np.ascontiguousarray(np.asarray(rows, dtype=np.int32).reshape(-1, 2))
+        M = rows.shape[0]
+        hidden = np.ascontiguousarray(hidden, dtype=np.float32)
+        assert hidden.shape == (M, c.hidden_size)
+        self._lib.check(self._lib.smi_llm_debug_layer(self._h, layer, M, rows.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                      hidden.ctypes.data_as(C.POINTER(C.c_float)), stage), "smi_llm_debug_layer")
+        nh, Q = c.num_attention_heads, c.num_attention_heads * 64
+        unpair = (np.arange(64) >> 1) + 32 * (np.arange(64) & 1)          # kernel row i of a head holds transformers' dim unpair[i]
+        if stage == 0:
+            qk = self.debug_read(0).view(np.float32).reshape(M, nh, 64)
+            q = np.empty_like(qk)
+            q[:, :, unpair] = qk
+            kv = [self.debug_get_kv(layer, int(s), int(p), 1) for s, p in rows]
+            return {"q": q, "k": np.concatenate([k for k, _ in kv]), "v": np.concatenate([v for _, v in kv])}
+        if stage == 1:
+            t = self._from_triples(self.debug_read(1), Q, M).reshape(M, 2, nh, 32)     # k tile = half * heads + head
+            return {"attn": np.ascontiguousarray(t.transpose(0, 2, 1, 3)).reshape(M, Q)}
+        if stage == 3:
+            return {"act": self._from_triples(self.debug_read(2), c.intermediate_size, M)}
+        fused_one = stage == 2 and M == 1 and self.debug_fused_o()
+        return {"h": self.debug_read(8 if fused_one else 4).view(np.float32).reshape(M, c.hidden_size)[:M].copy()}
+
+    def debug_fused_o(self) -> bool:
+        """One live row takes the fused attention + o_proj kernel (smi_llm.hip: fuse_o_now) unless SPARKMI_NO_FUSE_O=1 was set
+        when the engine was built or the head count has no fused instantiation."""
+        import os
+        return os.environ.get("SPARKMI_NO_FUSE_O") is None and self.cfg.num_attention_heads in (4, 14)
 
     def debug_sample(self, logits_row: Optional[np.ndarray], n_rows: int, seed: int, use_bound: bool = True) -> np.ndarray:
         """The device sampler alone on a caller's logits row (``smi_llm_debug_sample``): ``n_rows`` independent draws with

@@ -199,7 +199,7 @@ def test_bad_arguments_are_reported(tiny):
         _llm(cfg, syn, max_positions=64).decode(1)   # decode before prefill
 
 
-def test_full_size_0p5b_against_transformers_golden(golden_dir, full_llm):
+def test_full_size_0p5b_against_transformers_golden(golden_dir, full_llm, full_llm_oracle):
     """Spark-TTS-0.5B shape (24 layers, vocab 166000), synthetic weights: last-position logits and
     the 150 greedy tokens transformers produced in the build container."""
     from conftest import FULL_MAX_POS
@@ -211,12 +211,21 @@ def test_full_size_0p5b_against_transformers_golden(golden_dir, full_llm):
     assert abs(float(np.abs(logits.astype(np.float64)).sum()) - float(g["last_logits_abs"])) < 1e-4 * float(g["last_logits_abs"])
     got = llm.generate_ids([g["prompt"].tolist()], 150)[0]
     assert got == g["greedy"].tolist()
-    # production setting (bf16 KV, hipGraph): teacher-forced agreement with the fp32 result
+    # production setting (bf16 KV): teacher-forced on the golden sequence.  The bar for the KERNELS is the CPU oracle run with the
+    # same bf16 KV cache (every position's arg-max; >= 0.97 asked, near-ties aside they are equal).  Against transformers' fp32-KV
+    # tokens the same pass agrees at 0.96 at this shape with synthetic weights -- that gap is the cache precision north_star fixes
+    # (bf16 KV), not summation order: the oracle's own bf16-KV pass shows the same positions.
     llm16 = _llm(cfg, None, max_positions=FULL_MAX_POS, kv_dtype="bf16", arena=arena)
     seq = np.concatenate([g["prompt"], g["greedy"][:-1]])
     lg = llm16.forward_logits(seq)[127:].argmax(-1).cpu().numpy()
+    full_llm_oracle.kv_dtype = "bf16"
+    full_llm_oracle.reset()
+    want16 = full_llm_oracle.forward(seq)[127:].argmax(-1).numpy()
+    full_llm_oracle.reset()
+    agree16 = float((lg == want16).mean())
+    assert agree16 >= 0.97, f"bf16-KV teacher-forced arg-max agreement with the bf16-KV oracle {agree16}"
     agree = float((lg == g["greedy"]).mean())
-    assert agree >= 0.97, f"bf16-KV teacher-forced token agreement {agree}"   # (the stricter bar: test_fullsize_gpu.py::test_config2_...)
+    assert agree >= 0.95 and abs(agree - float((want16 == g["greedy"]).mean())) <= 0.02, f"vs the fp32-KV golden tokens: {agree}"
 
 
 def test_full_size_batch_is_bit_identical_to_single_runs(full_llm):
@@ -554,6 +563,62 @@ def test_fp32_checkpoint_is_rounded_and_reported(tiny):
     agree = float((got.argmax(-1) == full.argmax(-1)).mean())
     print(f"fp32 checkpoint through the bf16 arena: max |logit diff| {dev:.3e}, greedy agreement {agree:.3f}")
     assert LOGIT_ATOL < dev < 0.5 and agree > 0.8                  # visible, bounded: bf16 weight rounding (2^-9 relative)
+
+
+@pytest.mark.parametrize("size", ["tiny", "full"])
+def test_exact_weights_mode_gives_the_fp32_models_tokens(tiny, size):
+    """smi_llm_cfg.weights_exact (verification mode): on a checkpoint SAVED in fp32 -- not bf16-representable, like the published
+    Spark-TTS-0.5B LLM/model.safetensors that the reference loads as saved (cli/SparkTTS.py:48-51) -- the GPU's teacher-forced
+    logits equal the UNROUNDED fp32 oracle's to summation-order noise and the free-running greedy tokens are the oracle's (where
+    the default bf16 arena stands ~1e-2 away and a tenth of the decisions change: the test above).  north_star's acceptance
+    sentence on such a checkpoint; the mode's one-row step time is printed."""
+    import time
+    if size == "tiny":
+        cfg, _ = tiny
+        n_new, max_pos = 48, 160
+    else:
+        cfg = C.spark_0p5b_llm()
+        n_new, max_pos = 24, 96
+    raw = W.SyntheticLLM(cfg, bf16_exact=False)
+    rng = np.random.Generator(np.random.PCG64(17))
+    ids = rng.integers(0, cfg.vocab_size, size=40)
+    prompt = rng.integers(0, cfg.vocab_size, size=33).tolist()
+    ref = Qwen2Ref(cfg, raw)                                        # the fp32 model as saved, fp32 KV
+    llm = _llm(cfg, raw, max_slots=4, max_positions=max_pos, kv_dtype="f32", weights_exact=True)
+    got = llm.forward_logits(ids).cpu().numpy()
+    want = ref.forward(ids).numpy()
+    err = float(np.abs(got - want).max())
+    assert err < LOGIT_ATOL, f"exact-weights logits: max |diff| {err} from the fp32 oracle"
+    assert (got.argmax(-1) == want.argmax(-1)).all()
+    ref.reset()
+    toks = llm.generate_ids([prompt], n_new)[0]
+    assert toks == ref.generate_greedy(prompt, n_new)
+    # a ragged batch through the same mode: rows are independent here too
+    prompts = [rng.integers(0, cfg.vocab_size, size=int(k)).tolist() for k in (5, 19, 33)]
+    batch = llm.generate_ids(prompts + [prompt], 8)
+    assert batch[3] == toks[:8]
+    for b in range(3):
+        ref.reset()
+        assert batch[b] == ref.generate_greedy(prompts[b], 8), f"row {b}"
+    if size == "full":
+        llm.prefill([prompt]); llm.decode(4); torch.cuda.synchronize()
+        t0 = time.perf_counter(); llm.decode(32); torch.cuda.synchronize()
+        print(f"exact-weights mode, 0.5B, one row: {(time.perf_counter() - t0) / 32 * 1e6:.0f} us per decode step")
+
+
+def test_arena_and_config_must_agree_on_how_the_weights_are_stored(tiny):
+    """The arena carries a layout tag (include/sparkmi.h: smi_llm_arena_tag): an arena packed for the exact-weights mode, another
+    W_down tile order or other dimensions is refused by smi_llm_create instead of being streamed as something it is not."""
+    from sparkmi import arena as A
+    from sparkmi._lib import SparkMIError
+    from sparkmi.llm import SparkLLM
+    cfg, syn = tiny
+    packed = torch.from_numpy(A.pack_llm_arena(cfg, syn, A.llm_cfg_struct(cfg, 1, 96, "bf16", True))).to("cuda:0")
+    SparkLLM(cfg, None, "cuda:0", max_positions=96, arena=packed)                                  # fine
+    with pytest.raises(SparkMIError, match="dimensions|too small"):
+        SparkLLM(cfg, None, "cuda:0", max_positions=128, arena=packed)                             # another RoPE table size
+    with pytest.raises(SparkMIError, match="weights_exact|too small"):
+        SparkLLM(cfg, None, "cuda:0", max_positions=96, arena=packed, weights_exact=True)
 
 
 def test_sampled_tokens_do_not_depend_on_batch_composition(tiny):

@@ -125,3 +125,39 @@ def test_llm_hidden_states_per_layer_match_transformers(golden_dir):
             h = ref.rmsnorm(h, ref.final_norm)
         assert abs(float(h.double().abs().sum()) - g["llm_hidden_abs"][i]) < 1e-5 * g["llm_hidden_abs"][i], f"layer {i}"
         np.testing.assert_allclose(h[-1, :8].numpy(), g["llm_hidden_first"][i], rtol=0, atol=2e-5, err_msg=f"layer {i}")
+
+
+def test_decoder_layer_taken_apart_at_head_dim_64(golden_dir):
+    """tests/golden/llm_ops.npz (transformers' Qwen2RMSNorm, q/k/v/o_proj, apply_rotary_pos_emb, eager_attention_forward, Qwen2MLP at
+    the head_dim the HIP kernels are built for): the oracle's pieces, stage by stage -- the same vectors tests/test_llm_ops_gpu.py
+    holds the kernels to."""
+    import torch.nn.functional as F
+    g = np.load(os.path.join(golden_dir, "llm_ops.npz"))
+    ref = Qwen2Ref.__new__(Qwen2Ref)
+    ref.cfg = types.SimpleNamespace(rms_norm_eps=1e-6, num_attention_heads=4, num_key_value_heads=2, head_dim=64, rope_theta=1000000.0)
+    ref.inv_freq = 1.0 / (ref.cfg.rope_theta ** (torch.arange(0, 64, 2, dtype=torch.float32) / 64))
+    t = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    rows, x = g["rows"], t("x")
+    M = len(rows)
+    pos = torch.from_numpy(rows[:, 1].astype(np.int64))
+    xn = ref.rmsnorm(x, t("ln1"))
+    q = ref.rope(F.linear(xn, t("attn/q_proj.weight"), t("attn/q_proj.bias")).view(M, 4, 64), pos)
+    k = ref.rope(F.linear(xn, t("attn/k_proj.weight"), t("attn/k_proj.bias")).view(M, 2, 64), pos)
+    v = F.linear(xn, t("attn/v_proj.weight"), t("attn/v_proj.bias")).view(M, 2, 64)
+    np.testing.assert_allclose(q.numpy(), g["q_rot"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(k.numpy(), g["k_rot"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(v.numpy(), g["v"], rtol=0, atol=3e-6)
+    ao = torch.zeros(M, 256)
+    for i, (s, p) in enumerate(rows):
+        own = [j for j, (s2, p2) in enumerate(rows) if s2 == s and p2 <= p]
+        K = torch.cat([t(f"kcache{s}").transpose(0, 1)] + [k[j: j + 1] for j in own])     # (T, Hkv, D)
+        V = torch.cat([t(f"vcache{s}").transpose(0, 1)] + [v[j: j + 1] for j in own])
+        assert K.shape[0] == p + 1
+        ao[i] = ref.attention(q[i: i + 1], K, V, torch.tensor([int(p)]))[0]
+    np.testing.assert_allclose(ao.numpy(), g["attn_out"], rtol=0, atol=2e-6)
+    h_mid = x + F.linear(ao, t("attn/o_proj.weight"))
+    np.testing.assert_allclose(h_mid.numpy(), g["h_mid"], rtol=0, atol=5e-6)
+    xn2 = ref.rmsnorm(h_mid, t("ln2"))
+    act = F.silu(F.linear(xn2, t("mlp/gate_proj.weight"))) * F.linear(xn2, t("mlp/up_proj.weight"))
+    np.testing.assert_allclose(act.numpy(), g["act"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose((h_mid + F.linear(act, t("mlp/down_proj.weight"))).numpy(), g["h_out"], rtol=0, atol=2e-5)
