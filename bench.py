@@ -139,6 +139,52 @@ def cpu_baseline(llm_cfg, voc_cfg, prompt, glob, n_tokens, runs):
     }
 
 
+def cpu_third_party(llm_cfg, prompt, n_tokens):
+    """SURVEY 8d's second CPU data point: transformers' OWN Qwen2ForCausalLM.generate(do_sample=False) -- the third-party code the
+    reference runs (cli/SparkTTS.py:49,197-204), not this repository's restatement -- on the same synthetic weights and prompt,
+    one warm-up + one timed run of a bounded token count.  LLM half only (the reference's vocoder cannot travel to this box).
+    None when transformers is not importable here."""
+    try:
+        from transformers import Qwen2Config, Qwen2ForCausalLM
+    except Exception as e:   # noqa: BLE001 -- absence is a recorded fact, not an error
+        return {"available": False, "why": f"transformers not importable: {type(e).__name__}"}
+    from sparkmi import weights as W
+    syn = W.SyntheticLLM(llm_cfg)
+    hc = Qwen2Config(vocab_size=llm_cfg.vocab_size, hidden_size=llm_cfg.hidden_size, intermediate_size=llm_cfg.intermediate_size,
+                     num_hidden_layers=llm_cfg.num_hidden_layers, num_attention_heads=llm_cfg.num_attention_heads,
+                     num_key_value_heads=llm_cfg.num_key_value_heads, rms_norm_eps=llm_cfg.rms_norm_eps, rope_theta=llm_cfg.rope_theta,
+                     tie_word_embeddings=llm_cfg.tie_word_embeddings, max_position_embeddings=llm_cfg.max_position_embeddings,
+                     use_sliding_window=False, attn_implementation="eager")
+    with torch.device("meta"):
+        m = Qwen2ForCausalLM(hc)
+    m = m.to_empty(device="cpu")
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n == "lm_head.weight" and llm_cfg.tie_word_embeddings:
+                continue
+            p.copy_(torch.from_numpy(syn[n]))
+    m.tie_weights()
+    for mod in m.modules():   # non-persistent rotary buffers are not restored by to_empty
+        if hasattr(mod, "inv_freq") and hasattr(mod, "compute_default_rope_parameters"):
+            inv, _ = mod.compute_default_rope_parameters(mod.config)
+            mod.inv_freq = inv
+            mod.original_inv_freq = inv.clone()
+    m.eval()
+    ids = torch.tensor([prompt], dtype=torch.long)
+    out = None
+    times = []
+    for r in range(2):
+        t0 = time.time()
+        with torch.no_grad():
+            out = m.generate(ids, attention_mask=torch.ones_like(ids), max_new_tokens=n_tokens, do_sample=False, eos_token_id=None, pad_token_id=0)
+        times.append(time.time() - t0)
+    import transformers
+    return {"available": True, "transformers": transformers.__version__, "tokens": n_tokens, "seconds": times[1],
+            "tokens_per_s": n_tokens / times[1], "ms_per_token_incl_prefill": 1e3 * times[1] / n_tokens,
+            "first_tokens": out[0, len(prompt):len(prompt) + 8].tolist(),
+            "sample": f"{len(prompt)}-token prefill + {n_tokens} greedy tokens through transformers' generate(), fp32, 1 warm-up + 1 timed run"}
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -610,6 +656,11 @@ def main():
             cglob = np.random.Generator(np.random.PCG64(1235)).integers(0, 4096, size=ntok_glob)
             res["cpu_baseline"] = cpu_baseline(llm_cfg, voc_cfg, cprompt, cglob, a.cpu_tokens, a.cpu_runs)
             res["gpu_over_cpu_rtf"] = res["cpu_baseline"]["rtf"] / res["rtf"]
+            log("timing transformers' own generate() on the host (third-party data point)")
+            tp = cpu_third_party(llm_cfg, cprompt, min(32, a.cpu_tokens))
+            if tp.get("available"):   # the restated path and the third-party code must walk the same tokens
+                tp["same_first_tokens_as_oracle"] = tp["first_tokens"] == res["cpu_baseline"]["first_tokens"][:len(tp["first_tokens"])]
+            res["cpu_baseline"]["third_party"] = tp
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -158,13 +158,14 @@ int smi_llm_get_tokens(smi_llm* h, int64_t* out_host, int32_t* lens_host, int ca
  * prefills n new prompts into free slots (returned in slots_out) and emits their first token without
  * touching the live sequences; smi_llm_decode then steps every live sequence; smi_llm_slot_tokens reads one
  * sequence's tokens so far and whether it has produced eos; smi_llm_retire frees its slot.  A sequence's
- * DECODE steps do not depend on what else is live: rows are independent in every decode kernel and every decode path
- * (row-grouped GEMMs, one-row engine) sums a row in the same order -- bit for bit.  Its PROMPT rows run through the
- * kernel the call's total prompt rows select (row-grouped GEMMs or the prefill GEMM, smi_llm.hip: pg_min), whose fp32
- * sums associate differently: with an f32 KV cache the tokens are still identical (tested at full size); with the bf16
- * cache a last-bit difference can move a K/V element to the neighbouring bf16 value, so a greedy arg-max whose top two
- * logits are closer than ~1e-2 may resolve differently between two batch compositions (about 1 token in 80 at 0.5B
- * with synthetic weights; tests/test_fullsize_gpu.py bounds the rate and checks each flip sits on such a tie). */
+ * tokens do not depend on what else is live, was admitted with it or shares its call: rows are independent in every decode
+ * kernel and every decode path (row-grouped GEMMs, chain-split down_proj, one-row kernels) sums a row in the same order, and the
+ * kernels its PROMPT rows run through are chosen from ITS OWN length alone (up to SMI_MAX_ROWS rows: the decode kernels; more:
+ * the prefill GEMM family, whose few-row and many-row shapes sum o_proj / down_proj in the same K segments in the same order),
+ * each class of a call in its own pass -- bit for bit, with either KV cache type (tests/test_fullsize_gpu.py: 32 of 32 rows,
+ * prompts of 3 .. 600 tokens in one call against every sequence alone, K rows compared).  Round 3 chose the prompt kernels
+ * from the call's TOTAL rows; with the bf16 cache a last-bit difference between two kernels could then move a K/V element to
+ * the neighbouring bf16 value and flip a near-tie arg-max between two batch compositions. */
 int smi_llm_session_begin(smi_llm* h, const int64_t* eos_ids_host, int n_eos, void* stream);
 int smi_llm_admit(smi_llm* h, const int64_t* ids_host, const int32_t* lens_host, int n, int P_max, int32_t* slots_out, void* stream);
 int smi_llm_retire(smi_llm* h, int slot, void* stream);

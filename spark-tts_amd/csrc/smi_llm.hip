@@ -113,6 +113,13 @@ struct GemmP {
   const float* Yin;      // RESID: residual row source when it is not Y itself (null: Y)
   const unsigned char* pf2_base; int pf2_slice, pf2_nslices;   // PRO_FUSEDO: a later kernel's weights the work blocks touch (null: none)
   int wperm;             // weight tiles stored row-part-major [q:4][k8:4][r:4][8] (W_down): lane (k8, n = 4q + r) owns piece q*16 + k8*4 + r
+  // k_pgemm<RESID>: the K range is summed in SEGMENTS of kseg k tiles (segment sums added in order) -- the association both the
+  // in-block form (many rows: a second accumulator set) and the split-K form (few rows: one block per segment -> `slab`
+  // [segment][n tile][m tile][lane] f32x4, combined in order by k_resid_comb) produce, so a prompt row has the same bits in
+  // either.  kseg = 0: one running sum over all of K (the other GEMMs).
+  int kseg;
+  float4* slab;
+  int slab_mt;           // m-tiles of the whole launch (slab indexing)
 };
 // piece index of `lane` inside a 1 KiB weight tile (see GemmP::wperm)
 __device__ __forceinline__ int smi_wlane(int lane, int wperm) {
@@ -1077,7 +1084,7 @@ __device__ __forceinline__ void embed_row_x(const float* W32, int KT, int token,
 // four weight tiles for ALL rows: 40 KB of weights (every weight byte leaves HBM once per launch) and 1/16 of the operand
 // (61 KB at 32 rows), staged once per block in LDS.  A wave owns one weight tile -- no cross-wave reduction -- and leaves the
 // chain's sum, (lo + mid) + hi exactly as k_gemm forms it, in `part` [chain][n tile][m tile][lane] (the accumulator's own
-// layout: 1-KiB stores).  k_down_comb then adds the 16 chains IN ORDER and runs the RESID epilogue: the same sums in the same
+// layout: 1-KiB stores).  k_resid_comb then adds the 16 chains IN ORDER and runs the RESID epilogue: the same sums in the same
 // order as k_gemm<RESID, NW = 16> / k_downS / k_down1, so a row keeps its bits whatever the batch.  Blocks of one chain sit on
 // one XCD (block id = cg * 16 + c): they share the operand slice through one L2.
 // ------------------------------------------------------------------------------------------
@@ -1164,10 +1171,13 @@ __global__ __launch_bounds__(256) void k_downC(DownCP p) {
   }
 }
 
-// One wave per (n tile, m tile): the 16 chain sums in order, then k_gemm's RESID epilogue (residual add, h, the next norm's
-// operand triples and partial sums of squares).
-template <int MTN>
-__global__ __launch_bounds__(64) void k_down_comb(DownCP p) {
+// One wave per (n tile, m tile): the S partial sums in order, then the RESID epilogue (residual add, h, the next norm's operand
+// triples and partial sums of squares).  Two producers: k_downC (S = 16 chains; the running sum starts from chain 0's term, as
+// k_gemm's cross-wave reduction does; one partial sum of squares per 4 columns) and k_pgemm's split-K form (S segments; ZI: the
+// running sum starts from zero, as its in-block fold does; SSTILE: one partial per n tile, combined across the lanes exactly
+// as k_pgemm's epilogue combines them) -- in both cases the same sums in the same order as the single-launch form.
+template <int ZI, int SSTILE>
+__global__ __launch_bounds__(64) void k_resid_comb(DownCP p, int S, int MTN) {
   const int lane = threadIdx.x, unit = (int)blockIdx.x;
   const int nt = unit / MTN, mt = unit - nt * MTN;
   const int NT = p.NT, M = p.M, N = NT * 16;
@@ -1178,25 +1188,34 @@ __global__ __launch_bounds__(64) void k_down_comb(DownCP p) {
   const float4 epre = *(const float4*)((p.Yin ? p.Yin : p.Y) + (size_t)mc * N + n);
   float4 q[16];
 #pragma unroll
-  for (int ch = 0; ch < 16; ++ch) q[ch] = p.part[(((size_t)ch * NT + nt) * MTN + mt) * 64 + lane];
-  float4 s = q[0];
+  for (int ch = 0; ch < 16; ++ch) q[ch] = p.part[(((size_t)(ch < S ? ch : S - 1) * NT + nt) * MTN + mt) * 64 + lane];
+  float4 s = ZI ? make_float4(0.f, 0.f, 0.f, 0.f) : q[0];
 #pragma unroll
-  for (int ch = 1; ch < 16; ++ch) { s.x += q[ch].x; s.y += q[ch].y; s.z += q[ch].z; s.w += q[ch].w; }
-  if (!valid) return;
-  float4 h = epre;
-  h.x += s.x; h.y += s.y; h.z += s.z; h.w += s.w;
-  *(float4*)(p.Y + (size_t)m * N + n) = h;
-  const float ssq = (h.x * h.x + h.y * h.y) + (h.z * h.z + h.w * h.w);
-  const float t[4] = {egam.x * h.x, egam.y * h.y, egam.z * h.z, egam.w * h.w};
-  uint32_t hi[4], mi[4], lo[4];
+  for (int ch = ZI ? 0 : 1; ch < 16; ++ch)
+    if (ch < S) { s.x += q[ch].x; s.y += q[ch].y; s.z += q[ch].z; s.w += q[ch].w; }   // wave-uniform
+  float ssq = 0.f;
+  if (valid) {
+    float4 h = epre;
+    h.x += s.x; h.y += s.y; h.z += s.z; h.w += s.w;
+    *(float4*)(p.Y + (size_t)m * N + n) = h;
+    ssq = (h.x * h.x + h.y * h.y) + (h.z * h.z + h.w * h.w);
+    const float t[4] = {egam.x * h.x, egam.y * h.y, egam.z * h.z, egam.w * h.w};
+    uint32_t hi[4], mi[4], lo[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) split3(t[e], hi[e], mi[e], lo[e]);
-  const size_t o = xs_off(n >> 5, 0, (n >> 3) & 3, m, M) + ((n >> 2) & 1) * 8;
-  const size_t pl = (size_t)4 * M * 16;
-  *(uint2*)(p.XSout + o) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
-  *(uint2*)(p.XSout + o + pl) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
-  *(uint2*)(p.XSout + o + 2 * pl) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
-  p.ssout[((size_t)m * NT + nt) * 4 + (lane >> 4)] = ssq;
+    for (int e = 0; e < 4; ++e) split3(t[e], hi[e], mi[e], lo[e]);
+    const size_t o = xs_off(n >> 5, 0, (n >> 3) & 3, m, M) + ((n >> 2) & 1) * 8;
+    const size_t pl = (size_t)4 * M * 16;
+    *(uint2*)(p.XSout + o) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+    *(uint2*)(p.XSout + o + pl) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
+    *(uint2*)(p.XSout + o + 2 * pl) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+  }
+  if (SSTILE) {   // k_pgemm's epilogue: the tile's four column groups of a row added across the lanes, one partial per (row, n tile)
+    ssq += __shfl_xor(ssq, 16, 64);
+    ssq += __shfl_xor(ssq, 32, 64);
+    if (lane < 16 && valid) p.ssout[(size_t)m * NT + nt] = ssq;
+  } else if (valid) {
+    p.ssout[((size_t)m * NT + nt) * 4 + (lane >> 4)] = ssq;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1232,9 +1251,11 @@ __device__ __forceinline__ void smi_keep4(const uint4& v) { asm volatile("" ::"v
 // block's prologue, epilogue and barrier stalls are covered by the other's MFMAs (gate_up: 2432 blocks of 128 x 256 in 9.5 rounds,
 // 10 us of un-overlapped prologue + epilogue per round at one block per CU).  One fragment set, the ring's other slot one k
 // tile ahead, and the RMSNorm factors are computed after the k loop into the ring's memory (no LDS left for them beside it).
-template <int PRO, int EPI, int KVF32, int NTW = 2, int WR = 1, int RING = 0, int XMAP = 0, int TWO = 0>
+// MTB (ring form only): m-tiles per block, 8 (128 rows) or 4 (64 rows: the few-row shapes -- twice the blocks for a 127-row prompt).
+template <int PRO, int EPI, int KVF32, int NTW = 2, int WR = 1, int RING = 0, int XMAP = 0, int TWO = 0, int MTB = 8>
 __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_pgemm(GemmP p) {
-  constexpr int MTB = 8, ROWS = MTB * 16, PIECES = 3 * 4 * ROWS;   // 1536 16-byte pieces per k tile; NTW weight tiles per wave
+  static_assert(MTB == 8 || (MTB == 4 && RING >= 3 && !TWO), "64-row tiles: ring form");
+  constexpr int ROWS = MTB * 16, PIECES = 3 * 4 * ROWS;   // 1536 (768) 16-byte pieces per k tile; NTW weight tiles per wave
   constexpr int MTW = MTB / WR, NWC = 4 / WR;                      // m-tiles per wave, waves across the block's columns
   constexpr int CT = NWC * NTW;                                    // weight tiles per block
   constexpr int SLOT = PIECES + CT * 64;                           // RING: 16-byte pieces per ring slot (operand image, then weight tiles)
@@ -1262,15 +1283,38 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_pgemm(GemmP p) {
   for (int a = 0; a < NTW; ++a)
 #pragma unroll
     for (int b = 0; b < MTW; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // K segments (RESID, ring form): in-block -- `tot` takes each finished segment's sum, in order; split-K -- this block sums
+  // segment blockIdx.y only and leaves it in p.slab
+  constexpr bool SEG = EPI == EPI_RESID && RING >= 3 && !TWO && XMAP;
+  const int kseg = SEG ? p.kseg : 0;
+  const bool part = SEG && p.slab != nullptr;
+  const int k_lo = part ? (int)blockIdx.y * kseg : 0;
+  const int k_hi = part ? (k_lo + kseg < KT ? k_lo + kseg : KT) : KT;
+  f32x4 tot[SEG ? NTW : 1][SEG ? MTW : 1];
+  if constexpr (SEG) {
+#pragma unroll
+    for (int a = 0; a < NTW; ++a)
+#pragma unroll
+      for (int b = 0; b < MTW; ++b) tot[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  auto fold = [&]() {   // a segment is complete: total += segment sum (0 + s0, then + s1, ...: the order k_resid_comb adds the slab in)
+    if constexpr (SEG) {
+#pragma unroll
+      for (int a = 0; a < NTW; ++a)
+#pragma unroll
+        for (int b = 0; b < MTW; ++b) { tot[a][b] = tot[a][b] + acc[a][b]; acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    }
+  };
   if constexpr (RING != 0) {
     static_assert((TWO ? RING == 2 : RING >= 3) && CT % 4 == 0, "ring form: a wave-instruction moves one weight tile, four per pass of the block");
-    constexpr int GA = CT / 4, G = 6 + GA;               // LDS-DMA instructions per thread and k tile
+    constexpr int NI = PIECES / 256, PPI = 256 / ROWS;   // operand issues per thread and k tile; (split, octet) planes one issue covers
+    constexpr int GA = CT / 4, G = NI + GA;              // LDS-DMA instructions per thread and k tile
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const uint32_t lbase = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)smem);
     int brow = m0 + (tid & (ROWS - 1));
     brow = brow < M ? brow : M - 1;
-    const unsigned char* bsrc = p.XS + ((size_t)(tid >> 7) * M + brow) * 16;   // piece i of k tile kt: + ((kt * 12 + 2 i) * M) * 16
+    const unsigned char* bsrc = p.XS + ((size_t)(tid / ROWS) * M + brow) * 16;   // issue i of k tile kt: + ((kt * 12 + PPI i) * M) * 16
     const uint4* asrc[GA];
 #pragma unroll
     for (int a = 0; a < GA; ++a) {
@@ -1278,40 +1322,41 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_pgemm(GemmP p) {
       asrc[a] = p.W + (size_t)(nt < NT ? nt : NT - 1) * KT * 64 + smi_wlane(lane, p.wperm);
     }
     auto issue = [&](int kt, int slot) {                 // tile kt (clamped: the extra requests of the last iterations keep the count uniform) -> ring slot
-      const int kc = kt < KT ? kt : KT - 1;
+      const int kc = kt < k_hi ? kt : k_hi - 1;
       const uint32_t d = lbase + (uint32_t)(slot * SLOT + wv * 64) * 16;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) smi_glds16(bsrc + ((size_t)(kc * 12 + 2 * i) * M) * 16, d + 256 * 16 * i);
+      for (int i = 0; i < NI; ++i) smi_glds16(bsrc + ((size_t)(kc * 12 + PPI * i) * M) * 16, d + 256 * 16 * i);
 #pragma unroll
       for (int a = 0; a < GA; ++a) smi_glds16(asrc[a] + (size_t)kc * 64, d + (uint32_t)(PIECES + 4 * a * 64) * 16);
     };
 #pragma unroll
-    for (int t = 0; t < RING - 1; ++t) issue(t, t);
+    for (int t = 0; t < RING - 1; ++t) issue(k_lo + t, t);
     // RMSNorm factors of the block's rows.  A wave takes 32 rows with all their loads in flight together (one row after the
     // other: 32 dependent L2 round trips, ~50 us in front of the k loop); per row the order of smi_ss_lane_sum + smi_wave_sum.
+    constexpr int RPN = ROWS / 4;                       // rows whose factor a wave computes
     auto norm_factors = [&]() {
       const int np = p.npart, last = np - 1;
       if (np <= 64) {                                     // (the prefill GEMM's own RESID epilogue: one partial per n tile)
-        float a[32];
+        float a[RPN];
         const int i0 = lane < np ? lane : last;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-          int m = m0 + wave * 32 + j;
+        for (int j = 0; j < RPN; ++j) {
+          int m = m0 + wave * RPN + j;
           m = m < M ? m : M - 1;
           a[j] = p.sspart[(size_t)m * np + i0];
         }
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
+        for (int j = 0; j < RPN; ++j) {
           float v = 0.f;
           v += lane < np ? a[j] : 0.f;
           v = smi_wave_sum(v);
-          if (lane == 0) rarr[wave * 32 + j] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
+          if (lane == 0) rarr[wave * RPN + j] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
         }
       } else if (np <= 256) {
         int idx[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) idx[q] = lane + 64 * q < np ? lane + 64 * q : last;
-        for (int r0 = wave * 32; r0 < wave * 32 + 32; r0 += 8) {
+        for (int r0 = wave * RPN; r0 < wave * RPN + RPN; r0 += 8) {
           float a[8][4];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -1331,7 +1376,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_pgemm(GemmP p) {
           }
         }
       } else {
-        for (int r = wave * 32; r < wave * 32 + 32; ++r) {
+        for (int r = wave * RPN; r < wave * RPN + RPN; ++r) {
           int m = m0 + r;
           m = m < M ? m : M - 1;
           float v = smi_ss_lane_sum(p.sspart + (size_t)m * np, np, lane);
@@ -1380,6 +1425,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_pgemm(GemmP p) {
       if (!(SMI_PG_ABL & 8)) fread(nxt_, rn); \
       if (!(SMI_PG_ABL & 2)) issue((kt_) + RING - 1, ws); \
       if (!(SMI_PG_ABL & 1)) fmma(cur_); else { _Pragma("unroll") for (int i_ = 0; i_ < NTW; ++i_) smi_keep4((cur_).a[i_]); _Pragma("unroll") for (int m_ = 0; m_ < MTW; ++m_) { smi_keep4((cur_).b[m_][0]); smi_keep4((cur_).b[m_][1]); smi_keep4((cur_).b[m_][2]); } } \
+      if (SEG && !part && kseg > 0 && ((kt_) + 1) % kseg == 0) fold();   /* (block-uniform) a segment ends with this tile */ \
       SMI_PG_SYNC(); \
       rn = rn + 1 == RING ? 0 : rn + 1; \
       ws = ws + 1 == RING ? 0 : ws + 1; \
@@ -1403,12 +1449,21 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_pgemm(GemmP p) {
     __syncthreads();
     fread(f0, 0);
     int rn = 1, ws = RING - 1;
-    for (int kt = 0; kt < KT; kt += 2) {
+    for (int kt = k_lo; kt < k_hi; kt += 2) {
       SMI_PG_STEP(f0, f1, kt);
-      if (kt + 1 < KT) SMI_PG_STEP(f1, f0, kt + 1);
-      else f0 = f1;                                       // (odd KT: the loop ends here; keeps the two paths' live sets alike)
+      if (kt + 1 < k_hi) SMI_PG_STEP(f1, f0, kt + 1);
+      else f0 = f1;                                       // (odd count: the loop ends here; keeps the two paths' live sets alike)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped extra requests: nothing may still write LDS when the block ends
+    if constexpr (SEG) {
+      if (!part && kseg > 0) {
+        if (KT % kseg) fold();                            // the last, shorter segment
+#pragma unroll
+        for (int a = 0; a < NTW; ++a)
+#pragma unroll
+          for (int b = 0; b < MTW; ++b) acc[a][b] = tot[a][b];
+      }
+    }
     }
 #undef SMI_PG_STEP
 #undef SMI_PG_SYNC
@@ -1492,6 +1547,22 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_pgemm(GemmP p) {
     return;
   }
 #endif
+  if constexpr (SEG) {
+    if (part) {   // split-K form: this segment's sums as they lie in the accumulators (1-KiB stores); k_resid_comb finishes the rows
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        const int nt = (bx * NWC + wc) * NTW + i;
+        if (nt >= NT) continue;   // wave-uniform
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          const int mtile = (m0 >> 4) + mt0 + mt;
+          if (mtile < p.slab_mt)
+            p.slab[(((size_t)blockIdx.y * NT + nt) * p.slab_mt + mtile) * 64 + lane] = make_float4(acc[i][mt][0], acc[i][mt][1], acc[i][mt][2], acc[i][mt][3]);
+        }
+      }
+      return;
+    }
+  }
   // ---- epilogue (same arithmetic as k_gemm's).  Its loads first, all together and from clamped addresses: written inside the
   // `if (valid)` bodies hipcc branched around every load and waited for it on the spot (QKV: 137 `s_waitcnt vmcnt(0)`, three
   // dependent round trips -- bias, row descriptor, RoPE pair -- for each of the 24 (tile, m-tile) pairs of a wave).
@@ -1775,6 +1846,25 @@ __global__ __launch_bounds__(256) void k_lm32(GemmP p, int ngroups, int m0) {
   uint4* xl = (uint4*)(smem + (size_t)NW * NTB * 2 * 1024 + 32 * 4 + NTB * 32 * 8);   // [KT][3][4][16]
   const int k8 = lane >> 4, em = lane & 15;
   const int row0 = m0 + (em < M ? em : M - 1);                     // m-tile 0 row of this lane (clamped)
+  // ---- prologue: EVERY load of it is requested before anything waits -- the RMSNorm partials of this wave's rows (8 rows x 4
+  // dwords), the m-tile-0 operand registers, the 21 pieces per thread of m-tile 1's LDS image, then the first two groups' weight
+  // tiles.  As first written (round 3) the image was copied load -> wait -> ds_write per piece and the partials row by row: 29
+  // dependent round trips behind the cold weight tiles, 14 of the kernel's 65 us (round-4 stamps: block 0 streams its 20 groups
+  // in 50 us).  Loads return in issue order, so the small L2-resident ones go first.
+  constexpr int RPW = 8;                                           // rows per wave (32 / NW)
+  float ssv[RPW][4];
+  const bool ss_early = p.npart <= 256;
+  if (ss_early) {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      int mr = m0 + wave + i * NW;
+      mr = mr < p.M ? mr : p.M - 1;
+      const float* sp = p.sspart + (size_t)mr * p.npart;
+      const int last = p.npart - 1;
+      ssv[i][0] = sp[lane < last ? lane : last]; ssv[i][1] = sp[lane + 64 < last ? lane + 64 : last];
+      ssv[i][2] = sp[lane + 128 < last ? lane + 128 : last]; ssv[i][3] = sp[lane + 192 < last ? lane + 192 : last];
+    }
+  }
   bf16x8 bf[U][3];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -1782,6 +1872,19 @@ __global__ __launch_bounds__(256) void k_lm32(GemmP p, int ngroups, int m0) {
     j = j < KT ? j : KT - 1;
 #pragma unroll
     for (int s = 0; s < 3; ++s) bf[u][s] = *(const bf16x8*)(p.XS + xs_off(j, s, k8, row0, p.M));
+  }
+  constexpr int XPT = (UW * NW * 12 * 16 + 255) / 256;             // LDS-image pieces per thread (KT <= UW * NW)
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 xpc[XPT];
+  const int nxl = KT * 12 * 16;
+#pragma unroll
+  for (int q = 0; q < XPT; ++q) {
+    int i = tid + 256 * q;
+    i = i < nxl ? i : nxl - 1;
+    const int r = i & 15, pcx = i >> 4;                            // pcx = (kt * 3 + s) * 4 + k8
+    int mr = m0 + 16 + r;
+    mr = mr < p.M ? mr : p.M - 1;
+    xpc[q] = *(const u32x4*)(p.XS + ((size_t)pcx * p.M + mr) * 16);
   }
   uint4 w0[U][NTB], w1[U][NTB];
   // EVERY request below is unconditional (group and tile indices are clamped, a block's surplus requests re-read the last group
@@ -1808,16 +1911,30 @@ __global__ __launch_bounds__(256) void k_lm32(GemmP p, int ngroups, int m0) {
   load_w(w0, g);
   load_w(w1, g + G);
   // m-tile 1's operand pieces -> LDS (rows beyond M repeat the last row; their results are never stored)
-  for (int i = tid; i < KT * 12 * 16; i += 256) {
-    const int r = i & 15, pc = i >> 4;                             // pc = (kt * 3 + s) * 4 + k8
-    int m = m0 + 16 + r;
-    m = m < p.M ? m : p.M - 1;
-    xl[i] = *(const uint4*)(p.XS + ((size_t)pc * p.M + m) * 16);
+#pragma unroll
+  for (int q = 0; q < XPT; ++q) asm volatile("" : "+v"(xpc[q]));   // (the loads stay above the weight requests, not sunk into the guarded stores)
+#pragma unroll
+  for (int q = 0; q < XPT; ++q) {
+    const int i = tid + 256 * q;
+    if (i < nxl) *(u32x4*)&xl[i] = xpc[q];
   }
-  for (int m = wave; m < M; m += NW) {
-    float v = smi_ss_lane_sum(p.sspart + (size_t)(m0 + m) * p.npart, p.npart, lane);
-    v = smi_wave_sum(v);
-    if (lane == 0) rarr[m] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
+  if (ss_early) {   // same order as smi_ss_lane_sum + smi_wave_sum
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int m = wave + i * NW;
+      float v = lane < p.npart ? ssv[i][0] : 0.f;
+      v += lane + 64 < p.npart ? ssv[i][1] : 0.f;
+      v += lane + 128 < p.npart ? ssv[i][2] : 0.f;
+      v += lane + 192 < p.npart ? ssv[i][3] : 0.f;
+      v = smi_wave_sum(v);
+      if (lane == 0 && m < M) rarr[m] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
+    }
+  } else {
+    for (int m = wave; m < M; m += NW) {
+      float v = smi_ss_lane_sum(p.sspart + (size_t)(m0 + m) * p.npart, p.npart, lane);
+      v = smi_wave_sum(v);
+      if (lane == 0) rarr[m] = 1.0f / sqrtf(v / (float)(KT * 32) + p.eps);
+    }
   }
   for (int i = tid; i < NTB * 32; i += 256) { bestv[i] = -INFINITY; besti[i] = 0x7fffffff; }
   __syncthreads();
@@ -1908,6 +2025,7 @@ __global__ __launch_bounds__(256) void k_lm32(GemmP p, int ngroups, int m0) {
     __syncthreads();   // red is rewritten by the next group
     SMI_LMSTAMP(3);
     ++gi;
+    (void)gi;
   };
 #undef SMI_LMSTAMP
   for (; g < ngroups; g += 2 * G) {   // block-uniform trip counts (every wave keeps the barriers); a group beyond the last stores nothing
@@ -2997,9 +3115,13 @@ struct smi_llm {
   float* sspart;       // [kMaxRows][NTh * 4] partial sums of squares of h (RMSNorm), one per 4 columns
   // prefill workspace for up to big_rows rows at once (allocated at the first multi-chunk prefill)
   float *bh, *bq; unsigned char *bxs_h, *bxs_attn, *bxs_act; float* bss; int big_rows;
+  float4* pslab; size_t pslab_bytes;   // k_pgemm split-K partial sums (prompt rows passes of up to kPgSplitRows rows)
+  int pf_long;          // prompt rows (len - 1) from which a sequence's prompt runs through the prefill-GEMM family (default 65)
+  int pg_split_rows;    // passes of up to this many rows take the few-row prefill GEMM shapes / split-K (kPgSplitRows; SPARKMI_PG_SPLIT_ROWS: A/B, same bits)
+  int pg_forced;        // diagnostics: SPARKMI_PGEMM_MIN_* set -- kernels picked per launch by the pass's row count, as in round 3
   float *part_o, *h2;  // fused o_proj (one row): per-head partials [heads][H]; h + o_proj [H]
   float4* dpart;       // chain-split down_proj (k_downC): [16 chains][NTh][4 m-tiles][64] chain sums
-  int dc_min;          // rows from which down_proj runs chain-split (default 5; SPARKMI_DC_MIN in the diagnostics build)
+  int dc_min;          // rows from which down_proj runs chain-split (default 7; SPARKMI_DC_MIN in the diagnostics build)
   int fuse_o;          // config allows the fused o_proj (SPARKMI_NO_FUSE_O=1 turns it off)
   RowDesc* rows;       // live decode rows [kMaxRows]
   RowDesc* plan;       // prefill plan
@@ -3394,6 +3516,9 @@ int eng_check(smi_llm* L) {
 #endif   // SMI_DIAG
 
 enum { KQKV = 0, KATTN, KO, KGU, KD, KLM, KFIN };
+enum { PF_GROUPED = 1, PF_PGEMM = 2 };   // kernel family of a pass over prompt rows (launch_layers_big)
+constexpr int kPgSplitRows = 512;        // passes of up to this many rows run o_proj / down_proj in k_pgemm's split-K form
+constexpr int kPgSegO = 2, kPgSegD = 8;  // K segments of the prefill o_proj / down_proj sums (fixed: part of the association)
 
 int ensure_apart(smi_llm* L, size_t floats) {
   if (floats <= L->apart_floats) return SMI_OK;
@@ -3467,7 +3592,7 @@ int launch_oproj(const smi_llm* L, const GemmP& p, int M, hipStream_t st) {
   }
 }
 
-// down_proj with the chains split over blocks (k_downC) and the in-order combine + RESID epilogue (k_down_comb)
+// down_proj with the chains split over blocks (k_downC) and the in-order combine + RESID epilogue (k_resid_comb)
 template <int TPC, int MTN>
 int launch_down_chains_t(const smi_llm* L, const DownCP& d, hipStream_t st) {
   const size_t lds = (size_t)TPC * 12 * (d.M < MTN * 16 ? d.M : MTN * 16) * 16;
@@ -3484,7 +3609,7 @@ int launch_down_chains_t(const smi_llm* L, const DownCP& d, hipStream_t st) {
   }
   hipLaunchKernelGGL((k_downC<TPC, MTN>), dim3(d.NT / 4 * 16), dim3(256), lds, st, d);
   SMI_LAUNCH_CHECK();
-  hipLaunchKernelGGL((k_down_comb<MTN>), dim3(d.NT * MTN), dim3(64), 0, st, d);
+  hipLaunchKernelGGL((k_resid_comb<0, 0>), dim3(d.NT * MTN), dim3(64), 0, st, d, 16, MTN);
   SMI_LAUNCH_CHECK();
   return SMI_OK;
 }
@@ -3691,12 +3816,15 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
 }
 
 // One prefill GEMM over M rows (any M) with k_pgemm; `which` as in launch_one (GEMM kernels only).
-template <int PRO, int EPI, int NTW = 2, int WR = 1, int RING = 0, int XMAP = 0, int TWO = 0>
-int launch_pgemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
+// nsplit > 1 (RESID with XMAP only): one block per (tile, K segment) writes its segment's sums to L->pslab and k_resid_comb adds
+// the segments in order and runs the epilogue -- the few-row form of the segmented sum (GemmP::kseg), same bits as the in-block form.
+template <int PRO, int EPI, int NTW = 2, int WR = 1, int RING = 0, int XMAP = 0, int TWO = 0, int MTB = 8>
+int launch_pgemm(const smi_llm* L, GemmP p, hipStream_t st, int nsplit = 1) {
   constexpr int cols = (4 / WR) * NTW;   // weight tiles per block
-  const dim3 grid2((p.NT + cols - 1) / cols, (p.M + 127) / 128);
-  const dim3 grid = XMAP ? dim3(grid2.x * grid2.y) : grid2;
-  const size_t lds = (RING ? (size_t)RING * (1536 + cols * 64) : (size_t)2 * 1536) * 16 + (TWO ? 0 : 128 * 4);
+  constexpr int rows = MTB * 16;
+  const dim3 grid2((p.NT + cols - 1) / cols, (p.M + rows - 1) / rows);
+  dim3 grid = XMAP ? dim3(grid2.x * grid2.y) : grid2;
+  const size_t lds = (RING ? (size_t)RING * (12 * rows + cols * 64) : (size_t)2 * 12 * rows) * 16 + (TWO ? 0 : rows * 4);
   if (lds > 64 * 1024) {   // opt in once per instantiation and device (as in launch_gemm_kv)
     static std::mutex mu;
     static bool done[64] = {};
@@ -3704,14 +3832,28 @@ int launch_pgemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
     SMI_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
     if (dev >= 0 && dev < 64 && !done[dev]) {
-      SMI_HIP(hipFuncSetAttribute((const void*)k_pgemm<PRO, EPI, 1, NTW, WR, RING, XMAP, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      SMI_HIP(hipFuncSetAttribute((const void*)k_pgemm<PRO, EPI, 0, NTW, WR, RING, XMAP, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      SMI_HIP(hipFuncSetAttribute((const void*)k_pgemm<PRO, EPI, 1, NTW, WR, RING, XMAP, TWO, MTB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      SMI_HIP(hipFuncSetAttribute((const void*)k_pgemm<PRO, EPI, 0, NTW, WR, RING, XMAP, TWO, MTB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       done[dev] = true;
     }
   }
-  if (L->cfg.kv_dtype) hipLaunchKernelGGL((k_pgemm<PRO, EPI, 1, NTW, WR, RING, XMAP, TWO>), grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((k_pgemm<PRO, EPI, 0, NTW, WR, RING, XMAP, TWO>), grid, dim3(256), lds, st, p);
+  const int mtiles = (p.M + 15) / 16;
+  if (nsplit > 1) {
+    SMI_REQUIRE(EPI == EPI_RESID && XMAP && RING >= 3 && p.kseg > 0 && nsplit <= 16, "launch_pgemm: split-K is the RESID ring form's");
+    SMI_REQUIRE(L->pslab && (size_t)nsplit * p.NT * mtiles * 1024 <= L->pslab_bytes, "launch_pgemm: partial slab too small");
+    p.slab = L->pslab; p.slab_mt = mtiles;
+    grid = dim3(grid2.x * grid2.y, nsplit);
+  }
+  if (L->cfg.kv_dtype) hipLaunchKernelGGL((k_pgemm<PRO, EPI, 1, NTW, WR, RING, XMAP, TWO, MTB>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((k_pgemm<PRO, EPI, 0, NTW, WR, RING, XMAP, TWO, MTB>), grid, dim3(256), lds, st, p);
   SMI_LAUNCH_CHECK();
+  if (nsplit > 1) {
+    DownCP d;
+    d.W = nullptr; d.NT = p.NT; d.KT = p.KT; d.M = p.M; d.wperm = 0; d.XS = nullptr; d.part = L->pslab;
+    d.Y = p.Y; d.Yin = p.Yin; d.gamma_next = p.gamma_next; d.XSout = p.XSout; d.ssout = p.ssout;
+    hipLaunchKernelGGL((k_resid_comb<1, 1>), dim3(p.NT * mtiles), dim3(64), 0, st, d, nsplit, mtiles);
+    SMI_LAUNCH_CHECK();
+  }
   return SMI_OK;
 }
 
@@ -3719,12 +3861,20 @@ int launch_pgemm(const smi_llm* L, const GemmP& p, hipStream_t st) {
 // states of the last layer never needed (no prompt row except each sequence's last feeds lm_head).
 // Up to kPgemmMinRows rows the decode GEMM runs with one block row per 32 rows (same bits as 32-row
 // chunks, one launch instead of M / 32); beyond, the LDS-shared prefill GEMM (k_pgemm) takes over.
-int launch_layers_big(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
+int launch_layers_big(smi_llm* L, const RowDesc* rows, int M, int family, hipStream_t st) {
   const smi_llm_cfg& c = L->cfg;
-  // per kernel: row-grouped decode GEMM or the prefill GEMM.  The RESID kernels leave the RMSNorm partials as [rows][NT * 4]
-  // (grouped) or [rows][NT] (prefill GEMM); their consumers are told which.
-  const bool gq = M < L->pg_min[0], go = M < L->pg_min[1], gg = M < L->pg_min[2], gd = M < L->pg_min[3];
+  // Which GEMM family: decided by the CALLER from the sequences' own lengths (prefill_prompts), the same for all four kernels of
+  // the pass.  Diagnostics (SPARKMI_PGEMM_MIN_* set): per kernel by the pass's row count, as in round 3 -- every mix is
+  // parity-tested.  The RESID kernels leave the RMSNorm partials as [rows][NT * 4] (grouped) or [rows][NT] (prefill GEMM and
+  // its split-K combine); their consumers are told which.
+  const bool pg = family == PF_PGEMM;
+  const bool gq = L->pg_forced ? M < L->pg_min[0] : !pg, go = L->pg_forced ? M < L->pg_min[1] : !pg,
+             gg = L->pg_forced ? M < L->pg_min[2] : !pg, gd = L->pg_forced ? M < L->pg_min[3] : !pg;
   const int np_from_d = gd ? L->NTh * 4 : L->NTh, np_from_o = go ? L->NTh * 4 : L->NTh;
+  // few rows: 64-column tiles (more blocks) and a deeper ring; o_proj / down_proj as one block per K segment + in-order combine
+  const bool few = M <= L->pg_split_rows && !(L->tune2 & 16384);
+  const int kseg_o = (L->KTq + kPgSegO - 1) / kPgSegO, kseg_d = (L->KTi + kPgSegD - 1) / kPgSegD;
+  const int nseg_o = (L->KTq + kseg_o - 1) / kseg_o, nseg_d = (L->KTi + kseg_d - 1) / kseg_d;
   int rc;
   for (int l = 0; l < c.num_layers; ++l) {
     GemmP p;
@@ -3735,7 +3885,11 @@ int launch_layers_big(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
     p.Y = L->bq; p.bias = (const float*)sec(L, SMI_LLM_BQKV, l); p.rope = (const float2*)sec(L, SMI_LLM_ROPE, 0);
     p.kcache = kv_layer(L, L->kcache, l); p.vcache = kv_layer(L, L->vcache, l);
     p.q_dim = L->Q; p.kv_dim = L->KV; p.n_kv = c.num_kv_heads; p.max_pos = c.max_positions; p.km = kv_map(L);
-    if ((rc = gq ? launch_gemm<1, 16, 2, 1, PRO_NORM, EPI_QKV>(L, p, st) : ((L->tune2 & 16384) ? launch_pgemm<PRO_NORM, EPI_QKV>(L, p, st) : launch_pgemm<PRO_NORM, EPI_QKV, 6, 2, 3, 1>(L, p, st)))) return rc;
+    if (gq) rc = launch_gemm<1, 16, 2, 1, PRO_NORM, EPI_QKV>(L, p, st);
+    else if (L->tune2 & 16384) rc = launch_pgemm<PRO_NORM, EPI_QKV>(L, p, st);
+    else if (few) rc = launch_pgemm<PRO_NORM, EPI_QKV, 2, 2, 6, 1, 0, 4>(L, p, st);
+    else rc = launch_pgemm<PRO_NORM, EPI_QKV, 6, 2, 3, 1>(L, p, st);
+    if (rc) return rc;
     if (l == c.num_layers - 1) break;
     // attention
     AttnP a;
@@ -3760,31 +3914,54 @@ int launch_layers_big(smi_llm* L, const RowDesc* rows, int M, hipStream_t st) {
     o.M = M; o.rows = rows; o.eps = c.rms_eps; o.sspart = L->bss; o.npart = np_from_d;
     o.W = (const uint4*)sec(L, SMI_LLM_WO, l); o.NT = L->NTh; o.KT = L->KTq; o.XS = L->bxs_attn; o.Y = L->bh;
     o.XSout = L->bxs_h; o.gamma_next = (const float*)sec(L, SMI_LLM_LN2, l); o.ssout = L->bss;
-    if ((rc = go ? launch_oproj(L, o, M, st) : ((L->tune2 & 16384) ? launch_pgemm<PRO_PLAIN, EPI_RESID>(L, o, st) : launch_pgemm<PRO_PLAIN, EPI_RESID, 4, 2, 4, 1>(L, o, st)))) return rc;
+    o.kseg = kseg_o;
+    if (go) rc = launch_oproj(L, o, M, st);
+    else if (L->tune2 & 16384) rc = launch_pgemm<PRO_PLAIN, EPI_RESID>(L, o, st);
+    else if (few) rc = launch_pgemm<PRO_PLAIN, EPI_RESID, 2, 2, 6, 1, 0, 4>(L, o, st, nseg_o);
+    else rc = launch_pgemm<PRO_PLAIN, EPI_RESID, 4, 2, 4, 1>(L, o, st);
+    if (rc) return rc;
     // gate_up
     GemmP g;
     memset(&g, 0, sizeof(g));
     g.M = M; g.rows = rows; g.eps = c.rms_eps; g.sspart = L->bss; g.npart = np_from_o;
     g.W = (const uint4*)sec(L, SMI_LLM_WGU, l); g.NT = L->NTgu; g.KT = L->KTh; g.XS = L->bxs_h; g.XSout = L->bxs_act;
-    if ((rc = gg ? launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_SWIGLU, 1, 2>(L, g, st) : ((L->tune2 & 512) ? launch_pgemm<PRO_NORM, EPI_SWIGLU>(L, g, st) : (L->tune2 & 16384) ? launch_pgemm<PRO_NORM, EPI_SWIGLU, 4>(L, g, st) : (L->tune2 & 32768) ? launch_pgemm<PRO_NORM, EPI_SWIGLU, 8, 2, 3>(L, g, st) : launch_pgemm<PRO_NORM, EPI_SWIGLU, 8, 2, 2, 0, 1>(L, g, st)))) return rc;
+    if (gg) rc = launch_gemm<1, 8, 4, 1, PRO_NORM, EPI_SWIGLU, 1, 2>(L, g, st);
+    else if (L->tune2 & 512) rc = launch_pgemm<PRO_NORM, EPI_SWIGLU>(L, g, st);
+    else if (L->tune2 & 16384) rc = launch_pgemm<PRO_NORM, EPI_SWIGLU, 4>(L, g, st);
+    else if (L->tune2 & 32768) rc = launch_pgemm<PRO_NORM, EPI_SWIGLU, 8, 2, 3>(L, g, st);
+    else if (few) rc = launch_pgemm<PRO_NORM, EPI_SWIGLU, 2, 2, 4, 0, 0, 4>(L, g, st);   // 64 KiB ring: two blocks per CU, the 304 blocks of a 127-row prompt in one round (ring of 6: 1.2 rounds, 30 us)
+    else rc = launch_pgemm<PRO_NORM, EPI_SWIGLU, 8, 2, 2, 0, 1>(L, g, st);
+    if (rc) return rc;
     // down
     GemmP d;
     memset(&d, 0, sizeof(d));
     d.M = M; d.rows = rows; d.eps = c.rms_eps; d.sspart = L->bss; d.npart = np_from_o;
     d.W = (const uint4*)sec(L, SMI_LLM_WD, l); d.NT = L->NTh; d.KT = L->KTi; d.XS = L->bxs_act; d.Y = L->bh; d.wperm = L->wd_parts;
     d.XSout = L->bxs_h; d.ssout = L->bss; d.gamma_next = (const float*)sec(L, SMI_LLM_LN1, l + 1);
-    if ((rc = gd ? launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID>(L, d, st) : ((L->tune2 & 16384) ? launch_pgemm<PRO_PLAIN, EPI_RESID>(L, d, st) : launch_pgemm<PRO_PLAIN, EPI_RESID, 4, 2, 4, 1>(L, d, st)))) return rc;
+    d.kseg = kseg_d;
+    if (gd) rc = launch_gemm<1, 16, 2, 5, PRO_PLAIN, EPI_RESID>(L, d, st);
+    else if (L->tune2 & 16384) rc = launch_pgemm<PRO_PLAIN, EPI_RESID>(L, d, st);
+    else if (few) rc = launch_pgemm<PRO_PLAIN, EPI_RESID, 2, 2, 6, 1, 0, 4>(L, d, st, nseg_d);
+    else rc = launch_pgemm<PRO_PLAIN, EPI_RESID, 4, 2, 4, 1>(L, d, st);
+    if (rc) return rc;
   }
   return SMI_OK;
 }
 
 int ensure_big(smi_llm* L, int rows) {
   if (rows <= L->big_rows) return SMI_OK;
-  void* old[] = {L->bh, L->bq, L->bxs_h, L->bxs_attn, L->bxs_act, L->bss};
+  void* old[] = {L->bh, L->bq, L->bxs_h, L->bxs_attn, L->bxs_act, L->bss, L->pslab};
   for (void* q : old)
     if (q) (void)hipFree(q);
   L->bh = L->bq = nullptr; L->bxs_h = L->bxs_attn = L->bxs_act = nullptr; L->bss = nullptr; L->big_rows = 0;
+  L->pslab = nullptr; L->pslab_bytes = 0;
   const size_t R = (size_t)rows;
+  {   // split-K partial sums: up to kPgSegD segments x NTh tiles x (min(rows, kPgSplitRows) / 16) m-tiles x 1 KiB
+    const size_t mt = ((size_t)(rows < kPgSplitRows ? rows : kPgSplitRows) + 15) / 16;
+    const size_t bytes = (size_t)16 * L->NTh * mt * 1024;
+    if (hipMalloc((void**)&L->pslab, bytes) != hipSuccess) { smi_set_error("hipMalloc(prefill split-K slab, %zu bytes) failed", bytes); return SMI_ENOMEM; }
+    L->pslab_bytes = bytes;
+  }
   if (hipMalloc((void**)&L->bh, R * L->H * 4) != hipSuccess || hipMalloc((void**)&L->bq, R * L->Q * 4) != hipSuccess ||
       hipMalloc((void**)&L->bxs_h, R * L->H * 6) != hipSuccess || hipMalloc((void**)&L->bxs_attn, R * L->Q * 6) != hipSuccess ||
       hipMalloc((void**)&L->bxs_act, R * L->I * 6) != hipSuccess || hipMalloc((void**)&L->bss, R * L->NTh * 4 * 4) != hipSuccess) {
@@ -3896,6 +4073,7 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->do_sample = 0; L->top_k = 50; L->temperature = 0.8f; L->top_p = 0.95f; L->seed = 0; L->logits = nullptr; L->tok = nullptr; L->cand_v = nullptr; L->cand_i = nullptr; L->cand_n = nullptr; L->stamps = nullptr; L->stamps_on = 0;
   { L->tune[0] = L->tune[1] = L->tune[2] = L->tune[3] = 0; const char* e = smi_env("SPARKMI_TUNE"); if (e) sscanf(e, "%d,%d,%d,%d", &L->tune[0], &L->tune[1], &L->tune[2], &L->tune[3]); }
   L->bh = L->bq = nullptr; L->bxs_h = L->bxs_attn = L->bxs_act = nullptr; L->bss = nullptr; L->big_rows = 0;
+  L->pslab = nullptr; L->pslab_bytes = 0;
   // helper-block prefetch per producer: bit 0 QKV (gate_up's first half), bit 1 attention (second half), bit 2 down_proj (the next
   // layer's QKV / o_proj); SPARKMI_PREFETCH=<mask> picks, SPARKMI_NO_PREFETCH=1 is mask 0
   // Default since k_down1 (round 3): QKV's helpers at ONE row only.  Measured on one box, alternating processes, graph step at one
@@ -3910,7 +4088,8 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   L->part_o = nullptr; L->h2 = nullptr; L->dpart = nullptr;
   // rows from which down_proj runs chain-split (k_downC): graph step at 0.5B, same box (profiles/r04_batch_ab.txt): 4 rows 641 (k_downS) vs
   // 692 us (chains), 8 rows 728 vs 713, 16 rows 790 (k_gemm<.., H = 4>) vs 744, 32 rows 892 vs 859
-  { const char* e = smi_env("SPARKMI_DC_MIN"); L->dc_min = e ? atoi(e) : 5; }
+  // (5 / 6 rows: 731 / 728 us with the chains, the same as k_downS within noise -- the chains take over from 7)
+  { const char* e = smi_env("SPARKMI_DC_MIN"); L->dc_min = e ? atoi(e) : 7; }
   L->fuse_o = !smi_env("SPARKMI_NO_FUSE_O") && (cfg->num_heads == 14 || cfg->num_heads == 4) && cfg->num_heads <= kMaxOHeads &&
               L->NTh % kFuseQB == 0 && L->NTh / kFuseQB <= kAttnWaves * kFuseOT && L->KTh * 8 <= 256;
   { const char* e = smi_env("SPARKMI_TUNE2"); L->tune2 = e ? atoi(e) : 0; }
@@ -3921,8 +4100,14 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
     // the operand triples once per 32 columns), down_proj from ~900, the two short-K GEMMs from ~1300
     const int dflt[4] = {1280, 1280, 288, 896};
     const bool common = smi_env("SPARKMI_PGEMM_MIN_ROWS") != nullptr;
-    for (int i = 0; i < 4; ++i) { const char* e = smi_env(names[i]); L->pg_min[i] = e ? atoi(e) : common ? L->pgemm_min_rows : dflt[i]; }
+    L->pg_forced = common;
+    for (int i = 0; i < 4; ++i) { const char* e = smi_env(names[i]); L->pg_forced |= e != nullptr; L->pg_min[i] = e ? atoi(e) : common ? L->pgemm_min_rows : dflt[i]; }
   }
+  // A sequence's prompt rows take the kernel family ITS OWN length selects (never the call's total): up to kMaxRows rows the
+  // decode kernels in chunks, from pf_long rows the prefill-GEMM family (k_pgemm + k_attn_pf2), in between (empty by default)
+  // the row-grouped decode GEMMs -- so its K/V rows, and with a bf16 cache its tokens, do not depend on what else is in the call.
+  { const char* e = smi_env("SPARKMI_PG_SPLIT_ROWS"); L->pg_split_rows = e ? atoi(e) : kPgSplitRows; if (L->pg_split_rows > kPgSplitRows) L->pg_split_rows = kPgSplitRows; }
+  { const char* e = smi_env("SPARKMI_PF_LONG"); L->pf_long = e ? atoi(e) : kMaxRows + 1; if (L->pf_long < kMaxRows + 1) L->pf_long = kMaxRows + 1; }
   { const char* e = smi_env("SPARKMI_GU1_ROWS"); L->gu1_rows = e ? atoi(e) : 32; }
   { const char* e = smi_env("SPARKMI_GU1_LO"); L->gu1_lo = e ? atoi(e) : 4; }
   L->wd_parts = cfg->wd_plain ? 0 : 1;   // the arena's W_down tile order comes with its config (never from the environment)
@@ -4029,7 +4214,7 @@ int smi_llm_destroy(smi_llm* L) {
   graphs_flush(L);
   eng_destroy(L);
   void* ptrs[] = {L->h, L->qbuf, L->xs_h, L->xs_attn, L->xs_act, L->sspart, L->part_o, L->h2, L->dpart, L->rows, L->plan, L->pf_tiles, L->pval, L->pidx, L->hist,
-                  L->count, L->finished, L->step, L->ctl, L->ptab, L->kcache, L->vcache, L->logits, L->tok, L->cand_v, L->cand_i, L->cand_n, L->stamps, L->bh, L->bq, L->bxs_h, L->bxs_attn, L->bxs_act, L->bss, L->apart};
+                  L->count, L->finished, L->step, L->ctl, L->ptab, L->kcache, L->vcache, L->logits, L->tok, L->cand_v, L->cand_i, L->cand_n, L->stamps, L->bh, L->bq, L->bxs_h, L->bxs_attn, L->bxs_act, L->bss, L->pslab, L->apart};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (L->ev0) (void)hipEventDestroy(L->ev0);
@@ -4083,26 +4268,52 @@ static int prefill_prompts(smi_llm* L, const int64_t* ids, const int32_t* lens, 
     for (int b = 0; b < B; ++b) longest = lens[b] > longest ? lens[b] : longest;
     L->attn_seg = segs_for(longest);
   }
-  // plan: every prompt token except each sequence's last, packed 32 rows per chunk; then the
-  // B "last prompt token" rows, which run as the first regular step (lm_head + argmax).
-  const size_t nchunks = (total + kMaxRows - 1) / kMaxRows;
+  // Every prompt token but each sequence's last is a row (slot, pos, token); the B last tokens run as the first regular step
+  // (lm_head + argmax).  WHICH kernels a sequence's prompt rows run through is decided by ITS OWN row count alone:
+  //   class 0  up to kMaxRows rows        the decode kernels, kMaxRows-row chunks (rows are independent there: any chunking, same bits)
+  //   class 1  kMaxRows + 1 .. pf_long-1  row-grouped decode GEMMs + the prefill attention (empty by default: pf_long = kMaxRows + 1)
+  //   class 2  pf_long rows and more      the prefill GEMM family (k_pgemm, segmented o_proj / down_proj sums) + the prefill attention
+  // and every class is its own pass over the layers, so a sequence's K/V rows -- and, K/V being rounded to bf16, its tokens --
+  // are the same bits whatever else the call holds (round 3 picked the kernels from the call's TOTAL rows).
+  // Diagnostics keep the old single pass: SPARKMI_PREFILL_CHUNKS (chunks only), SPARKMI_PGEMM_MIN_* (per kernel by total rows);
+  // the exact-weights mode always takes chunks.
+  const bool chunks_only = smi_env("SPARKMI_PREFILL_CHUNKS") != nullptr || L->exact;
+  auto cls_of = [&](int b) -> int {
+    const int r = lens[b] - 1;
+    if (chunks_only) return 0;
+    if (L->pg_forced) return total > (size_t)kMaxRows ? 3 : 0;   // 3: one pass, kernels by the pass's row count (launch_layers_big)
+    return r <= kMaxRows ? 0 : r < L->pf_long ? 1 : 2;
+  };
+  size_t ncls[4] = {0, 0, 0, 0};
+  for (int b = 0; b < B; ++b) ncls[cls_of(b)] += lens[b] - 1;
+  const size_t nchunks = (ncls[0] + kMaxRows - 1) / kMaxRows;
+  // plan: [class 2 rows][class 1 rows][class 3 rows][class 0 rows, padded to whole chunks][the B last-token rows]
+  const size_t off2 = 0, off1 = ncls[2], off3 = off1 + ncls[1], off0 = off3 + ncls[3], tail = off0 + nchunks * kMaxRows;
   int rc;
-  if ((rc = ensure_plan(L, nchunks * kMaxRows + kMaxRows))) return rc;
-  L->host_rows.assign(nchunks * kMaxRows + kMaxRows, RowDesc{0, 0, 0, 0});
-  size_t r = 0;
+  if ((rc = ensure_plan(L, tail + kMaxRows))) return rc;
+  L->host_rows.assign(tail + kMaxRows, RowDesc{0, 0, 0, 0});
+  {
+    size_t w[4] = {off0, off1, off2, off3};
+    for (int b = 0; b < B; ++b) {
+      size_t& r = w[cls_of(b)];
+      for (int t = 0; t + 1 < lens[b]; ++t) L->host_rows[r++] = RowDesc{slots[b], t, (int32_t)ids[(size_t)b * P_max + t], 0};
+    }
+  }
   for (int b = 0; b < B; ++b)
-    for (int t = 0; t + 1 < lens[b]; ++t) L->host_rows[r++] = RowDesc{slots[b], t, (int32_t)ids[(size_t)b * P_max + t], 0};
-  for (int b = 0; b < B; ++b)
-    L->host_rows[nchunks * kMaxRows + b] = RowDesc{slots[b], lens[b] - 1, (int32_t)ids[(size_t)b * P_max + lens[b] - 1], 0};   // flags = tokens emitted
+    L->host_rows[tail + b] = RowDesc{slots[b], lens[b] - 1, (int32_t)ids[(size_t)b * P_max + lens[b] - 1], 0};   // flags = tokens emitted
   SMI_HIP(hipMemcpyAsync(L->plan, L->host_rows.data(), L->host_rows.size() * sizeof(RowDesc), hipMemcpyHostToDevice, st));
   // measured (tools/prefill_time.py, profiles/README.md): 32-row chunks ~1.4 ms each; row-grouped decode GEMMs
   // ~1.5 ms + 9 us/row; the prefill GEMM ~15 ms + 5 us/row (crossover near 3000 rows)
-  if (total > (size_t)kMaxRows && !smi_env("SPARKMI_PREFILL_CHUNKS") && !L->exact) {   // (exact-weights mode: 64-row chunks through k_gemm_x)
-    // many prompt rows: whole groups of up to kBigRows rows through the prefill GEMM (k_pgemm)
+  const size_t pass_off[3] = {off2, off1, off3}, pass_rows[3] = {ncls[2], ncls[1], ncls[3]};
+  const int pass_family[3] = {PF_PGEMM, PF_GROUPED, PF_PGEMM};   // (class 3: the family argument is overridden per kernel by pg_min)
+  for (int ps = 0; ps < 3; ++ps) {
+    if (pass_rows[ps] == 0) continue;
+    // whole groups of up to kBigRows rows through the row-grouped decode GEMMs / the prefill GEMM (k_pgemm)
     constexpr size_t kBigRows = 4096;
-    if ((rc = ensure_big(L, (int)(total < kBigRows ? total : kBigRows)))) return rc;
-    for (size_t r0 = 0; r0 < total; r0 += kBigRows) {
-      const int M = (int)((total - r0) < kBigRows ? (total - r0) : kBigRows);
+    if ((rc = ensure_big(L, (int)(pass_rows[ps] < kBigRows ? pass_rows[ps] : kBigRows)))) return rc;
+    for (size_t q0 = 0; q0 < pass_rows[ps]; q0 += kBigRows) {
+      const size_t r0 = pass_off[ps] + q0;
+      const int M = (int)((pass_rows[ps] - q0) < kBigRows ? (pass_rows[ps] - q0) : kBigRows);
       const RowDesc* rows = L->plan + r0;
       // prefill attention tiles of this row group: runs of up to 16 rows that are consecutive tokens of one KV slot
       L->pf_ntiles = 0;
@@ -4127,20 +4338,20 @@ static int prefill_prompts(smi_llm* L, const int64_t* ids, const int32_t* lens, 
         SMI_HIP(hipMemcpyAsync(L->pf_tiles, T.data(), T.size() * sizeof(PfTile), hipMemcpyHostToDevice, st));
         L->pf_ntiles = (int)T.size();
       }
+      const bool d_grouped = L->pg_forced ? M < L->pg_min[3] : pass_family[ps] == PF_GROUPED;   // who leaves the RMSNorm partials of the layer input
       hipLaunchKernelGGL(k_embed, dim3((M + 3) / 4), dim3(256), 0, st, (const uint16_t*)sec(L, SMI_LLM_LM_HEAD, 0), L->KTh, rows, M,
-                         (const float*)sec(L, SMI_LLM_LN1, 0), L->bh, L->bxs_h, L->bss, M < L->pg_min[3] ? L->NTh * 4 : L->NTh, 0);
+                         (const float*)sec(L, SMI_LLM_LN1, 0), L->bh, L->bxs_h, L->bss, d_grouped ? L->NTh * 4 : L->NTh, 0);
       SMI_LAUNCH_CHECK();
-      if ((rc = launch_layers_big(L, rows, M, st))) return rc;
-    }
-  } else {
-    for (size_t c = 0; c < nchunks; ++c) {
-      const int M = (int)((total - c * kMaxRows) < (size_t)kMaxRows ? (total - c * kMaxRows) : kMaxRows);
-      const RowDesc* rows = L->plan + c * kMaxRows;
-      if ((rc = launch_embed(L, rows, M, st))) return rc;
-      if ((rc = launch_layers(L, rows, M, true, st))) return rc;
+      if ((rc = launch_layers_big(L, rows, M, pass_family[ps], st))) return rc;
     }
   }
-  *tail_off = nchunks * kMaxRows;
+  for (size_t c = 0; c < nchunks; ++c) {
+    const int M = (int)((ncls[0] - c * kMaxRows) < (size_t)kMaxRows ? (ncls[0] - c * kMaxRows) : kMaxRows);
+    const RowDesc* rows = L->plan + off0 + c * kMaxRows;
+    if ((rc = launch_embed(L, rows, M, st))) return rc;
+    if ((rc = launch_layers(L, rows, M, true, st))) return rc;
+  }
+  *tail_off = tail;
   return SMI_OK;
 }
 

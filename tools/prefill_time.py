@@ -44,6 +44,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "pf2":   # prefill attention: 16-row til
     modes = (("attn tiles (k_attn_pf2)", {}), ("attn per row (k_attn_pf)", {"SPARKMI_ATTN_PF2": "0"}))
 if len(sys.argv) > 1 and sys.argv[1] == "gu1":   # gate_up's one-batch shape beyond 32 rows (row-grouped prefill)
     modes = tuple((f"grouped gu1<={r}", {"SPARKMI_PGEMM_MIN_ROWS": "100000", "SPARKMI_GU1_ROWS": str(r)}) for r in (32, 128, 100000))
+if len(sys.argv) > 1 and sys.argv[1] == "r04":   # round 4: kernels by each sequence's own length; few-row shapes + split-K up to 512 rows
+    os.environ.setdefault("PF_SIZES", "1x128,1x66,1x256,1x460,4x128,8x460,32x128")
+    modes = (("default (own length: prefill GEMM family, few-row shapes <= 512 rows)", {}), ("many-row shapes at any size", {"SPARKMI_PG_SPLIT_ROWS": "0"}),
+             ("row-grouped decode GEMMs (round 3's choice below 288..1280 rows)", {"SPARKMI_PGEMM_MIN_ROWS": "100000"}), ("round-3 thresholds by total rows", {"SPARKMI_PGEMM_MIN_GU": "288", "SPARKMI_PGEMM_MIN_D": "896", "SPARKMI_PGEMM_MIN_QKV": "1280", "SPARKMI_PGEMM_MIN_O": "1280"}))
 for mode, env in modes:
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MODE=mode, **env), capture_output=True, text=True)
     print(r.stdout.strip() or r.stderr[-1500:], flush=True)
