@@ -2065,13 +2065,21 @@ struct AttnP {
   // fused o_proj (one-row kernel): this head's two k tiles of W_o against its own output -> per-head partial of the o_proj
   const uint4* Wo;     // [NTo][2 * n_heads][64] tiles (head-interleaved k order)
   int NTo;             // n tiles of W_o (hidden / 16)
-  float* part_o;       // [n_heads][NTo * 16] f32
+  float* part_o;       // [n_heads][NTo * 16] f32 (FUSE = 2: [row][n_heads][NTo * 16])
+  // FUSE = 2 (2 .. 8 rows): the last of a (row, quarter)'s n_heads blocks to arrive adds the heads' partials in order and runs
+  // the RESID epilogue of the o_proj for that quarter of the row's columns
+  unsigned int* cnt;   // [rows][kFuseQB] arrival counters (zero between launches: the last arriver resets its counter)
+  float* h;            // [rows][hidden] residual stream: read and rewritten (h += o_proj)
+  const float* gamma_next;   // the post-attention norm's weight
+  unsigned char* xs_next;    // its operand triples [hidden / 32][3][4][M][16 B]
+  float* ssout;        // [rows][NTo * 4] partial sums of squares of the new residual rows
 };
 
 constexpr int kAttnWaves = 8;
 constexpr int kAttnSeg = 1024;   // tokens per segment (a multiple of the chunk of either KV type)
 constexpr int kFuseQB = 4;       // fused o_proj: blocks per head -- each repeats the head's attention (latency-bound, the CUs are idle anyway)
                                  // and takes a quarter of W_o's n tiles: a CU pulls 28 KB of cold weights instead of 112 KB
+constexpr int kFuse2Max = 8;     // rows up to which several live rows take the fused attention + o_proj (FUSE = 2: last-arriver head sum)
 constexpr int kFuseOT = 2;       // W_o n tiles per wave (8 waves x 2 x 4 blocks x 16 = hidden sizes up to 1024)
 
 // 8 waves; a group of LPT lanes owns one token per pass (16-byte K and V pieces per lane, dot product
@@ -2094,9 +2102,18 @@ constexpr int kFuseOT = 2;       // W_o n tiles per wave (8 waves x 2 x 4 blocks
 // PG (with ONE != 0): the KV cache is paged -- a token's row comes through the slot's page-table row (one more dependent,
 // cache-resident load in front of the K/V loads; every table entry is a valid page at all times, so the unconditional first
 // chunk stays safe), everything else as the slot == row kernels.
+// FUSE == 2 (with ONE == 2; round 4): the fused o_proj for 2 .. 8 live rows.  Four blocks per (row, head) as at one row; a block
+// leaves its per-head partial of a quarter of the row's columns in part_o with write-through (sc1) stores, drains them, and -- behind
+// a workgroup barrier -- one lane counts the block in on the (row, quarter)'s counter with an agent-scope atomic add.  The block whose
+// add returns n_heads - 1 is the last: its first 56 lanes read the n_heads partials of their 4 columns with sc1 loads (the guide's
+// hand-off form: every payload byte stored sc1 and drained before the count, every read of it an sc1 load behind the add), add
+// them in head order -- the order k_gemm<RESID> with NW = n_heads adds its waves, and gate_up's one-row prologue its partials --
+// and run the RESID epilogue (residual add, h, the next norm's operand triples, partial sums of squares).  No block ever waits for
+// another: nothing can dead-lock and there is nothing to time out.  The o_proj launch (and its boundary) is gone for these row
+// counts; gate_up reads an ordinary operand (with more rows the per-head partials would be re-read by every gate_up block).
 template <int KVF32, int ONE = 0, int FUSE = 0, int PG = 0>
 __global__ __launch_bounds__((FUSE ? 2 : 1) * kAttnWaves * 64) void k_attn(AttnP p) {
-  static_assert(!FUSE || ONE == 1, "fused o_proj: one-row kernel only");
+  static_assert(!FUSE || (FUSE == 1 && ONE == 1) || (FUSE == 2 && ONE == 2), "fused o_proj: one row (per-head partials for gate_up) or 2..8 rows (last-arriver head sum)");
   constexpr int LPT = KVF32 ? 16 : 8;   // lanes per token row (each lane 16 bytes)
   constexpr int DPL = kHeadDim / LPT;   // dims per lane
   constexpr int TPW = 64 / LPT;         // tokens per wave per pass
@@ -2109,14 +2126,24 @@ __global__ __launch_bounds__((FUSE ? 2 : 1) * kAttnWaves * 64) void k_attn(AttnP
   __shared__ float sl[kAttnWaves][TPW];
   __shared__ float pw[kAttnWaves][kHeadDim], pl[kAttnWaves];
   __shared__ __attribute__((aligned(16))) unsigned char xsl[FUSE ? 2 * 3 * 4 * 16 : 16];   // FUSE: this head's output as B-operand pieces
+  __shared__ unsigned int s_last;   // FUSE == 2: this block was the last of its (row, quarter) to arrive
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if ((int)blockIdx.x >= p.work_blocks) {
     pf_run(p.pf, (int)blockIdx.x - p.work_blocks, (int)gridDim.x - p.work_blocks, tid, (FUSE ? 2 : 1) * kAttnWaves * 64);
     return;
   }
+  // FUSE == 2: natural block order (row, quarter, head), head fastest -- the 7 query heads of a KV group and the four quarter
+  // blocks of a row are neighbours; XCD x takes the x-th contiguous eighth of it (as the unfused batched kernel does)
+  unsigned fbid = blockIdx.x;
+  if constexpr (FUSE == 2) {
+    const unsigned total = (unsigned)p.work_blocks, xcd = fbid & 7u, slot = fbid >> 3, q8 = total >> 3, r8 = total & 7u;
+    fbid = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
+  }
+  const int f_head = FUSE ? (int)(fbid % (unsigned)p.n_heads) : 0, f_q = FUSE ? (int)(fbid / (unsigned)p.n_heads) % kFuseQB : 0,
+            f_row = FUSE == 2 ? (int)(fbid / (unsigned)(p.n_heads * kFuseQB)) : 0;
   if constexpr (FUSE) {
     if (wave >= kAttnWaves) {   // the o_proj waves: tiles (nt, half * n_heads + head), nt = fq * fper + (wave - 8) + 8 i
-      const int fq = (int)blockIdx.x / p.n_heads, fper = p.NTo / kFuseQB, fh = (int)blockIdx.x % p.n_heads;
+      const int fq = f_q, fper = p.NTo / kFuseQB, fh = f_head;
       const int ow = wave - kAttnWaves, KTo = 2 * p.n_heads;
       uint4 wo[kFuseOT][2];
 #pragma unroll
@@ -2143,13 +2170,22 @@ __global__ __launch_bounds__((FUSE ? 2 : 1) * kAttnWaves * 64) void k_attn(AttnP
           f32x4 t;
 #pragma unroll
           for (int r = 0; r < 4; ++r) t[r] = (smi_dpp<0x102>(a0[r]) + smi_dpp<0x101>(a0[r])) + a0[r];   // (lo + mid) + hi
-          if ((lane & 15) == 0)
-            *(float4*)(p.part_o + (size_t)fh * (p.NTo * 16) + nt * 16 + 4 * (lane >> 4)) = make_float4(t[0], t[1], t[2], t[3]);
+          if ((lane & 15) == 0) {
+            float* dst = p.part_o + ((size_t)f_row * p.n_heads + fh) * (p.NTo * 16) + nt * 16 + 4 * (lane >> 4);
+            if constexpr (FUSE == 2) {   // write-through: the last arriver reads these from another CU inside this launch
+#pragma unroll
+              for (int r = 0; r < 4; ++r) __hip_atomic_store((uint32_t*)dst + r, __float_as_uint(t[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+              *(float4*)dst = make_float4(t[0], t[1], t[2], t[3]);
+            }
+          }
         }
       }
-      return;
+      if constexpr (FUSE != 2) return;
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial stores have left before the block is counted in
     }
   }
+  if (!FUSE || wave < kAttnWaves) {   // ---- the attention waves (FUSE == 2: the o_proj waves skip to the arrival protocol below)
   // Several rows: the query heads of one KV group (and a row's segments) are neighbours in the natural block order, but
   // consecutive block ids go to the 8 XCDs round-robin, so each of a group's 7 heads would pull the same K/V rows into a
   // different L2.  Re-number: XCD x works through the x-th contiguous eighth of the natural order.
@@ -2158,8 +2194,8 @@ __global__ __launch_bounds__((FUSE ? 2 : 1) * kAttnWaves * 64) void k_attn(AttnP
     const unsigned total = (unsigned)p.work_blocks, xcd = bid & 7u, slot = bid >> 3, q8 = total >> 3, r8 = total & 7u;
     bid = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
   }
-  const int head = ONE == 1 ? (FUSE ? (int)bid % p.n_heads : (int)bid) : ONE == 2 ? (int)bid % p.n_heads : (int)(bid / p.nseg) % p.n_heads,
-            m = ONE == 1 ? 0 : ONE == 2 ? (int)bid / p.n_heads : (int)bid / (p.nseg * p.n_heads),
+  const int head = FUSE == 2 ? f_head : ONE == 1 ? (FUSE ? (int)bid % p.n_heads : (int)bid) : ONE == 2 ? (int)bid % p.n_heads : (int)(bid / p.nseg) % p.n_heads,
+            m = FUSE == 2 ? f_row : ONE == 1 ? 0 : ONE == 2 ? (int)bid / p.n_heads : (int)bid / (p.nseg * p.n_heads),
             seg = ONE ? 0 : (int)bid % p.nseg;
   const int tl = lane / LPT, dl = lane % LPT;
   const int grp = wave * TPW + tl;
@@ -2312,6 +2348,54 @@ __global__ __launch_bounds__((FUSE ? 2 : 1) * kAttnWaves * 64) void k_attn(AttnP
     }
   }
   if constexpr (FUSE) __syncthreads();   // the o_proj waves take over: xsl holds this head's output
+  }   // attention waves
+  if constexpr (FUSE == 2) {
+    __syncthreads();                          // every o_proj wave of this block has drained its partial stores (vmcnt(0) above)
+    unsigned int* cnt = p.cnt + f_row * kFuseQB + f_q;
+    if (tid == 0) s_last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(p.n_heads - 1);
+    __syncthreads();                          // (the adding lane joins only after its add has returned)
+    if (!s_last) return;                      // block-uniform
+    const int H = p.NTo * 16, ncol4 = H / kFuseQB / 4;     // float4 column groups of this quarter (56 at 0.5B)
+    if (tid < ncol4) {
+      const int n = f_q * (H / kFuseQB) + 4 * tid, m = f_row, M = p.M;
+      // the heads in order (k_gemm<RESID, NW = n_heads>'s wave order, k_gemm<PRO_FUSEDO>'s partial order), every read an sc1 load
+      // (ALL reads are requested before the first is used: as a loop over the heads they were 14 dependent memory round trips --
+      // write-through stores leave no copy in any L2 -- and the kernel took 17 us at 8 rows)
+      uint32_t pv[kMaxOHeads][4];
+#pragma unroll
+      for (int hd = 0; hd < kMaxOHeads; ++hd) {
+        const uint32_t* src = (const uint32_t*)(p.part_o + ((size_t)m * p.n_heads + (hd < p.n_heads ? hd : p.n_heads - 1)) * H + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[hd][r] = __hip_atomic_load(src + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      float y[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[r] = __uint_as_float(pv[0][r]);
+#pragma unroll
+      for (int hd = 1; hd < kMaxOHeads; ++hd)
+        if (hd < p.n_heads) {   // uniform
+#pragma unroll
+          for (int r = 0; r < 4; ++r) y[r] += __uint_as_float(pv[hd][r]);
+        }
+      // k_gemm's RESID epilogue for row m, columns n .. n + 3
+      const float4 egam = *(const float4*)(p.gamma_next + n);
+      float4 h = *(const float4*)(p.h + (size_t)m * H + n);
+      h.x += y[0]; h.y += y[1]; h.z += y[2]; h.w += y[3];
+      *(float4*)(p.h + (size_t)m * H + n) = h;
+      const float ssq = (h.x * h.x + h.y * h.y) + (h.z * h.z + h.w * h.w);
+      const float t[4] = {egam.x * h.x, egam.y * h.y, egam.z * h.z, egam.w * h.w};
+      uint32_t hi[4], mi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split3(t[e], hi[e], mi[e], lo[e]);
+      const size_t o = xs_off(n >> 5, 0, (n >> 3) & 3, m, M) + ((n >> 2) & 1) * 8;
+      const size_t pl = (size_t)4 * M * 16;
+      *(uint2*)(p.xs_next + o) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+      *(uint2*)(p.xs_next + o + pl) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
+      *(uint2*)(p.xs_next + o + 2 * pl) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+      p.ssout[((size_t)m * p.NTo + (n >> 4)) * 4 + ((n >> 2) & 3)] = ssq;
+    }
+    if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+  }
 }
 
 // Prompt rows (prefill of more than one chunk): one WAVE per (row, head), eight consecutive rows of one head per
@@ -3123,6 +3207,9 @@ struct smi_llm {
   float4* dpart;       // chain-split down_proj (k_downC): [16 chains][NTh][4 m-tiles][64] chain sums
   int dc_min;          // rows from which down_proj runs chain-split (default 7; SPARKMI_DC_MIN in the diagnostics build)
   int fuse_o;          // config allows the fused o_proj (SPARKMI_NO_FUSE_O=1 turns it off)
+  int fuse1_last;      // diagnostics (SPARKMI_FUSE1_LAST=1): ONE live row also takes the last-arriver form instead of per-head partials summed by every gate_up block (A/B for DESIGN 3.9)
+  int fuse2_rows;      // rows up to which 2+ live rows take the fused attention + o_proj with the last-arriver head sum (diagnostics: SPARKMI_FUSE2_ROWS; default 0 = off: measured slower)
+  unsigned int* fuse_cnt;   // [kFuse2Max][kFuseQB] arrival counters of that kernel (zero between launches)
   RowDesc* rows;       // live decode rows [kMaxRows]
   RowDesc* plan;       // prefill plan
   PfTile* pf_tiles;     // prefill attention tiles of the row group in flight (k_attn_pf2)
@@ -3543,8 +3630,9 @@ template <int KVF32>
 int launch_attn(smi_llm* L, AttnP a, int helpers_ok, hipStream_t st) {
   a.nseg = L->attn_seg < 1 ? 1 : L->attn_seg;
   a.work_blocks = a.n_heads * a.M * a.nseg;
-  const bool fuse = a.M == 1 && a.nseg == 1 && a.slot_is_row && a.part_o;
-  if (fuse) a.work_blocks *= kFuseQB;
+  const bool fuse = a.M == 1 && a.nseg == 1 && a.slot_is_row && a.part_o && !a.cnt;
+  const bool fuse2 = a.nseg == 1 && a.slot_is_row && a.part_o && a.cnt;   // (a.cnt is only set by fuse2_now)   // 2 .. 8 rows: fused o_proj + last-arriver head sum
+  if (fuse || fuse2) a.work_blocks *= kFuseQB;
   if (a.nseg > 1) {
     int rc = ensure_apart(L, (size_t)a.M * a.n_heads * a.nseg * 66);
     if (rc) return rc;
@@ -3552,6 +3640,13 @@ int launch_attn(smi_llm* L, AttnP a, int helpers_ok, hipStream_t st) {
   }
   const int helpers = (helpers_ok && (L->prefetch_mask & 2) && a.M <= L->prefetch_rows && a.work_blocks < 232) ? (256 - a.work_blocks) / 8 * 8 : 0;
   const bool pg = a.km.ptab != nullptr;   // paged cache: the slot == row kernels look the token's page up (PG)
+#ifdef SMI_DIAG   // measured, not adopted: the product library does not carry these instantiations
+  if (fuse2 && pg)
+    hipLaunchKernelGGL((k_attn<KVF32, 2, 2, 1>), dim3(a.work_blocks), dim3(2 * kAttnWaves * 64), 0, st, a);
+  else if (fuse2)
+    hipLaunchKernelGGL((k_attn<KVF32, 2, 2>), dim3(a.work_blocks), dim3(2 * kAttnWaves * 64), 0, st, a);
+  else
+#endif
   if (fuse && pg)
     hipLaunchKernelGGL((k_attn<KVF32, 1, 1, 1>), dim3(a.work_blocks + helpers), dim3(2 * kAttnWaves * 64), 0, st, a);
   else if (fuse)
@@ -3578,7 +3673,12 @@ int launch_attn(smi_llm* L, AttnP a, int helpers_ok, hipStream_t st) {
 // (k_attn<.., FUSE>), gate_up builds its operand from those partials (PRO_FUSEDO) and down_proj adds its residual from h2;
 // the o_proj kernel is not launched.  The predicate is the one launch_attn picks the one-row kernel by.
 bool fuse_o_now(const smi_llm* L, const RowDesc* rows, int M) {
-  return L->fuse_o && M == 1 && rows == L->rows && L->identity_slots && L->attn_seg <= 1;
+  return L->fuse_o && !L->fuse1_last && M == 1 && rows == L->rows && L->identity_slots && L->attn_seg <= 1;
+}
+// 2 .. fuse2_rows live rows, each in its own slot, one context segment: the attention kernel also computes the o_proj and the last
+// block of a (row, quarter) to arrive finishes the rows (k_attn<.., FUSE = 2>); the o_proj kernel is not launched.
+bool fuse2_now(const smi_llm* L, const RowDesc* rows, int M) {
+  return L->fuse_o && M >= (L->fuse1_last ? 1 : 2) && M <= L->fuse2_rows && rows == L->rows && L->identity_slots && L->attn_seg <= 1;
 }
 
 // o_proj: NW = number of heads, so that wave w sums head w's two (head-interleaved) k tiles -- the per-head partial the
@@ -3697,10 +3797,15 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       // helpers: second half of this layer's gate_up slices
       a.pf = PfDesc{sec(L, SMI_LLM_WGU, layer), L->KTh * 1024, L->NTgu, (L->NTgu / 8 + 1) / 2, (L->NTgu + 7) / 8};
       if (fused) { a.Wo = (const uint4*)sec(L, SMI_LLM_WO, layer); a.NTo = L->NTh; a.part_o = L->part_o; }
+      if (fuse2_now(L, rows, M)) {
+        a.Wo = (const uint4*)sec(L, SMI_LLM_WO, layer); a.NTo = L->NTh; a.part_o = L->part_o; a.cnt = L->fuse_cnt;
+        a.h = L->h; a.gamma_next = (const float*)sec(L, SMI_LLM_LN2, layer); a.xs_next = L->xs_h; a.ssout = L->sspart;
+      }
       return c.kv_dtype ? launch_attn<1>(L, a, 1, st) : launch_attn<0>(L, a, 1, st);
     }
     case KO:   // h += Wo attn; emits the post-attention norm's operand
       if (fused) return SMI_OK;   // done by the attention kernel (per-head partials) and gate_up's prologue
+      if (fuse2_now(L, rows, M)) return SMI_OK;   // done by the attention kernel (per-head partials + last-arriver head sum and epilogue)
       p.W = (const uint4*)sec(L, SMI_LLM_WO, layer); p.NT = L->NTh; p.KT = L->KTq;
       p.XS = L->xs_attn; p.Y = L->h;
       p.XSout = L->xs_h; p.gamma_next = (const float*)sec(L, SMI_LLM_LN2, layer); p.ssout = L->sspart;
@@ -4085,7 +4190,13 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   { const char* e = smi_env("SPARKMI_GRAPH_STEPS"); L->graph_steps = e ? atoi(e) : 8; if (L->graph_steps < 1 || L->graph_steps > 32) L->graph_steps = 8; }
   { const char* e = smi_env("SPARKMI_PF_INLINE"); L->pf_inline = !(e && e[0] == '0'); }
   { const char* e = smi_env("SPARKMI_PF_QKV"); L->pf_qkv_eighths = e ? atoi(e) : 2; if (L->pf_qkv_eighths < 0 || L->pf_qkv_eighths > 8) L->pf_qkv_eighths = 2; }
-  L->part_o = nullptr; L->h2 = nullptr; L->dpart = nullptr;
+  L->part_o = nullptr; L->h2 = nullptr; L->dpart = nullptr; L->fuse_cnt = nullptr;
+  { const char* e = smi_env("SPARKMI_FUSE1_LAST"); L->fuse1_last = e && e[0] == '1'; }
+  // OFF by default (diagnostics build: SPARKMI_FUSE2_ROWS=n enables it up to n <= 8 rows).  Measured at 0.5B, graph step, one box
+  // (profiles/r04_fused_oproj_last_arriver.txt): 8 rows 730 -> 863 us (attention 3.9 -> 14.1 us for the 4.3-us o_proj launch it
+  // replaces), 2 rows 616 -> 640, one row (SPARKMI_FUSE1_LAST=1, against the per-head partials every gate_up block sums) 543 -> 581:
+  // the arrival count + the reads of write-through partials cost 3-4 us at one row, where a kernel boundary costs 1.8.
+  { const char* e = smi_env("SPARKMI_FUSE2_ROWS"); L->fuse2_rows = e ? atoi(e) : 0; if (L->fuse2_rows > kFuse2Max) L->fuse2_rows = kFuse2Max; }
   // rows from which down_proj runs chain-split (k_downC): graph step at 0.5B, same box (profiles/r04_batch_ab.txt): 4 rows 641 (k_downS) vs
   // 692 us (chains), 8 rows 728 vs 713, 16 rows 790 (k_gemm<.., H = 4>) vs 744, 32 rows 892 vs 859
   // (5 / 6 rows: 731 / 728 us with the chains, the same as k_downS within noise -- the chains take over from 7)
@@ -4141,7 +4252,9 @@ int smi_llm_create(const smi_llm_cfg* cfg, const void* arena_dev, size_t arena_b
   SMI_ALLOC(L->xs_attn, (size_t)kMaxRows * L->Q * 6);
   SMI_ALLOC(L->xs_act, (size_t)kMaxRows * L->I * 6);
   SMI_ALLOC(L->sspart, (size_t)kMaxRows * L->NTh * 4 * 4);
-  SMI_ALLOC(L->part_o, (size_t)kMaxOHeads * L->H * 4);
+  SMI_ALLOC(L->part_o, (size_t)kFuse2Max * kMaxOHeads * L->H * 4);
+  SMI_ALLOC(L->fuse_cnt, (size_t)kFuse2Max * kFuseQB * 4);
+  SMI_HIP(hipMemset(L->fuse_cnt, 0, (size_t)kFuse2Max * kFuseQB * 4));
   SMI_ALLOC(L->h2, (size_t)L->H * 4);
   SMI_ALLOC(L->dpart, (size_t)16 * L->NTh * 4 * 64 * 16);
   SMI_ALLOC(L->rows, kMaxRows * sizeof(RowDesc));
@@ -4213,7 +4326,7 @@ int smi_llm_destroy(smi_llm* L) {
   if (!L) return SMI_OK;
   graphs_flush(L);
   eng_destroy(L);
-  void* ptrs[] = {L->h, L->qbuf, L->xs_h, L->xs_attn, L->xs_act, L->sspart, L->part_o, L->h2, L->dpart, L->rows, L->plan, L->pf_tiles, L->pval, L->pidx, L->hist,
+  void* ptrs[] = {L->h, L->qbuf, L->xs_h, L->xs_attn, L->xs_act, L->sspart, L->part_o, L->h2, L->dpart, L->fuse_cnt, L->rows, L->plan, L->pf_tiles, L->pval, L->pidx, L->hist,
                   L->count, L->finished, L->step, L->ctl, L->ptab, L->kcache, L->vcache, L->logits, L->tok, L->cand_v, L->cand_i, L->cand_n, L->stamps, L->bh, L->bq, L->bxs_h, L->bxs_attn, L->bxs_act, L->bss, L->pslab, L->apart};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);

@@ -93,6 +93,38 @@ def test_a_sequence_does_not_depend_on_its_batch_with_the_bf16_cache(full_llm, m
         assert np.array_equal(inblock.debug_get_kv(cfg.num_hidden_layers - 1, 0, 0, lens[b])[0], kv_big[b][1]), "split-K vs in-block segments"
 
 
+@pytest.mark.parametrize("B", [2, 8])
+def test_fused_o_proj_with_the_last_arriver_head_sum_keeps_the_bits(full_llm, monkeypatch, B):
+    """The diagnostics build's opt-in form for 2 .. 8 live rows (SPARKMI_FUSE2_ROWS; measured slower than the separate o_proj launch
+    and off by default, DESIGN 3.9 -- kept because it is the in-launch hand-off the review asked to be measured, and correct):
+    the attention kernel also computes the o_proj and the LAST of a (row, quarter)'s 14 head blocks to arrive
+    adds the heads in order and finishes the rows (k_attn<.., FUSE = 2>: sc1 partial stores, an agent-scope arrival count, sc1
+    reads).  120 free-running steps of ragged contexts (uneven load: the rows' contexts differ by hundreds of tokens, so their
+    head blocks finish at different times) must give the tokens -- and, teacher-forced, the residual rows -- of the separate o_proj
+    kernel (SPARKMI_FUSE2_ROWS=0) bit for bit, and every row must equal its own one-row run."""
+    from conftest import FULL_MAX_POS
+    from sparkmi.llm import SparkLLM
+    cfg, syn, arena = full_llm
+    rng = np.random.Generator(np.random.PCG64(88 + B))
+    lens = [int(v) for v in rng.integers(5, 400, size=B)]
+    prompts = [rng.integers(0, cfg.vocab_size, size=L).tolist() for L in lens]
+    n = 120
+    mk = lambda slots: SparkLLM(cfg, None, "cuda:0", max_slots=slots, max_positions=FULL_MAX_POS, arena=arena, kv_dtype="bf16", diag=True)  # noqa: E731
+    monkeypatch.setenv("SPARKMI_FUSE2_ROWS", "8")
+    fused = mk(B)
+    got = fused.generate_ids(prompts, n)
+    h_fused = fused.debug_hidden()
+    again = fused.generate_ids(prompts, n)            # second utterance on the same captured graphs: the counters were left at zero
+    assert again == got
+    monkeypatch.delenv("SPARKMI_FUSE2_ROWS")
+    plain = mk(B)
+    assert plain.generate_ids(prompts, n) == got
+    assert np.array_equal(plain.debug_hidden(), h_fused)
+    one = mk(1)
+    for b in range(B):
+        assert one.generate_ids([prompts[b]], n)[0] == got[b], f"row {b} of {B}"
+
+
 def test_config3_ragged_batch_with_rows_retired_equals_the_padded_batch(full_llm):
     """What `bench.py --batch 32` runs (configs[2] / [3]): 32 ragged prompts (97..154 ids), per-row token budgets, rows retired on
     the device as they reach their budget (`SparkLLM.generate_ragged`: admit through the session path, cached step graph per
@@ -134,9 +166,11 @@ def test_paged_kv_cache_at_full_size_equals_contiguous_cache_and_oracle(full_llm
                 assert got[b] == want, f"row {b} vs oracle"
             else:
                 _assert_same_or_tie(flat, prompts[b], got[b], want, f"row {b} vs oracle")
-        # one sequence alone on the paged engine (the general kernels: no one-row engine, no fused o_proj) = its row of the batch
-        if kv == "f32":
-            assert paged.generate_ids([prompts[5]], n)[0] == got[5]
+        # one sequence alone on the paged engine (the one-row kernels through the page table: k_attn<.., ONE, FUSE, PG = 1> with the
+        # fused o_proj) = its row of the batch = the contiguous engine's one-row run -- with either cache type: a sequence's
+        # kernels are chosen from its own length, so even the bf16 cache leaves no room for a difference
+        assert paged.generate_ids([prompts[5]], n)[0] == got[5], f"paged one-row run ({kv})"
+        assert _llm(cfg, arena, max_slots=1, kv_dtype=kv).generate_ids([prompts[5]], n)[0] == got[5], f"contiguous one-row run ({kv})"
 
 
 def test_config5_clone_length_prompts_through_the_prefill_gemm(full_llm, full_llm_oracle):

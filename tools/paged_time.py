@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Decode step with the paged KV cache against the contiguous cache at 0.5B (GPU box):  python tools/paged_time.py
-A paged engine (kv_page_tokens > 0, the serving configuration) takes the general attention kernel and the stand-alone o_proj:
-the one-row fast paths (one-row attention, fused o_proj) need slot == row addressing.  This prints what that costs."""
+A paged engine (kv_page_tokens > 0, the serving configuration) runs the same kernels as a contiguous one since round 3 -- the
+one-row attention with the fused o_proj and the slot == row batch kernel look a token's row up through the slot's page-table row
+(k_attn<.., PG = 1>) -- so what is printed here is the cost of that lookup (+17 us at one row, +22 at 32 rows at 0.5B)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "spark-tts_amd"))

@@ -47,6 +47,7 @@ if a.json:
     steps = a.tokens - 1
     roles = {}
     resid = []
+    comb = None
     for name, grid, n, rd, wr in rows:
         if n < 24 * steps and not name.startswith("k_lm") and not name.startswith("k_engine"):
             continue
@@ -58,7 +59,11 @@ if a.json:
         elif name.startswith("k_attn<"):
             roles.setdefault("attn", ent)
         elif name.startswith("k_down1<") or name.startswith("k_downS<"):
-            roles.setdefault("down", ent)         # down_proj at 1 .. 8 rows (four chains per wave)
+            roles.setdefault("down", ent)         # down_proj at 1 .. 6 rows (four chains per wave)
+        elif name.startswith("k_downC<"):
+            roles.setdefault("down", ent)         # 7 .. 64 rows: one chain per block ...
+        elif name.startswith("k_resid_comb<"):
+            comb = ent                            # ... + the in-order combine: a second launch of the same operation
         elif name.startswith("k_gemm<"):
             args = [x.strip() for x in name[name.index("<") + 1: name.rindex(">")].split(",")]
             epi = int(args[6])
@@ -68,6 +73,11 @@ if a.json:
                 roles.setdefault("gate_up", ent)
             elif epi == 0:
                 resid.append(ent)
+    if comb is not None and roles.get("down", {}).get("kernel", "").startswith("k_downC<"):
+        d = roles["down"]
+        roles["down"] = {"kernel": d["kernel"] + " + " + comb["kernel"], "grid": d["grid"], "launches": d["launches"],
+                         "read_bytes": d["read_bytes"] + comb["read_bytes"], "write_bytes": d["write_bytes"] + comb["write_bytes"],
+                         "hbm_bytes_per_launch": d["hbm_bytes_per_launch"] + comb["hbm_bytes_per_launch"], "launches_per_operation": 2}
     resid.sort(key=lambda e: -e["read_bytes"])
     if "down" in roles:                           # the residual GEMMs left are o_proj's (none at one row: fused into attention)
         if resid:

@@ -24,6 +24,8 @@ print("B", B, os.environ.get("AB_TAG"), "eager", eager, "in-seq", seq, "graph st
 ''' % ROOT
 for B in sys.argv[1:] or ["32"]:
     for rep in range(2):
-        variants = (("new", {}), ("old-down", {"SPARKMI_DC_MIN": "1000"})) if int(B) > 8 else (("default", {}), ("chains-from-2", {"SPARKMI_DC_MIN": "2"}))
+        variants = (("new", {}), ("old-down", {"SPARKMI_DC_MIN": "1000"})) if int(B) > 8 else (("fused o_proj (FUSE2)", {}), ("separate o_proj", {"SPARKMI_FUSE2_ROWS": "0"}))
+        if int(B) == 1:
+            variants = (("per-head partials summed by gate_up (default)", {}), ("last-arriver head sum", {"SPARKMI_FUSE1_LAST": "1"}))
         for tag, env in variants:
             subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AB_B=B, AB_TAG=tag, **env), check=False)
