@@ -331,9 +331,10 @@ __device__ __forceinline__ void split2x8(const float (&v)[8], uint4& hi, uint4& 
 #ifndef SMI_CB_OCC
 #define SMI_CB_OCC 4
 #endif
-template <int QB, bool KS, int CHG, int NC>
+template <int QB, bool KS, int CHG, int NC, bool WPF = false>
 __global__ __launch_bounds__(256, SMI_CB_OCC) void k_convb(ConvP p) {
   static_assert(!KS || CHG % 2 == 0, "channel-split waves own whole 16-channel steps");
+  static_assert(!WPF || (KS && CHG == 4), "WPF: one-tap layers with the channels split over the waves, 128-channel chunks");
   constexpr int kCh = 32 * CHG;        // channels per staged chunk (four waves x CHG octets)
   constexpr int NOCT = 4 * CHG;        // octets per chunk
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -391,6 +392,56 @@ __global__ __launch_bounds__(256, SMI_CB_OCC) void k_convb(ConvP p) {
         }
       }
   };
+  if constexpr (WPF) {
+    // One-tap layers with the channels split over the waves, launched with so few blocks that a SIMD holds one or two waves
+    // (one utterance: the prenet's point-wise convs, 80 blocks of 12 chunks at 150 frames).  A wave's work per chunk is 3 * QB * 2
+    // MFMAs, so the loop runs at the pace of its memory round trips: with the weights requested one step ahead INSIDE a chunk
+    // there were three of them per chunk (staged rows, first step's weights, second step's weights: ~3 us per chunk, 35 us per
+    // layer).  Here the chunk's weights -- two steps x two planes, 16 registers -- are requested one chunk ahead together with
+    // its staged rows: one round trip per chunk, hidden behind the previous chunk.  Same steps in the same order: same bits.
+    uint4 wn[4];
+    const int ksl = ksteps;   // (steps past the last one multiply zero rows: their weights are clamped loads, never used)
+    auto wload = [&](int c0) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        int st = (c0 >> 4) + wave * 2 + g;
+        st = st < ksl ? st : ksl - 1;
+        wn[2 * g] = live ? Wp[(long long)st * 128 + lane] : make_uint4(0u, 0u, 0u, 0u);
+        wn[2 * g + 1] = live ? Wp[(long long)st * 128 + 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
+      }
+    };
+    stage_load(0);
+    wload(0);
+    const int col0 = p.halo_l + p.off[phase][0] + (lane & 31);
+    for (int c0 = 0; c0 < p.CinP; c0 += kCh) {
+      if (c0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stage_store();
+      uint4 wc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wc[i] = wn[i];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (c0 + kCh < p.CinP) { stage_load(c0 + kCh); wload(c0 + kCh); }
+      if (live) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          if ((c0 >> 4) + wave * 2 + g < ksl) {   // wave-uniform
+            const uint4* bp = lds16 + (size_t)(2 * (wave * 2 + g) + (lane >> 5)) * xw + col0;
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, wc[2 * g]), am = __builtin_bit_cast(bf16x8, wc[2 * g + 1]);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+              const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[qb * 32]);
+              const bf16x8 bm = __builtin_bit_cast(bf16x8, bp[(size_t)NOCT * xw + qb * 32]);
+              acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[qb], 0, 0, 0);
+              acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[qb], 0, 0, 0);
+              acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[qb], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    conv_finish<QB, KS>(p, acc, lds, ct, live, b, phase, q0, olen, lane, wave);
+    return;
+  }
   stage_load(0);
   for (int c0 = 0; c0 < p.CinP; c0 += kCh) {
     if (c0) { if (KS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads(); }   // previous chunk fully read
@@ -430,6 +481,165 @@ __global__ __launch_bounds__(256, SMI_CB_OCC) void k_convb(ConvP p) {
     }
   }
   conv_finish<QB, KS>(p, acc, lds, ct, live, b, phase, q0, olen, lane, wave);
+}
+
+// k_convbT (round 4): ConvTranspose1d on the bf16-split pipe with PH output PHASES per block.  As a polyphase conv on k_convb
+// every phase r is its own set of blocks (grid.z = B * S): the input tile is staged S times, and -- what costs -- output element
+// (q, r) lives at t = q * S + r, so a phase's stores put 4 bytes per lane at a stride of 4 S bytes: 64 store instructions per wave
+// (16 rows x 2 column tiles x 2 outputs), each spread over 64 different 32-byte sectors -- about half of the kernel's time
+// (the transposed convs ran at 118-154 TFLOP/s fp32-equivalent beside 280-320 for the 7-tap convs of the same shapes).  Here a
+// block keeps PH accumulator sets (PH * 16 registers) for ONE 32-column tile: the chunk is staged once for the PH phases -- 32 + halo
+// <= 64 columns, one 64-lane pass per row -- and in the epilogue a lane holds the PH consecutive outputs t = q S + r0 .. + PH - 1 of
+// each of its rows: one 16-byte store (PH = 4) or PH dword stores per row.  Measured (profiles/r04_convT_multi_phase.txt): what pays
+// is the STAGING -- a 2-tap phase carries 24 MFMAs per 32 staged channels against ~150 staging instructions (loads, the fp32 -> 2 x
+// bf16 split, LDS writes), PH phases share them; the stores alone (first build: two passes per row as in k_convb) changed nothing.
+// A phase's taps and 16-channel steps run in k_convb's order (64-channel chunks), one accumulator per phase: the bits of k_convb
+// with CHG = 2.  Epilogue: bias, raw output and / or the next layer's Snake -- what the WaveGenerator's transposed convs need (the
+// launch builder checks that nothing else is asked for).
+template <int PH>
+__global__ __launch_bounds__(256, 3) void k_convbT(ConvP p) {
+  constexpr int QB = 1, NC = 1, CHG = 2, NOCT = 4 * CHG, kCh = 32 * CHG, RW = 8 * CHG;   // 32 + halo <= 64 staged columns: ONE 64-lane pass per row
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  uint4* lds16 = (uint4*)lds;          // [2 planes][NOCT][xw]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int QT = QB * 32;
+  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  const int ngrp = p.S / PH;
+  const int b = bz / ngrp, phase0 = (bz - b * ngrp) * PH;
+  const int q0 = bx * QT;
+  const int len = p.lens[b];
+  if (q0 >= len) return;
+  const int ct = by * 4 + wave;
+  const bool live = ct * 32 < p.Cout;
+  const int ksteps = (p.Cin + 15) >> 4;
+  const float* Xb = p.X + (long long)b * p.xb;
+  f32x16 acc[PH][QB];
+#pragma unroll
+  for (int h = 0; h < PH; ++h)
+#pragma unroll
+    for (int i = 0; i < QB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[h][i][r] = 0.f;
+  const int xw = p.xw;
+  float sreg[RW][NC];
+  auto stage_load = [&](int c0) {
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int ci = c0 + wave * RW + r;
+      const float* xr = Xb + (long long)(ci < p.Cin ? ci : p.Cin - 1) * p.xstride;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        const int col = lane + 64 * k, t = q0 - p.halo_l + col;
+        const bool ok = ci < p.Cin && col < xw && t >= 0 && t < len;
+        const float v = xr[t < 0 ? 0 : (t < len ? t : len - 1)];   // unconditional load from a clamped address, masked by value
+        sreg[r][k] = ok ? v : 0.f;
+      }
+    }
+  };
+  auto stage_store = [&]() {
+#pragma unroll
+    for (int g = 0; g < CHG; ++g)
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = sreg[g * 8 + r][k];
+        uint4 hi, mid;
+        split2x8(v, hi, mid);
+        if (lane + 64 * k < xw) {
+          lds16[(size_t)(wave * CHG + g) * xw + lane + 64 * k] = hi;
+          lds16[(size_t)(NOCT + wave * CHG + g) * xw + lane + 64 * k] = mid;
+        }
+      }
+  };
+  // weights of (phase, tap, step): two 1-KiB planes at wbase(phase) + ((tap * ksteps + step) * 128 + lane [+ 64])
+  auto wbase = [&](int phase) { return (const uint4*)(p.W + p.wphase[phase]) + (long long)ct * p.ntaps[phase] * ksteps * 128 + lane; };
+  stage_load(0);
+  for (int c0 = 0; c0 < p.CinP; c0 += kCh) {
+    if (c0) __syncthreads();   // previous chunk fully read
+    stage_store();
+    __syncthreads();
+    if (c0 + kCh < p.CinP) stage_load(c0 + kCh);
+    if (live) {
+      int sl = ksteps - (c0 >> 4);
+      sl = sl < 2 * CHG ? sl : 2 * CHG;            // live 16-channel steps of this chunk (>= 1)
+      const long long so = (long long)(c0 >> 4) * 128;
+      uint4 wh, wm;
+      { const uint4* w0 = wbase(phase0) + so; wh = w0[0]; wm = w0[64]; }
+#pragma unroll
+      for (int h = 0; h < PH; ++h) {
+        const int phase = phase0 + h, ntap = p.ntaps[phase];
+        const uint4* Wq = wbase(phase) + so;
+        const uint4* Wnext = wbase(h + 1 < PH ? phase + 1 : phase) + so;   // the next phase's first step (last phase: any valid address)
+        const int nstep = ntap * sl;
+        int tap = 0, g = 0;
+        for (int st = 0; st < nstep; ++st) {
+          int gn = g + 1, tn = tap;
+          if (gn == sl) { gn = 0; ++tn; }
+          const uint4* wnp = tn == ntap ? Wnext : Wq + ((long long)tn * ksteps + gn) * 128;
+          const uint4 whn = wnp[0], wmn = wnp[64];
+          __builtin_amdgcn_sched_barrier(0);
+          const int col0 = p.halo_l + p.off[phase][tap] + (lane & 31);
+          const uint4* bp = lds16 + (size_t)(2 * g + (lane >> 5)) * xw + col0;
+          const bf16x8 ah = __builtin_bit_cast(bf16x8, wh), am = __builtin_bit_cast(bf16x8, wm);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) {
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[qb * 32]);
+            const bf16x8 bm = __builtin_bit_cast(bf16x8, bp[(size_t)NOCT * xw + qb * 32]);
+            acc[h][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[h][qb], 0, 0, 0);
+            acc[h][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[h][qb], 0, 0, 0);
+            acc[h][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[h][qb], 0, 0, 0);
+          }
+          wh = whn; wm = wmn; g = gn; tap = tn;
+        }
+      }
+    }
+  }
+  if (!live) return;
+  // epilogue: register r of lane l is row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31 (the 32x32 MFMA D layout)
+  const long long yboff = (long long)b * p.yb;
+  const bool hb = p.bias != nullptr, hs = p.Ys != nullptr, hy = p.Y != nullptr, fsin = p.fast_sin != 0;
+  const float* dummy = p.X;
+#pragma unroll
+  for (int r0 = 0; r0 < 16; r0 += 8) {
+    float bv[8], av[8];
+    int co[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = r0 + i;
+      co[i] = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int cc = co[i] < p.Cout ? co[i] : p.Cout - 1;
+      bv[i] = (hb ? p.bias : dummy)[cc];
+      av[i] = (hs ? p.alpha : dummy)[cc];
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const int q = q0 + qb * 32 + (lane & 31);
+      if (q >= len) continue;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (co[i] >= p.Cout) continue;
+        float y[PH], ys[PH];
+#pragma unroll
+        for (int h = 0; h < PH; ++h) {
+          y[h] = acc[h][qb][r0 + i];
+          y[h] = hb ? y[h] + bv[i] : y[h];
+          ys[h] = snake_f(y[h], av[i], fsin);
+        }
+        const long long o = yboff + (long long)co[i] * p.ystride + (long long)q * p.S + phase0;
+        if constexpr (PH == 4) {
+          if (hy) *(float4*)(p.Y + o) = make_float4(y[0], y[1], y[2], y[3]);
+          if (hs) *(float4*)(p.Ys + o) = make_float4(ys[0], ys[1], ys[2], ys[3]);
+        } else {
+#pragma unroll
+          for (int h = 0; h < PH; ++h) {
+            if (hy) p.Y[o + h] = y[h];
+            if (hs) p.Ys[o + h] = ys[h];
+          }
+        }
+      }
+    }
+  }
 }
 
 // Conv1d with ONE output channel (the vocoder's last layer: C -> 1, 7 taps, tanh): y[b][q] = act(bias + sum_ci sum_tap W[ci][tap]
@@ -704,6 +914,7 @@ struct Launch {
   std::string name;
   double flops;
   ConvP cp; int qb; bool ks; int chg; int nwv = 4; bool gemv; bool bf = false; bool c1 = false; int c1_len = 0; dim3 grid; size_t lds;
+  int tph = 0;       // k_convbT: output phases per block of a transposed conv (0: k_convb, one phase per block)
   LnP lp; int cpt;
   // small kernels keep their args here
   const int64_t* sem; int semstride; const float* cb; int D, cbsize; float* Z; int zstride; long long zb;
@@ -719,15 +930,23 @@ int run_launch(const Launch& L, hipStream_t st) {
         hipLaunchKernelGGL(k_gemv1, L.grid, dim3(256), 0, st, L.cp);
       } else if (L.c1) {            // one output channel, 7 taps: a thread per output sample (k_conv_c1)
         hipLaunchKernelGGL((k_conv_c1<7>), dim3((L.c1_len + 255) / 256, L.grid.z), dim3(256), (size_t)L.cp.Cin * 7 * 4, st, L.cp);
+      } else if (L.bf && L.tph) {   // transposed conv, several output phases per block (k_convbT)
+        if (L.tph == 4) hipLaunchKernelGGL((k_convbT<4>), L.grid, dim3(256), L.lds, st, L.cp);
+        else hipLaunchKernelGGL((k_convbT<5>), L.grid, dim3(256), L.lds, st, L.cp);
       } else if (L.bf) {            // bf16-split matrix pipe (k_convb): weights packed as two bf16 planes
 #define SMI_CB(QB_, KS_, CHG_, NC_) hipLaunchKernelGGL((k_convb<QB_, KS_, CHG_, NC_>), L.grid, dim3(256), L.lds, st, L.cp)
         const bool wide = L.cp.xw > 64;
         if (L.chg == 4) {
-          if (L.ks) { if (L.qb == 1) SMI_CB(1, true, 4, 1); else SMI_CB(2, true, 4, 1); }
+          // one tap, channels split over the waves, at most two blocks per CU: the chunk's weights are requested one chunk ahead (WPF)
+          const bool wpf = L.ks && L.cp.S == 1 && L.cp.ntaps[0] == 1 && (long long)L.grid.x * L.grid.y * L.grid.z <= 512 && !smi_env("SPARKMI_CB_NOWPF");
+          if (wpf) { if (L.qb == 1) hipLaunchKernelGGL((k_convb<1, true, 4, 1, true>), L.grid, dim3(256), L.lds, st, L.cp); else hipLaunchKernelGGL((k_convb<2, true, 4, 1, true>), L.grid, dim3(256), L.lds, st, L.cp); }
+          else if (L.ks) { if (L.qb == 1) SMI_CB(1, true, 4, 1); else SMI_CB(2, true, 4, 1); }
           else { if (L.qb == 1) SMI_CB(1, false, 4, 1); else SMI_CB(2, false, 4, 1); }
         } else if (L.ks) {
           if (L.qb == 1) { if (wide) SMI_CB(1, true, 2, 2); else SMI_CB(1, true, 2, 1); }
           else SMI_CB(2, true, 2, 2);
+        } else if (L.chg == 2) {    // few taps per phase, rows wider than 64 columns (transposed convs): 64-channel chunks
+          if (L.qb == 1) SMI_CB(1, false, 2, 2); else SMI_CB(2, false, 2, 2);
         } else {
           if (L.qb == 1) { if (wide) SMI_CB(1, false, 1, 2); else SMI_CB(1, false, 1, 1); }
           else SMI_CB(2, false, 1, 2);
@@ -837,6 +1056,36 @@ Launch make_conv_w(const std::string& name, const float* W, const float* bias,
   L.grid = dim3(nq, L.ks ? cot : (cot + L.nwv - 1) / L.nwv, B * S);
   L.chg = (S == 1 && K == 1 && Cin >= 128 && L.ks) ? 4 : 1;   // K-split 1-tap layers stage 128 channels per chunk
   if (bf && L.ks && L.chg == 1) L.chg = 2;                     // k_convb: a channel-split wave owns whole 16-channel steps
+  // k_convb, one output tile per wave, few taps per phase (1x1 convs: 1; transposed convs: 2-3): a 32-channel chunk carries only
+  // 6 * taps MFMAs per wave between its two barriers and its staging round trip.  128-channel chunks where the staged row is one
+  // 64-column pass (1 tap), 64-channel chunks up to 128 columns (round 4; SPARKMI_CB_CHG=0: 32-channel chunks everywhere, A/B).
+  // A 1-tap layer sums its channels in the same order whatever the chunk; a transposed conv's order goes from (32 channels, taps)
+  // to (64 channels, taps) -- the choice depends on the layer's shape only, never on the batch.
+  if (bf && !L.ks && istr == 1 && Cin >= 128) {
+    int maxtap = 0;
+    for (int r = 0; r < S; ++r) maxtap = g.ntaps[r] > maxtap ? g.ntaps[r] : maxtap;
+    const char* e = smi_env("SPARKMI_CB_CHG");
+    if (maxtap <= 3 && !(e && e[0] == '0')) L.chg = p.xw <= 64 ? 4 : (p.xw <= 128 ? 2 : 1);
+  }
+  // transposed convs with a grid that still fills the chip with PH phases per block: k_convbT (SPARKMI_CBT=0: off, A/B).  Its
+  // epilogue knows bias, the raw output and the Snake'd output only: check_launches() rejects a program that set anything else
+  // on such a launch after this function returned.
+  if (bf && !L.ks && S > 1 && istr == 1 && Cin >= 64 && olens == nullptr) {
+    const int ph = S % 4 == 0 ? 4 : (S == 5 ? 5 : 0);   // (S = 2: two phases x two column tiles measured level with k_convb -- it stays there)
+    const int qbt = 1;
+    const char* e = smi_env("SPARKMI_CBT");
+    if (ph && !(e && e[0] == '0')) {
+      const int qtt = qbt * 32, nqt = (Lmax + qtt - 1) / qtt;
+      const int xwt = qtt + g.halo_l + g.halo_r;
+      // (eight blocks per CU and more: at 900 blocks the stride-5 layer of an 8-row batch lost 0.40 -> 0.48 ms, at 3000+ every layer gained)
+      if ((long long)nqt * ((cot + 3) / 4) * B * (S / ph) >= 2048 && xwt <= 64 && !R && act == ACT_NONE) {
+        L.tph = ph; L.qb = qbt; L.chg = 2;
+        p.xw = xwt;
+        L.grid = dim3(nqt, (cot + 3) / 4, B * (S / ph));
+        L.lds = (size_t)2 * 8 * xwt * 16;
+      }
+    }
+  }
   L.gemv = false;   // set by the caller for the per-utterance vector projections (use_gemv)
   size_t lds = (size_t)8 * L.nwv * L.chg * p.xw * 4;
   const size_t red = L.ks ? (size_t)4 * qb * 16 * 64 * 4 : 0;

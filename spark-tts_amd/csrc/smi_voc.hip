@@ -251,6 +251,8 @@ int check_launches(const std::vector<Launch>& P, const char* who) {
       SMI_REQUIRE(L.cp.W, "%s: arena entry for %s not found", who, L.name.c_str());
       SMI_REQUIRE(L.lds <= 64 * 1024, "%s: %s needs %zu bytes of LDS", who, L.name.c_str(), L.lds);
       SMI_REQUIRE(L.cp.xw <= 128 && (L.chg != 4 || L.cp.xw <= 64), "%s: %s stages %d columns", who, L.name.c_str(), L.cp.xw);
+      if (L.tph) SMI_REQUIRE(!L.cp.bbias && !L.cp.gamma && !L.cp.beta && !L.cp.R && !L.cp.X2 && L.cp.out_scale == 1.0f && L.cp.act == ACT_NONE,
+                             "%s: %s: the multi-phase transposed conv has a bias / Snake epilogue only", who, L.name.c_str());
     }
   }
   return SMI_OK;

@@ -165,3 +165,28 @@ def test_tiny_exact_fp32_mode_matches_reference_vectors(tiny, golden_dir):
     for case in range(4):
         wav = voc.detokenize(torch.from_numpy(g[f"c{case}_semantic"]), torch.from_numpy(g[f"c{case}_global"])).cpu().numpy()
         assert np.abs(wav - g[f"c{case}_wav"]).max() < WAV_ATOL
+
+
+
+def test_multi_phase_transposed_convs_at_batch(full_voc, monkeypatch):
+    """k_convbT keeps PH output phases of a ConvTranspose1d in one block (the chunk staged once, a lane stores the PH consecutive
+    outputs of each of its rows) wherever the grid still fills the chip: at the 0.5B shape every transposed conv of a 6-row batch
+    (strides 8, 5, 4, 2 -> 4, 5, 4 and 2 phases per block).  Per phase the taps and 16-channel steps run in k_convb's order with
+    64-channel chunks, so the ragged batch equals the same call on k_convb alone (SPARKMI_CBT=0, diagnostics build) bit for bit,
+    and its rows agree with their solo runs (another launch plan: fp32 re-association only)."""
+    cfg, sd, _ = full_voc
+    rng = np.random.Generator(np.random.PCG64(78))
+    B, T = 6, 150
+    lens = [150, 97, 150, 33, 128, 1]
+    sem = torch.from_numpy(rng.integers(0, cfg.codebook_size, size=(B, T)))
+    glob = torch.from_numpy(rng.integers(0, 4096, size=(B, 1, cfg.spk_token_num)))
+    new = _voc(cfg, sd, max_batch=B, max_frames=T + 10, diag=False)
+    w_new = new.detokenize(sem, glob, lengths=lens).cpu().numpy()
+    monkeypatch.setenv("SPARKMI_CBT", "0")
+    old = _voc(cfg, sd, max_batch=B, max_frames=T + 10, diag=True)
+    w_old = old.detokenize(sem, glob, lengths=lens).cpu().numpy()
+    assert np.array_equal(w_new, w_old)
+    for b in (1, 3, 5):
+        solo = new.detokenize(sem[b:b + 1, :lens[b]], glob[b:b + 1]).cpu().numpy()
+        assert np.abs(solo[0, :, : lens[b] * cfg.hop] - w_new[b, :, : lens[b] * cfg.hop]).max() < 1e-4
+        assert not w_new[b, :, lens[b] * cfg.hop:].any()

@@ -9,7 +9,8 @@ from sparkmi.bicodec import BiCodecVocoder
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 cfg = C.spark_0p5b_bicodec()
-voc = BiCodecVocoder(cfg, W.bicodec_detok_state(cfg), "cuda:0", max_batch=B, max_frames=T + 10)
+voc = BiCodecVocoder(cfg, W.bicodec_detok_state(cfg), "cuda:0", max_batch=B, max_frames=T + 10,
+                     diag=any(k.startswith("SPARKMI_") for k in os.environ))   # SPARKMI_* switches exist in the diagnostics build only
 rng = np.random.Generator(np.random.PCG64(3))
 sem = torch.from_numpy(rng.integers(0, 8192, size=(B, T)))
 glob = torch.from_numpy(rng.integers(0, 4096, size=(B, 1, 32)))
