@@ -3825,6 +3825,7 @@ int launch_one(smi_llm* L, int which, int layer, const RowDesc* rows, int M, flo
       p.XS = L->xs_h; p.XSout = L->xs_act;
       if (fused) {
         p.part_o = L->part_o; p.n_oheads = c.num_heads; p.hres = L->h; p.h2out = L->h2;
+        if (const char* e = smi_env("SPARKMI_FAKE_OHEADS")) p.n_oheads = atoi(e);   // TIMING ONLY (diagnostics build): gate_up reads that many partials -- wrong sums (profiles/r04_gate_up_two_tiles_and_fewer_partials.txt)
         if (const char* e = smi_env("SPARKMI_FAKE_OHEADS")) p.n_oheads = atoi(e);   // TIMING ONLY (diagnostics build): gate_up reads that many partials -- wrong sums
         if (L->pf_inline && layer + 1 < c.num_layers && L->NTqkv % 8 == 0) {   // SPARKMI_PF_INLINE=0: off (A/B)
           p.pf2_base = sec(L, SMI_LLM_WQKV, layer + 1); p.pf2_slice = L->KTh * 1024; p.pf2_nslices = L->NTqkv;
