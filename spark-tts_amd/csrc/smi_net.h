@@ -642,6 +642,199 @@ __global__ __launch_bounds__(256, 3) void k_convbT(ConvP p) {
   }
 }
 
+// k_resunit (round 4): a whole ResidualUnit (blocks/layers.py:51-67) in ONE launch where a block can hold every channel of its
+// time tile -- C = 96 (three waves) and C = 192 (six waves), the two resolutions at which the unit is bound by memory, not by the
+// matrix pipe: y = x + conv1(snake(conv7_dil(snake(x)))).  As two launches the 7-tap conv writes A = snake(conv7 + b) to HBM and the
+// 1x1 conv reads it back, stages it and splits it again: six passes over a [C][T] tensor per unit (Xs in, A out | A in, residual in,
+// raw out, Snake'd out).  Here wave w owns output tile w in BOTH convs: phase 1 is k_convb's 7-tap loop (48-channel chunks: 8 rows per
+// wave x 6 waves, or 16 x 3); its accumulators -- register r of lane l = channel 32 w + (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31:
+// four consecutive channels per lane -- get bias and Snake, are split into the two bf16 planes and go straight into the LDS image of
+// the 1x1 conv's B operand ([plane][octet][column][8 bf16], over the dead staging rows); phase 2 multiplies W1 (2 KiB per step from
+// L2) against that image, adds bias and the residual and writes the unit's two outputs.  Four passes per unit, no second staging.
+// Same products and the same (tap, step) order per chunk as k_convb; the 7-tap sum runs over 48- instead of 32-channel chunks.
+struct ResP {
+  const float* Xs;      // snake(U, alpha0): [B][C][stride]
+  const float* U;       // residual (raw), same layout
+  const float* W7;      // conv7 weights, bf16 planes (PACK_CONV_B)
+  const float* b7;
+  const float* alpha2;  // Snake between the convs
+  const float* W1;      // 1x1 weights, bf16 planes
+  const float* b1;
+  const float* alpha_next;   // Snake of the NEXT consumer (Ys) or null
+  float* Y;             // raw output (may alias U) or null
+  float* Ys;            // snake(Y, alpha_next) or null
+  const int* lens;
+  int C, stride;
+  long long bs;
+  int halo_l, xw;
+  int off[kMaxTaps];
+  int fast_sin;
+};
+
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64) void k_resunit(ResP p) {
+  constexpr int QB = 2, NC = 2, RW = 48 / NWV, OPW = RW / 8;   // 64 columns per block; rows / octets staged per wave per 48-channel chunk
+  static_assert(NWV == 3 || NWV == 6, "C = 96 or 192");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  uint4* lds16 = (uint4*)lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, q0 = blockIdx.x * (QB * 32);
+  const int len = p.lens[b];
+  if (q0 >= len) return;
+  const int C = p.C, ksteps = C >> 4, xw = p.xw;
+  const float* Xb = p.Xs + (long long)b * p.bs;
+  f32x16 acc[QB];
+#pragma unroll
+  for (int i = 0; i < QB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float sreg[RW][NC];
+  auto stage_load = [&](int c0) {
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const float* xr = Xb + (long long)(c0 + wave * RW + r) * p.stride;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        const int col = lane + 64 * k, t = q0 - p.halo_l + col;
+        const bool ok = col < xw && t >= 0 && t < len;
+        const float v = xr[t < 0 ? 0 : (t < len ? t : len - 1)];
+        sreg[r][k] = ok ? v : 0.f;
+      }
+    }
+  };
+  auto stage_store = [&]() {
+#pragma unroll
+    for (int g = 0; g < OPW; ++g)
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = sreg[g * 8 + r][k];
+        uint4 hi, mid;
+        split2x8(v, hi, mid);
+        if (lane + 64 * k < xw) {
+          lds16[(size_t)(wave * OPW + g) * xw + lane + 64 * k] = hi;
+          lds16[(size_t)(6 + wave * OPW + g) * xw + lane + 64 * k] = mid;
+        }
+      }
+  };
+  // ---- phase 1: the dilated 7-tap conv, output tile `wave`
+  {
+    const uint4* Wp = (const uint4*)p.W7 + (long long)wave * 7 * ksteps * 128 + lane;
+    stage_load(0);
+    for (int c0 = 0; c0 < C; c0 += 48) {
+      if (c0) __syncthreads();
+      stage_store();
+      __syncthreads();
+      if (c0 + 48 < C) stage_load(c0 + 48);
+      const uint4* Wq = Wp + (long long)(c0 >> 4) * 128;
+      int tap = 0, g = 0;
+      uint4 wh = Wq[0], wm = Wq[64];
+      for (int st = 0; st < 7 * 3; ++st) {
+        int gn = g + 1, tn = tap;
+        if (gn == 3) { gn = 0; ++tn; }
+        if (tn == 7) { tn = tap; gn = g; }
+        const uint4* wnp = Wq + ((long long)tn * ksteps + gn) * 128;
+        const uint4 whn = wnp[0], wmn = wnp[64];
+        __builtin_amdgcn_sched_barrier(0);
+        const uint4* bp = lds16 + (size_t)(2 * g + (lane >> 5)) * xw + p.halo_l + p.off[tap] + (lane & 31);
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, wh), am = __builtin_bit_cast(bf16x8, wm);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[qb * 32]);
+          const bf16x8 bm = __builtin_bit_cast(bf16x8, bp[(size_t)6 * xw + qb * 32]);
+          acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[qb], 0, 0, 0);
+          acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[qb], 0, 0, 0);
+          acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[qb], 0, 0, 0);
+        }
+        wh = whn; wm = wmn; g = gn; tap = tn;
+      }
+    }
+  }
+  // ---- A = snake(conv7 + b7, alpha2) -> the 1x1 conv's B operand in LDS: [plane][octet = channel / 8][64 columns][8 bf16]
+  const int noct = C >> 3;
+  const uint4* W1p = (const uint4*)p.W1 + (long long)wave * ksteps * 128 + lane;
+  uint4 wh = W1p[0], wm = W1p[64];         // the first step's 1x1 weights travel under the Snake arithmetic
+  __syncthreads();                          // every wave has read the last staged chunk: the image may overwrite it
+  {
+    const bool fsin = p.fast_sin != 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float bv[4], av[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const int c = wave * 32 + 8 * k + 4 * (lane >> 5) + e; bv[e] = p.b7[c]; av[e] = p.alpha2[c]; }
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        float a[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = snake_f(acc[qb][4 * k + e] + bv[e], av[e], fsin);
+        const uint32_t h0 = pk_bf16(a[0], a[1]), h1 = pk_bf16(a[2], a[3]);
+        const uint32_t m0 = pk_bf16(a[0] - __uint_as_float(h0 << 16), a[1] - __uint_as_float(h0 & 0xffff0000u));
+        const uint32_t m1 = pk_bf16(a[2] - __uint_as_float(h1 << 16), a[3] - __uint_as_float(h1 & 0xffff0000u));
+        unsigned char* q = (unsigned char*)lds + ((size_t)(wave * 4 + k) * 64 + qb * 32 + (lane & 31)) * 16 + 8 * (lane >> 5);
+        *(uint2*)q = make_uint2(h0, h1);
+        *(uint2*)(q + (size_t)noct * 64 * 16) = make_uint2(m0, m1);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: the 1x1 conv on the image, output tile `wave`
+#pragma unroll
+  for (int i = 0; i < QB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  for (int st = 0; st < ksteps; ++st) {
+    const int sn = st + 1 < ksteps ? st + 1 : st;
+    const uint4 whn = W1p[(long long)sn * 128], wmn = W1p[(long long)sn * 128 + 64];
+    __builtin_amdgcn_sched_barrier(0);
+    const uint4* bp = lds16 + (size_t)(2 * st + (lane >> 5)) * 64 + (lane & 31);
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, wh), am = __builtin_bit_cast(bf16x8, wm);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[qb * 32]);
+      const bf16x8 bm = __builtin_bit_cast(bf16x8, bp[(size_t)noct * 64 + qb * 32]);
+      acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[qb], 0, 0, 0);
+      acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[qb], 0, 0, 0);
+      acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[qb], 0, 0, 0);
+    }
+    wh = whn; wm = wmn;
+  }
+  // ---- epilogue: + b1 + residual; raw and Snake'd outputs (all loads of eight rows first, as in conv_finish)
+  const long long boff = (long long)b * p.bs;
+  const bool hs = p.Ys != nullptr, hy = p.Y != nullptr, fsin = p.fast_sin != 0;
+  bool qok[QB];
+  int tq[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) { const int q = q0 + qb * 32 + (lane & 31); qok[qb] = q < len; tq[qb] = qok[qb] ? q : len - 1; }
+#pragma unroll
+  for (int r0 = 0; r0 < 16; r0 += 8) {
+    float bv[8], av[8], rv[QB][8];
+    int co[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = r0 + i;
+      co[i] = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      bv[i] = p.b1[co[i]];
+      av[i] = (hs ? p.alpha_next : p.b1)[co[i]];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) rv[qb][i] = p.U[boff + (long long)co[i] * p.stride + tq[qb]];
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float y = acc[qb][r0 + i];
+        y = y + bv[i];
+        y = rv[qb][i] + y;
+        if (qok[qb]) {
+          const long long o = boff + (long long)co[i] * p.stride + tq[qb];
+          if (hy) p.Y[o] = y;
+          if (hs) p.Ys[o] = snake_f(y, av[i], fsin);
+        }
+      }
+  }
+}
+
 // Conv1d with ONE output channel (the vocoder's last layer: C -> 1, 7 taps, tanh): y[b][q] = act(bias + sum_ci sum_tap W[ci][tap]
 // x[b][ci][q + off[tap]]).  On the MFMA kernels 31 of a tile's 32 output rows are padding and the layer -- 393 MB of
 // activations at batch 32 -- ran at 0.3 TB/s (1.3 ms); here a thread owns one output sample, rows are read coalesced along time
@@ -909,12 +1102,13 @@ ConvGeom conv_geom(int Cout, int Cin, int K, int dil, int pad, int S, bool bf = 
 }
 
 struct Launch {
-  int kind;          // 0 conv, 1 dwln, 2 codebook, 3 fsq, 4 zero-tail, 9 closure (fn)
+  int kind;          // 0 conv, 1 dwln, 2 codebook, 3 fsq, 4 zero-tail, 5 fused ResidualUnit, 9 closure (fn)
   std::function<void(hipStream_t)> fn;
   std::string name;
   double flops;
   ConvP cp; int qb; bool ks; int chg; int nwv = 4; bool gemv; bool bf = false; bool c1 = false; int c1_len = 0; dim3 grid; size_t lds;
   int tph = 0;       // k_convbT: output phases per block of a transposed conv (0: k_convb, one phase per block)
+  ResP rp; int res_nwv = 0;   // kind 5: a fused ResidualUnit (k_resunit) with res_nwv waves per block
   LnP lp; int cpt;
   // small kernels keep their args here
   const int64_t* sem; int semstride; const float* cb; int D, cbsize; float* Z; int zstride; long long zb;
@@ -1003,6 +1197,10 @@ int run_launch(const Launch& L, hipStream_t st) {
       break;
     case 4:
       hipLaunchKernelGGL(k_zero_tail, L.grid, dim3(256), 0, st, L.wav, L.wstride, L.lens, L.hop);
+      break;
+    case 5:
+      if (L.res_nwv == 3) hipLaunchKernelGGL((k_resunit<3>), L.grid, dim3(192), L.lds, st, L.rp);
+      else hipLaunchKernelGGL((k_resunit<6>), L.grid, dim3(384), L.lds, st, L.rp);
       break;
     case 9:
       L.fn(st);

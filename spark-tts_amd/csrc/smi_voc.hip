@@ -193,19 +193,45 @@ Launch make_conv(const smi_voc* h, const std::string& name, const std::string& w
 
 // ResidualUnit (blocks/layers.py:51-67): y = x + conv1(snake(conv7_dil(snake(x)))).  US holds snake(U, <u>.0.alpha) -- the
 // producer's second output; conv7's epilogue applies the unit's second Snake (-> A); the 1x1 adds the residual U and writes
-// the new U to `rawout` (may be null) and snake(new U, next_alpha) to `US_out` (may be null).
-void add_res_unit(std::vector<Launch>& P, const WSrc& w, const std::string& u, int C, int dil, const float* U, const float* US,
-                  float* A, float* rawout, float* US_out, const float* next_alpha, int L, long long bs, const int* lens, int B) {
+// the new U to `rawout` (may be null) and, if `want_us`, snake(new U, next_alpha) over US (in place: the 7-tap conv has finished
+// with it).  The fused form (k_resunit, below) cannot write over US -- a block's neighbours still read their halo columns from it --
+// and leaves the Snake'd output in A, which it does not otherwise need.  Returns the buffer that holds it (null: none asked for).
+float* add_res_unit(std::vector<Launch>& P, const WSrc& w, const std::string& u, int C, int dil, const float* U, float* US,
+                    float* A, float* rawout, bool want_us, const float* next_alpha, int L, long long bs, const int* lens, int B) {
+  float* US_out = want_us ? US : nullptr;
   P.push_back(make_conv(w, u + ".conv7", u + ".1.weight", (u + ".1.bias").c_str(), C, C, 7, dil, 1, 3 * dil, US, L, bs,
                         nullptr, A, w.get(u + ".2.alpha"), nullptr, L, bs, lens, B, L, ACT_NONE));
   P.push_back(make_conv(w, u + ".conv1+res", u + ".3.weight", (u + ".3.bias").c_str(), C, C, 1, 1, 1, 0, A, L, bs,
                         rawout, US_out, next_alpha, U, L, bs, lens, B, L, ACT_NONE));
+  // C = 96 / 192 on the bf16-split pipe with one output tile per wave (not the channel-split mode of short sequences): the two
+  // launches become one k_resunit (SPARKMI_RESFUSE=0: two launches, A/B).  The choice depends on the layer and on whether the
+  // grid fills the chip, as every launch plan does -- never on a row's neighbours.
+  const Launch& c7 = P[P.size() - 2];
+  const Launch& c1 = P[P.size() - 1];
+  const char* e = smi_env("SPARKMI_RESFUSE");
+  if ((C == 96 || C == 192) && c7.bf && c1.bf && !c7.ks && !c1.ks && c7.cp.W && c1.cp.W && c7.cp.bias && c1.cp.bias && c7.cp.alpha &&
+      c7.cp.xw <= 128 && !(e && e[0] == '0')) {
+    Launch F; F.kind = 5; F.name = u + ".conv7+conv1+res"; F.flops = c7.flops + c1.flops; F.res_nwv = C / 32;
+    ResP& r = F.rp; memset(&r, 0, sizeof(r));
+    r.Xs = US; r.U = U; r.W7 = c7.cp.W; r.b7 = c7.cp.bias; r.alpha2 = c7.cp.alpha; r.W1 = c1.cp.W; r.b1 = c1.cp.bias;
+    r.alpha_next = want_us ? next_alpha : nullptr; r.Y = rawout; r.Ys = want_us ? A : nullptr; r.lens = lens; r.C = C; r.stride = L; r.bs = bs;
+    r.halo_l = c7.cp.halo_l; r.xw = c7.cp.xw; r.fast_sin = c7.cp.fast_sin;
+    for (int i = 0; i < 7; ++i) r.off[i] = c7.cp.off[0][i];
+    F.grid = dim3((L + 63) / 64, 1, B);
+    const size_t stage = (size_t)2 * 6 * r.xw * 16, image = (size_t)2 * (C / 8) * 64 * 16;
+    F.lds = stage > image ? stage : image;
+    P.pop_back(); P.pop_back();
+    P.push_back(F);
+    return F.rp.Ys;
+  }
+  return US_out;
 }
 
 // DecoderBlock (encoder_decoder/wave_generator.py:29-53) on s_in = snake(x, <b>.0.alpha) (left by the producer):
 // ConvTranspose1d (polyphase) -> U raw, US = snake(U, unit 2's first alpha); three ResidualUnits (dilation 1, 3, 9).
-// The last unit writes its raw output to `raw_final` (may be null) and snake(., next_alpha) to US (next_alpha may be null).
-void add_dec_block(std::vector<Launch>& P, const WSrc& w, const std::string& b, int cin, int cout, int k, int s, const float* s_in,
+// The last unit writes its raw output to `raw_final` (may be null) and snake(., next_alpha) (next_alpha may be null) to US or A:
+// the function returns which (a fused unit flips the two; see add_res_unit).
+float* add_dec_block(std::vector<Launch>& P, const WSrc& w, const std::string& b, int cin, int cout, int k, int s, const float* s_in,
                    int Lin, long long bs_in, float* U, float* US, float* A, float* raw_final, const float* next_alpha, long long bs,
                    const int* lens_in, const int* lens_out, int B) {
   const int Lout = Lin * s;
@@ -216,8 +242,10 @@ void add_dec_block(std::vector<Launch>& P, const WSrc& w, const std::string& b, 
     const int dil = r == 0 ? 1 : (r == 1 ? 3 : 9);
     const bool last = r == 2;
     const float* na = last ? next_alpha : w.get(b + "." + std::to_string(r + 3) + ".block.0.alpha");
-    add_res_unit(P, w, u, cout, dil, U, US, A, last ? raw_final : U, (last && !next_alpha) ? nullptr : US, na, Lout, bs, lens_out, B);
+    float* out = add_res_unit(P, w, u, cout, dil, U, US, A, last ? raw_final : U, !(last && !next_alpha), na, Lout, bs, lens_out, B);
+    if (out && out != US) { A = US; US = out; }   // the Snake'd stream now lives in the other buffer; the old one is the next unit's scratch
   }
+  return US;
 }
 
 // LayerNorm / AdaLayerNorm over channels, optionally behind the depthwise conv7 of a ConvNeXt block (k_dwln)
@@ -551,9 +579,8 @@ int smi_voc_forward(smi_voc* h, const int64_t* sem_dev, const int32_t* lens_host
     // NEXT consumer's Snake of the block's result (the next block's, or the output conv's)
     const std::string next_alpha = i + 1 < c.dec_nblocks ? "decoder.model." + std::to_string(i + 2) + ".block.0.alpha"
                                                          : "decoder.model." + std::to_string(c.dec_nblocks + 1) + ".alpha";
-    add_dec_block(P, ws, b, cin, cout, k, s, s_in, Lcur, bs, U, US, A, h->debug ? h->dbg[3 + i] : nullptr, ent(h, next_alpha), bs,
-                  lens_at(i), lens_at(i + 1), B);
-    s_in = US;
+    s_in = add_dec_block(P, ws, b, cin, cout, k, s, s_in, Lcur, bs, U, US, A, h->debug ? h->dbg[3 + i] : nullptr, ent(h, next_alpha), bs,
+                         lens_at(i), lens_at(i + 1), B);
     Lcur = Lout;
   }
   const int clast = ch >> c.dec_nblocks;
@@ -685,7 +712,7 @@ int smi_voc_block_run(const smi_voc_block_cfg* cfg, const void* arena_dev, size_
   if (c.kind == SMI_VOC_BLOCK_RESUNIT) {
     copy_in(buf[0], x_dev, c.C, L);
     copy_in(buf[1], xs_dev, c.C, L);
-    add_res_unit(P, w, "L.block", c.C, c.dil, buf[0], buf[1], buf[4], buf[2], nullptr, nullptr, L, bs, lens_in, B);
+    add_res_unit(P, w, "L.block", c.C, c.dil, buf[0], buf[1], buf[4], buf[2], false, nullptr, L, bs, lens_in, B);
     result = buf[2];
   } else if (c.kind == SMI_VOC_BLOCK_DECBLOCK) {
     copy_in(buf[1], xs_dev, c.C, L);

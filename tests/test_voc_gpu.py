@@ -190,3 +190,28 @@ def test_multi_phase_transposed_convs_at_batch(full_voc, monkeypatch):
         solo = new.detokenize(sem[b:b + 1, :lens[b]], glob[b:b + 1]).cpu().numpy()
         assert np.abs(solo[0, :, : lens[b] * cfg.hop] - w_new[b, :, : lens[b] * cfg.hop]).max() < 1e-4
         assert not w_new[b, :, lens[b] * cfg.hop:].any()
+
+
+def test_fused_residual_units_agree_with_the_two_launch_form(full_voc, golden_dir, monkeypatch):
+    """k_resunit runs a whole ResidualUnit -- 7-tap conv, Snake, 1x1 conv, residual -- in one launch at C = 96 and 192 (a block
+    holds every channel of its time tile; the 7-tap conv's output never leaves the CU).  Same products as the two launches; its
+    7-tap sum walks 48- instead of 32-channel chunks: the waveform agrees with the two-launch form (SPARKMI_RESFUSE=0,
+    diagnostics build) to fp32 re-association and with the reference's own vector within the usual bound; six launches fewer."""
+    cfg, sd, _ = full_voc
+    g = np.load(os.path.join(golden_dir, "vocoder_full.npz"))
+    T = 150
+    sem = np.zeros((2, T), np.int64)
+    sem[0], sem[1, :23] = g["c0_semantic"][0], g["c1_semantic"][0]
+    glob = np.concatenate([g["c0_global"], g["c1_global"]])
+    fused = _voc(cfg, sd, max_batch=2, max_frames=160, diag=False)
+    wf = fused.detokenize(torch.from_numpy(sem), torch.from_numpy(glob), lengths=[150, 23]).cpu().numpy()
+    names = [fused.time_launch(i, iters=1)[0] for i in range(fused.launches())]
+    assert sum(n.endswith(".conv7+conv1+res") for n in names) == 6, names
+    monkeypatch.setenv("SPARKMI_RESFUSE", "0")
+    two = _voc(cfg, sd, max_batch=2, max_frames=160, diag=True)
+    wt = two.detokenize(torch.from_numpy(sem), torch.from_numpy(glob), lengths=[150, 23]).cpu().numpy()
+    assert two.launches() == fused.launches() + 6
+    assert np.abs(wf - wt).max() < 2e-5
+    assert np.abs(wf[0] - g["c0_wav"][0]).max() < 3e-4
+    assert np.abs(wf[1, :, : 23 * 320] - g["c1_wav"][0]).max() < 3e-4
+    assert not wf[1, :, 23 * 320:].any()
