@@ -331,10 +331,11 @@ __device__ __forceinline__ void split2x8(const float (&v)[8], uint4& hi, uint4& 
 #ifndef SMI_CB_OCC
 #define SMI_CB_OCC 4
 #endif
-template <int QB, bool KS, int CHG, int NC, bool WPF = false>
-__global__ __launch_bounds__(256, SMI_CB_OCC) void k_convb(ConvP p) {
+template <int QB, bool KS, int CHG, int NC, bool WPF = false, bool WALL = false>
+__global__ __launch_bounds__(256, WALL ? 2 : SMI_CB_OCC) void k_convb(ConvP p) {
   static_assert(!KS || CHG % 2 == 0, "channel-split waves own whole 16-channel steps");
   static_assert(!WPF || (KS && CHG == 4), "WPF: one-tap layers with the channels split over the waves, 128-channel chunks");
+  static_assert(!WALL || (KS && CHG == 2 && !WPF), "WALL: several taps, the channels split over the waves, one 16-channel step per wave and chunk");
   constexpr int kCh = 32 * CHG;        // channels per staged chunk (four waves x CHG octets)
   constexpr int NOCT = 4 * CHG;        // octets per chunk
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -427,6 +428,53 @@ __global__ __launch_bounds__(256, SMI_CB_OCC) void k_convb(ConvP p) {
           if ((c0 >> 4) + wave * 2 + g < ksl) {   // wave-uniform
             const uint4* bp = lds16 + (size_t)(2 * (wave * 2 + g) + (lane >> 5)) * xw + col0;
             const bf16x8 ah = __builtin_bit_cast(bf16x8, wc[2 * g]), am = __builtin_bit_cast(bf16x8, wc[2 * g + 1]);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+              const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[qb * 32]);
+              const bf16x8 bm = __builtin_bit_cast(bf16x8, bp[(size_t)NOCT * xw + qb * 32]);
+              acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[qb], 0, 0, 0);
+              acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[qb], 0, 0, 0);
+              acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[qb], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    conv_finish<QB, KS>(p, acc, lds, ct, live, b, phase, q0, olen, lane, wave);
+    return;
+  }
+  if constexpr (WALL) {
+    // Several taps, the channels split over the waves, launched with about a block per CU (one utterance: the 7-tap convs at C = 768 /
+    // 384, conv_in, the prenet's embed convs, the transposed convs of the first two decoder blocks).  A wave's chunk is ONE 16-channel
+    // step x taps; with the next tap's weights requested one step ahead the taps were a chain of dependent round trips to cold
+    // weights -- 7 x ~0.8 us per chunk, 72 us for the 7-tap conv at C = 768 where its MFMAs need 7.  Here ALL taps' weight planes of the
+    // chunk (<= 8 x 2 KiB per wave: 64 registers, hence two waves per SIMD) are requested together at the top of the chunk, behind the
+    // staged rows requested one chunk earlier: one round trip per chunk.  Same taps in the same order: same bits.
+    stage_load(0);
+    for (int c0 = 0; c0 < p.CinP; c0 += kCh) {
+      const int stp = (c0 >> 4) + wave;                 // this wave's 16-channel step of the chunk
+      const bool has = live && stp < ksteps;             // wave-uniform
+      uint4 wt[kMaxTaps][2];
+      {
+        const uint4* Wq = Wp + (long long)(stp < ksteps ? stp : ksteps - 1) * 128 + lane;
+#pragma unroll
+        for (int t = 0; t < kMaxTaps; ++t) {
+          const int tc = t < ntap ? t : ntap - 1;
+          wt[t][0] = live ? Wq[(long long)tc * ksteps * 128] : make_uint4(0u, 0u, 0u, 0u);
+          wt[t][1] = live ? Wq[(long long)tc * ksteps * 128 + 64] : make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
+      if (c0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stage_store();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (c0 + kCh < p.CinP) stage_load(c0 + kCh);
+      if (has) {
+#pragma unroll
+        for (int t = 0; t < kMaxTaps; ++t) {
+          if (t < ntap) {   // uniform
+            const int col0 = p.halo_l + p.off[phase][t] + (lane & 31);
+            const uint4* bp = lds16 + (size_t)(2 * wave + (lane >> 5)) * xw + col0;
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, wt[t][0]), am = __builtin_bit_cast(bf16x8, wt[t][1]);
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
               const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[qb * 32]);
@@ -1137,8 +1185,17 @@ int run_launch(const Launch& L, hipStream_t st) {
           else if (L.ks) { if (L.qb == 1) SMI_CB(1, true, 4, 1); else SMI_CB(2, true, 4, 1); }
           else { if (L.qb == 1) SMI_CB(1, false, 4, 1); else SMI_CB(2, false, 4, 1); }
         } else if (L.ks) {
-          if (L.qb == 1) { if (wide) SMI_CB(1, true, 2, 2); else SMI_CB(1, true, 2, 1); }
+          // several taps on a grid of about a block per CU: all taps' weights of a chunk requested together (WALL)
+          int mt = 0;
+          for (int r = 0; r < L.cp.S; ++r) mt = L.cp.ntaps[r] > mt ? L.cp.ntaps[r] : mt;
+          // (measured at one / two utterances, 150 frames: 7-tap convs 71 -> 62 us at 456 blocks but 101 -> 115 at 912; the first transposed conv,
+          // 2 taps per phase, 85 -> 129 us: stride-1 layers with four taps or more on at most two blocks per CU)
+          const bool wall = L.chg == 2 && mt >= 4 && L.cp.S == 1 && (long long)L.grid.x * L.grid.y * L.grid.z <= 512 && !smi_env("SPARKMI_CB_NOWALL");
+#define SMI_CBW(QB_, NC_) hipLaunchKernelGGL((k_convb<QB_, true, 2, NC_, false, true>), L.grid, dim3(256), L.lds, st, L.cp)
+          if (wall) { if (L.qb == 1) { if (wide) SMI_CBW(1, 2); else SMI_CBW(1, 1); } else SMI_CBW(2, 2); }
+          else if (L.qb == 1) { if (wide) SMI_CB(1, true, 2, 2); else SMI_CB(1, true, 2, 1); }
           else SMI_CB(2, true, 2, 2);
+#undef SMI_CBW
         } else if (L.chg == 2) {    // few taps per phase, rows wider than 64 columns (transposed convs): 64-channel chunks
           if (L.qb == 1) SMI_CB(1, false, 2, 2); else SMI_CB(2, false, 2, 2);
         } else {
