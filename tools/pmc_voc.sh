@@ -18,7 +18,7 @@ acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(lambda: default
 for f in glob.glob("gpurun_out/pmcvoc_${tag}_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]).split("(")[0].replace("void ", "")
-        if not name.startswith("k_conv"): continue
+        if not name.startswith(("k_conv", "k_resunit")): continue
         k = (name, r.get("Grid_Size", ""))
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
 print("# per launch averages; SQ_* wave counters are quad-cycles summed over waves")
