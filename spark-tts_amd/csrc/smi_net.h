@@ -267,24 +267,36 @@ __global__ __launch_bounds__(256) void k_conv(ConvP p) {
       gl = gl < gcap ? gl : gcap;
       const int nstep = gl > 0 ? ntap * gl : 0;
       const f32x4v* Wq = (const f32x4v*)Wp + ((long long)(c0 >> 3) + gbase) * 64 + lane;
-      int tap = 0, g = 0;
-      f32x4v wv = *(gl > 0 ? Wq : (const f32x4v*)Wp + lane);   // (no live group: any valid address of this tile's weights, unused)
-      for (int st = 0; st < nstep; ++st) {
-        int gn = g + 1, tn = tap;
-        if (gn == gl) { gn = 0; ++tn; }
-        if (tn == ntap) { tn = tap; gn = g; }   // last step: re-request the current weights (no branch around the load)
-        const f32x4v wn = Wq[((long long)tn * groups + gn) * 64];
-        __builtin_amdgcn_sched_barrier(0);
-        const int col0 = p.halo_l + p.off[phase][tap] + (lane & 31) * p.istr;
+      // two weight registers used in turn (see k_convb's step loop: one register rotated with `wv = wn` makes hipcc wait for the
+      // weights it has just requested in the middle of the current step)
+      auto advance = [&](int& t, int& gg) { if (++gg == gl) { gg = 0; ++t; } };
+      auto wptr = [&](int t, int gg) { return Wq + ((long long)(t < ntap ? t : ntap - 1) * groups + gg) * 64; };
+      auto step = [&](const f32x4v& wv, int t, int gg) {
+        const int col0 = p.halo_l + p.off[phase][t] + (lane & 31) * p.istr;
         const float wa[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float* xr = lds + ((gbase + g) * 8 + j * 2 + (lane >> 5)) * xw + col0;
+          const float* xr = lds + ((gbase + gg) * 8 + j * 2 + (lane >> 5)) * xw + col0;
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb)
             acc[qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], xr[qb * 32 * p.istr], acc[qb], 0, 0, 0);
         }
-        wv = wn; g = gn; tap = tn;
+      };
+      if (nstep > 0) {
+        int ta = 0, ga = 0;
+        f32x4v wa_ = Wq[0];
+        for (int st = 0; st < nstep; st += 2) {
+          int tb = ta, gb = ga;
+          advance(tb, gb);
+          const f32x4v wb_ = *wptr(tb, gb);
+          __builtin_amdgcn_sched_barrier(0);
+          step(wa_, ta, ga);
+          ta = tb; ga = gb;
+          advance(ta, ga);
+          wa_ = *wptr(ta, ga);
+          __builtin_amdgcn_sched_barrier(0);
+          if (st + 1 < nstep) step(wb_, tb, gb);
+        }
       }
     }
   }
@@ -504,17 +516,16 @@ __global__ __launch_bounds__(256, WALL ? 2 : SMI_CB_OCC) void k_convb(ConvP p) {
       sl = sl < scap ? sl : scap;
       const int nstep = sl > 0 ? ntap * sl : 0;
       const uint4* Wq = Wp + ((long long)(c0 >> 4) + sbase) * 128 + lane;
-      int tap = 0, g = 0;
-      uint4 wh = sl > 0 ? Wq[0] : Wp[lane], wm = sl > 0 ? Wq[64] : Wp[lane];
-      for (int st = 0; st < nstep; ++st) {
-        int gn = g + 1, tn = tap;
-        if (gn == sl) { gn = 0; ++tn; }
-        if (tn == ntap) { tn = tap; gn = g; }   // last step: re-request the current weights (no branch around the load)
-        const uint4* wnp = Wq + ((long long)tn * ksteps + gn) * 128;
-        const uint4 whn = wnp[0], wmn = wnp[64];
-        __builtin_amdgcn_sched_barrier(0);
-        const int col0 = p.halo_l + p.off[phase][tap] + (lane & 31);
-        const uint4* bp = lds16 + (size_t)(2 * (sbase + g) + (lane >> 5)) * xw + col0;
+      // Two weight sets, A and B, used in turn (the loop advances two steps per trip): written as ONE set with `w = w_next` at the end
+      // of a step, hipcc copies the registers there and waits vmcnt(0) for the just-requested next weights in the MIDDLE of the
+      // current step's MFMAs (round-4 ISA of the 7-tap conv: every step exposed a whole L2 round trip; the prefetch hid nothing).
+      // A set that is loaded straight into its own registers after its last use needs no copy, and the wait in front of a step's
+      // MFMAs leaves the other set's request in flight.
+      auto advance = [&](int& t, int& gg) { if (++gg == sl) { gg = 0; ++t; } };
+      auto wptr = [&](int t, int gg) { return Wq + ((long long)(t < ntap ? t : ntap - 1) * ksteps + gg) * 128; };   // (past the end: a valid address, never used)
+      auto step = [&](const uint4& wh, const uint4& wm, int t, int gg) {
+        const int col0 = p.halo_l + p.off[phase][t] + (lane & 31);
+        const uint4* bp = lds16 + (size_t)(2 * (sbase + gg) + (lane >> 5)) * xw + col0;
         const bf16x8 ah = __builtin_bit_cast(bf16x8, wh), am = __builtin_bit_cast(bf16x8, wm);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
@@ -524,7 +535,24 @@ __global__ __launch_bounds__(256, WALL ? 2 : SMI_CB_OCC) void k_convb(ConvP p) {
           acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[qb], 0, 0, 0);
           acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[qb], 0, 0, 0);
         }
-        wh = whn; wm = wmn; g = gn; tap = tn;
+      };
+      if (nstep > 0) {
+        int ta = 0, ga = 0;                      // set A's step
+        uint4 wah = Wq[0], wam = Wq[64];
+        for (int st = 0; st < nstep; st += 2) {
+          int tb = ta, gb = ga;
+          advance(tb, gb);                       // set B's step = A's successor
+          const uint4* pb = wptr(tb, gb);
+          const uint4 wbh = pb[0], wbm = pb[64];
+          __builtin_amdgcn_sched_barrier(0);
+          step(wah, wam, ta, ga);
+          ta = tb; ga = gb;
+          advance(ta, ga);                       // A's next step = B's successor
+          const uint4* pa = wptr(ta, ga);
+          wah = pa[0]; wam = pa[64];
+          __builtin_amdgcn_sched_barrier(0);
+          if (st + 1 < nstep) step(wbh, wbm, tb, gb);
+        }
       }
     }
   }
@@ -612,23 +640,21 @@ __global__ __launch_bounds__(256, 3) void k_convbT(ConvP p) {
       int sl = ksteps - (c0 >> 4);
       sl = sl < 2 * CHG ? sl : 2 * CHG;            // live 16-channel steps of this chunk (>= 1)
       const long long so = (long long)(c0 >> 4) * 128;
-      uint4 wh, wm;
-      { const uint4* w0 = wbase(phase0) + so; wh = w0[0]; wm = w0[64]; }
+      // two weight sets used in turn, as in k_convb (a single set rotated with `w = w_next` makes hipcc wait for the just-requested
+      // weights in the middle of the current step); a phase's last step requests the NEXT phase's first weights
+      uint4 wah, wam;
+      { const uint4* w0 = wbase(phase0) + so; wah = w0[0]; wam = w0[64]; }
 #pragma unroll
       for (int h = 0; h < PH; ++h) {
         const int phase = phase0 + h, ntap = p.ntaps[phase];
         const uint4* Wq = wbase(phase) + so;
         const uint4* Wnext = wbase(h + 1 < PH ? phase + 1 : phase) + so;   // the next phase's first step (last phase: any valid address)
         const int nstep = ntap * sl;
-        int tap = 0, g = 0;
-        for (int st = 0; st < nstep; ++st) {
-          int gn = g + 1, tn = tap;
-          if (gn == sl) { gn = 0; ++tn; }
-          const uint4* wnp = tn == ntap ? Wnext : Wq + ((long long)tn * ksteps + gn) * 128;
-          const uint4 whn = wnp[0], wmn = wnp[64];
-          __builtin_amdgcn_sched_barrier(0);
-          const int col0 = p.halo_l + p.off[phase][tap] + (lane & 31);
-          const uint4* bp = lds16 + (size_t)(2 * g + (lane >> 5)) * xw + col0;
+        auto advance = [&](int& t, int& gg) { if (++gg == sl) { gg = 0; ++t; } };
+        auto wptr = [&](int t, int gg) { return t >= ntap ? Wnext : Wq + ((long long)t * ksteps + gg) * 128; };
+        auto step = [&](const uint4& wh, const uint4& wm, int t, int gg) {
+          const int col0 = p.halo_l + p.off[phase][t] + (lane & 31);
+          const uint4* bp = lds16 + (size_t)(2 * gg + (lane >> 5)) * xw + col0;
           const bf16x8 ah = __builtin_bit_cast(bf16x8, wh), am = __builtin_bit_cast(bf16x8, wm);
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb) {
@@ -638,7 +664,25 @@ __global__ __launch_bounds__(256, 3) void k_convbT(ConvP p) {
             acc[h][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[h][qb], 0, 0, 0);
             acc[h][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[h][qb], 0, 0, 0);
           }
-          wh = whn; wm = wmn; g = gn; tap = tn;
+        };
+        int ta = 0, ga = 0;
+        for (int st = 0; st < nstep; st += 2) {
+          int tb = ta, gb = ga;
+          advance(tb, gb);
+          const uint4* pb = wptr(tb, gb);                 // (an odd step count: the phase's successor, i.e. the next phase's first weights)
+          uint4 wbh = pb[0], wbm = pb[64];
+          __builtin_amdgcn_sched_barrier(0);
+          step(wah, wam, ta, ga);
+          if (st + 1 < nstep) {
+            ta = tb; ga = gb;
+            advance(ta, ga);
+            const uint4* pa = wptr(ta, ga);
+            wah = pa[0]; wam = pa[64];
+            __builtin_amdgcn_sched_barrier(0);
+            step(wbh, wbm, tb, gb);
+          } else {
+            wah = wbh; wam = wbm;                          // odd count: B already holds the next phase's first weights
+          }
         }
       }
     }
@@ -776,16 +820,11 @@ __global__ __launch_bounds__(NWV * 64) void k_resunit(ResP p) {
       __syncthreads();
       if (c0 + 48 < C) stage_load(c0 + 48);
       const uint4* Wq = Wp + (long long)(c0 >> 4) * 128;
-      int tap = 0, g = 0;
-      uint4 wh = Wq[0], wm = Wq[64];
-      for (int st = 0; st < 7 * 3; ++st) {
-        int gn = g + 1, tn = tap;
-        if (gn == 3) { gn = 0; ++tn; }
-        if (tn == 7) { tn = tap; gn = g; }
-        const uint4* wnp = Wq + ((long long)tn * ksteps + gn) * 128;
-        const uint4 whn = wnp[0], wmn = wnp[64];
-        __builtin_amdgcn_sched_barrier(0);
-        const uint4* bp = lds16 + (size_t)(2 * g + (lane >> 5)) * xw + p.halo_l + p.off[tap] + (lane & 31);
+      // 7 taps x 3 steps, two weight sets used in turn (k_convb's step loop: no register rotation, no wait for the set just requested)
+      auto advance = [&](int& t, int& gg) { if (++gg == 3) { gg = 0; ++t; } };
+      auto wptr = [&](int t, int gg) { return Wq + ((long long)(t < 7 ? t : 6) * ksteps + gg) * 128; };
+      auto step = [&](const uint4& wh, const uint4& wm, int t, int gg) {
+        const uint4* bp = lds16 + (size_t)(2 * gg + (lane >> 5)) * xw + p.halo_l + p.off[t] + (lane & 31);
         const bf16x8 ah = __builtin_bit_cast(bf16x8, wh), am = __builtin_bit_cast(bf16x8, wm);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
@@ -795,7 +834,22 @@ __global__ __launch_bounds__(NWV * 64) void k_resunit(ResP p) {
           acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[qb], 0, 0, 0);
           acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[qb], 0, 0, 0);
         }
-        wh = whn; wm = wmn; g = gn; tap = tn;
+      };
+      int ta = 0, ga = 0;
+      uint4 wah = Wq[0], wam = Wq[64];
+      for (int st = 0; st < 7 * 3; st += 2) {
+        int tb = ta, gb = ga;
+        advance(tb, gb);
+        const uint4* pb = wptr(tb, gb);
+        const uint4 wbh = pb[0], wbm = pb[64];
+        __builtin_amdgcn_sched_barrier(0);
+        step(wah, wam, ta, ga);
+        ta = tb; ga = gb;
+        advance(ta, ga);
+        const uint4* pa = wptr(ta, ga);
+        wah = pa[0]; wam = pa[64];
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < 7 * 3) step(wbh, wbm, tb, gb);
       }
     }
   }
@@ -831,21 +885,28 @@ __global__ __launch_bounds__(NWV * 64) void k_resunit(ResP p) {
   for (int i = 0; i < QB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  for (int st = 0; st < ksteps; ++st) {
-    const int sn = st + 1 < ksteps ? st + 1 : st;
-    const uint4 whn = W1p[(long long)sn * 128], wmn = W1p[(long long)sn * 128 + 64];
-    __builtin_amdgcn_sched_barrier(0);
-    const uint4* bp = lds16 + (size_t)(2 * st + (lane >> 5)) * 64 + (lane & 31);
-    const bf16x8 ah = __builtin_bit_cast(bf16x8, wh), am = __builtin_bit_cast(bf16x8, wm);
+  {
+    auto step2 = [&](const uint4& xh, const uint4& xm, int st) {
+      const uint4* bp = lds16 + (size_t)(2 * st + (lane >> 5)) * 64 + (lane & 31);
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, xh), am = __builtin_bit_cast(bf16x8, xm);
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-      const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[qb * 32]);
-      const bf16x8 bm = __builtin_bit_cast(bf16x8, bp[(size_t)noct * 64 + qb * 32]);
-      acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[qb], 0, 0, 0);
-      acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[qb], 0, 0, 0);
-      acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[qb], 0, 0, 0);
+      for (int qb = 0; qb < QB; ++qb) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[qb * 32]);
+        const bf16x8 bm = __builtin_bit_cast(bf16x8, bp[(size_t)noct * 64 + qb * 32]);
+        acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[qb], 0, 0, 0);
+        acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[qb], 0, 0, 0);
+        acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[qb], 0, 0, 0);
+      }
+    };
+    for (int st = 0; st < ksteps; st += 2) {      // ksteps = C / 16 = 6 or 12: even; (wh, wm) is set A, already requested
+      const uint4 wbh = W1p[(long long)(st + 1) * 128], wbm = W1p[(long long)(st + 1) * 128 + 64];
+      __builtin_amdgcn_sched_barrier(0);
+      step2(wh, wm, st);
+      const int sn = st + 2 < ksteps ? st + 2 : st;
+      wh = W1p[(long long)sn * 128]; wm = W1p[(long long)sn * 128 + 64];
+      __builtin_amdgcn_sched_barrier(0);
+      step2(wbh, wbm, st + 1);
     }
-    wh = whn; wm = wmn;
   }
   // ---- epilogue: + b1 + residual; raw and Snake'd outputs (all loads of eight rows first, as in conv_finish)
   const long long boff = (long long)b * p.bs;
