@@ -2579,14 +2579,20 @@ __global__ __launch_bounds__(256) void k_attn_pf2(AttnP p, const PfTile* tiles, 
     return acc;
   };
   // ---- pass 1: the queries' maxima (the next block's K rows are requested before this block's MFMAs)
+  // (two register sets used in turn, two key blocks per trip: with one set and `kc = kn` at the end of a trip hipcc copies the registers
+  // there and waits vmcnt(0) -- for the block it has just requested -- in front of the trip's last MFMA: round-4 ISA)
   float mx = NEG;
   {
-    KReg kc = kload(0);
-    for (int kb = 0; kb < nblk; ++kb) {
-      const KReg kn = kload(kb + 1 < nblk ? kb + 1 : kb);
-      const f32x4 sc = scores(kb, kc);
-      mx = fmaxf(mx, fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
-      kc = kn;
+    KReg ka = kload(0);
+    for (int kb = 0; kb < nblk; kb += 2) {
+      const KReg kbr = kload(kb + 1 < nblk ? kb + 1 : kb);
+      const f32x4 sa = scores(kb, ka);
+      mx = fmaxf(mx, fmaxf(fmaxf(sa[0], sa[1]), fmaxf(sa[2], sa[3])));
+      ka = kload(kb + 2 < nblk ? kb + 2 : kb);
+      if (kb + 1 < nblk) {
+        const f32x4 sb = scores(kb + 1, kbr);
+        mx = fmaxf(mx, fmaxf(fmaxf(sb[0], sb[1]), fmaxf(sb[2], sb[3])));
+      }
     }
   }
   mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -2607,14 +2613,8 @@ __global__ __launch_bounds__(256) void k_attn_pf2(AttnP p, const PfTile* tiles, 
     }
     return r;
   };
-  KReg kc = kload(0);
-  VReg vc = vload(0);
-  for (int kb = 0; kb < nblk; ++kb) {
-    const int kbn = kb + 1 < nblk ? kb + 1 : kb;
-    const KReg kn = kload(kbn);
-    const VReg vn = vload(kbn);
-    const uint2* vraw = vc.v;
-    const f32x4 sc = scores(kb, kc);
+  auto pv = [&](int kb, const KReg& kr, const VReg& vr) {
+    const f32x4 sc = scores(kb, kr);
     float pr[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -2623,14 +2623,24 @@ __global__ __launch_bounds__(256) void k_attn_pf2(AttnP p, const PfTile* tiles, 
     }
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
-      const float v0 = __uint_as_float(vraw[tt].x << 16), v1 = __uint_as_float(vraw[tt].x & 0xffff0000u);
-      const float v2 = __uint_as_float(vraw[tt].y << 16), v3 = __uint_as_float(vraw[tt].y & 0xffff0000u);
+      const float v0 = __uint_as_float(vr.v[tt].x << 16), v1 = __uint_as_float(vr.v[tt].x & 0xffff0000u);
+      const float v2 = __uint_as_float(vr.v[tt].y << 16), v3 = __uint_as_float(vr.v[tt].y & 0xffff0000u);
       o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[tt], v0, o[0], 0, 0, 0);
       o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[tt], v1, o[1], 0, 0, 0);
       o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[tt], v2, o[2], 0, 0, 0);
       o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[tt], v3, o[3], 0, 0, 0);
     }
-    kc = kn; vc = vn;
+  };
+  KReg ka = kload(0);
+  VReg va = vload(0);
+  for (int kb = 0; kb < nblk; kb += 2) {     // sets A and B in turn (see pass 1); the key blocks are visited in the same order
+    const int k1 = kb + 1 < nblk ? kb + 1 : kb, k2 = kb + 2 < nblk ? kb + 2 : kb;
+    const KReg kbr = kload(k1);
+    const VReg vbr = vload(k1);
+    pv(kb, ka, va);
+    ka = kload(k2);
+    va = vload(k2);
+    if (kb + 1 < nblk) pv(kb + 1, kbr, vbr);
   }
   lsum += __shfl_xor(lsum, 16, 64);
   lsum += __shfl_xor(lsum, 32, 64);               // lane (any g, j): the sum for query j
