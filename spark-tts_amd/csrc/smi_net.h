@@ -412,6 +412,77 @@ __global__ __launch_bounds__(256, WALL ? 2 : SMI_CB_OCC) void k_convb(ConvP p) {
     // there were three of them per chunk (staged rows, first step's weights, second step's weights: ~3 us per chunk, 35 us per
     // layer).  Here the chunk's weights -- two steps x two planes, 16 registers -- are requested one chunk ahead together with
     // its staged rows: one round trip per chunk, hidden behind the previous chunk.  Same steps in the same order: same bits.
+    if constexpr (QB == 1) {
+      // One 32-column tile (short sequences): lanes 32-63 would idle in a row load, so a load instruction takes TWO rows (lanes 0-31 row j,
+      // lanes 32-63 row 16 + j of the wave's 32): 16 + 4 loads per chunk -- and with 20 instead of 36 loads per chunk TWO chunks fit the
+      // 6-bit vmcnt: two register sets, A and B, used in turn, every request unconditional (past the end: clamped addresses, masked
+      // values, skipped steps) so that hipcc can count what is in flight: a chunk's round trip hides behind the chunk before it AND the
+      // one being multiplied.  (With 36 loads per set the counter overflowed and the waits drained to vmcnt(0): measured, no gain.)
+      const int rh = lane >> 5, colq = lane & 31;
+      auto loadx = [&](float (&sr)[16], uint4 (&wq)[4], int c0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int ci = c0 + wave * RW + rh * 16 + j;
+          const float* xr = Xb + (long long)(ci < p.Cin ? ci : p.Cin - 1) * p.xstride;
+          const int t = q0 - p.halo_l + colq;
+          sr[j] = xr[t < 0 ? 0 : (t < len ? t : len - 1)];
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          int st = (c0 >> 4) + wave * 2 + g;
+          st = st < ksteps ? st : ksteps - 1;
+          wq[2 * g] = Wp[(long long)st * 128 + lane];          // (channel-split mode: every block's output tile is live)
+          wq[2 * g + 1] = Wp[(long long)st * 128 + 64 + lane];
+        }
+      };
+      const int col0 = p.halo_l + p.off[phase][0] + (lane & 31);
+      auto chunk = [&](float (&sr)[16], uint4 (&wq)[4], int c0, bool first) {
+        if (!first) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous chunk's LDS reads are done
+        const int t = q0 - p.halo_l + colq;
+        const bool okc = colq < xw && t >= 0 && t < len;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = (okc && c0 + wave * RW + rh * 16 + o * 8 + r < p.Cin) ? sr[o * 8 + r] : 0.f;
+          uint4 hi, mid;
+          split2x8(v, hi, mid);
+          if (colq < xw) {
+            lds16[(size_t)(wave * CHG + 2 * rh + o) * xw + colq] = hi;
+            lds16[(size_t)(NOCT + wave * CHG + 2 * rh + o) * xw + colq] = mid;
+          }
+        }
+        uint4 wc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wc[i] = wq[i];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        loadx(sr, wq, c0 + 2 * kCh);                                       // this set's next chunk: two chunks ahead, unconditionally
+        if (live) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            if ((c0 >> 4) + wave * 2 + g < ksteps) {   // wave-uniform
+              const uint4* bp = lds16 + (size_t)(2 * (wave * 2 + g) + (lane >> 5)) * xw + col0;
+              const bf16x8 ah = __builtin_bit_cast(bf16x8, wc[2 * g]), am = __builtin_bit_cast(bf16x8, wc[2 * g + 1]);
+              const bf16x8 bh = __builtin_bit_cast(bf16x8, bp[0]);
+              const bf16x8 bm = __builtin_bit_cast(bf16x8, bp[(size_t)NOCT * xw]);
+              acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[0], 0, 0, 0);
+              acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[0], 0, 0, 0);
+              acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[0], 0, 0, 0);
+            }
+          }
+        }
+      };
+      float sa[16], sb[16];
+      uint4 wa[4], wb[4];
+      loadx(sa, wa, 0);
+      loadx(sb, wb, kCh);
+      for (int c0 = 0; c0 < p.CinP; c0 += 2 * kCh) {   // chunks in pairs (an odd count ends with a chunk of masked rows and skipped steps)
+        chunk(sa, wa, c0, c0 == 0);
+        chunk(sb, wb, c0 + kCh, false);
+      }
+      conv_finish<QB, KS>(p, acc, lds, ct, live, b, phase, q0, olen, lane, wave);
+      return;
+    }
     uint4 wn[4];
     const int ksl = ksteps;   // (steps past the last one multiply zero rows: their weights are clamped loads, never used)
     auto wload = [&](int c0) {
