@@ -215,3 +215,31 @@ def test_fused_residual_units_agree_with_the_two_launch_form(full_voc, golden_di
     assert np.abs(wf[0] - g["c0_wav"][0]).max() < 3e-4
     assert np.abs(wf[1, :, : 23 * 320] - g["c1_wav"][0]).max() < 3e-4
     assert not wf[1, :, 23 * 320:].any()
+
+
+def test_round4_conv_kernels_at_odd_shapes(full_voc, monkeypatch):
+    """The round-4 kernels (multi-phase transposed convs, fused residual units, the small-grid prefetch forms) at a frame count that is
+    no multiple of any tile (97 frames -> 31 040 samples: partial last tiles at every resolution) in a ragged 9-row batch, against the
+    same call with all of them switched off (diagnostics build): fp32 re-association only (the fused unit's 48-channel chunks), rows
+    zero behind their own length."""
+    cfg, sd, _ = full_voc
+    rng = np.random.Generator(np.random.PCG64(79))
+    B, T = 9, 97
+    lens = [97, 96, 65, 64, 63, 33, 32, 31, 2]
+    sem = torch.from_numpy(rng.integers(0, cfg.codebook_size, size=(B, T)))
+    glob = torch.from_numpy(rng.integers(0, 4096, size=(B, 1, cfg.spk_token_num)))
+    new = _voc(cfg, sd, max_batch=B, max_frames=T + 3, diag=False)
+    w_new = new.detokenize(sem, glob, lengths=lens).cpu().numpy()
+    names = [new.time_launch(i, iters=1)[0] for i in range(new.launches())]
+    assert sum(n.endswith(".conv7+conv1+res") for n in names) == 6
+    for k in ("SPARKMI_CBT", "SPARKMI_RESFUSE", "SPARKMI_CB_CHG"):
+        monkeypatch.setenv(k, "0")
+    monkeypatch.setenv("SPARKMI_CB_NOWPF", "1")
+    monkeypatch.setenv("SPARKMI_CB_NOWALL", "1")
+    old = _voc(cfg, sd, max_batch=B, max_frames=T + 3, diag=True)
+    w_old = old.detokenize(sem, glob, lengths=lens).cpu().numpy()
+    assert old.launches() == new.launches() + 6
+    assert np.abs(w_new - w_old).max() < 2e-5
+    for b in range(B):
+        assert not w_new[b, :, lens[b] * cfg.hop:].any()
+        assert np.abs(w_new[b, :, : lens[b] * cfg.hop]).max() > 1e-3
